@@ -1,0 +1,310 @@
+// Fused (flash-style) attention for LtxAttention::forward (ltx_transformer.rs:648-750):
+//   O = softmax(scale * Q K^T + key_bias) V   per (batch, head), non-causal.
+// The reference either calls candle-flash-attn (bf16, self-attention on GPU, :699-712) or
+// materialises the f32 [B,H,Sq,Sk] score matrix (:719-740); this kernel never materialises it.
+//
+// bf16 kernel (MFMA, gfx950):
+//   * workgroup = 4 waves = 128 queries of one head; wave = 32 queries; KV tile = 64 keys,
+//     K and V tiles double-buffered in LDS (register-staged prefetch, one barrier per tile);
+//   * "swapped" QK^T: S^T[key][query] = K . Q^T with v_mfma_f32_32x32x16_bf16, so a lane owns ONE
+//     query column and 16 keys per 32-key block -> the softmax row reduction is in-register plus
+//     one cross-half exchange (lanes l and l^32 hold the other 16 keys of the same query);
+//   * P never leaves registers: the S^T accumulator, rounded pairwise to bf16, is directly the
+//     B operand of O^T[d][query] += V^T[d][key] . P^T[key][query]  (the accumulator's row index
+//     is the contraction index; k-order inside a step is 16s + 8(j>>2) + 4h + (j&3));
+//   * V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware
+//     transpose read), two reads per MFMA operand, with a chunk XOR that keeps the 4x16 blocks
+//     of one read on distinct banks;
+//   * K tile rows are chunk-XOR-swizzled so the 32-row ds_read_b128 operand reads are conflict-free.
+// f32 kernel: exact-f32 VALU flash kernel (one query per lane), used only by the f32 parity mode.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BQ = 128, BKV = 64;
+
+template <int CPR> __device__ __forceinline__ int kswz(int row, int c) {
+    if constexpr (CPR >= 4) { constexpr int RPB = 16 / CPR; return c ^ ((row / RPB) % CPR); }
+    else return c;
+}
+template <int CPR> __device__ __forceinline__ int vswz(int row, int c) {
+    if constexpr (CPR == 8) return c ^ (((row >> 1) & 1) << 2);
+    else if constexpr (CPR == 16) return c ^ ((row & 3) << 2);
+    else return c;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a) {
+    constexpr int HDP = HD < 32 ? 32 : HD;          // padded head dim for the PV d-blocks
+    constexpr int KROW = HD * 2, VROW = HDP * 2;    // bytes per LDS row
+    constexpr int KCPR = KROW / 16, VCPR = VROW / 16, VCV = (HD * 2) / 16;  // chunks per row; valid V chunks
+    constexpr int NKS = HD / 16;                     // k-steps over head dim for S^T
+    constexpr int NDB = HDP / 32;                    // 32-row d blocks of O^T
+    constexpr int KCH = (BKV * KCPR + 255) / 256, VCH = (BKV * VCV + 255) / 256;
+    constexpr int TILE_BYTES = BKV * (KROW + VROW);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * BQ + wave * 32;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
+    const float* bias = a.bias ? a.bias + (int64_t)b * a.Sk : nullptr;
+    const float LOG2E = 1.4426950408889634f;
+    const float sc2 = a.scale * LOG2E;
+
+    // Q^T operand fragments (B operand: k = d, col = query)
+    bf16x8 qf[NKS];
+    {
+        int qr = q0 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+        const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    u32x4 rk[KCH], rv[VCH];
+    auto gload = [&](int t) {
+        const int kv0 = t * BKV;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            int idx = tid + 256 * i;
+            if (idx < BKV * KCPR) {
+                int row = idx / KCPR, c = idx % KCPR;
+                int key = kv0 + row; if (key > a.Sk - 1) key = a.Sk - 1;
+                rk[i] = *reinterpret_cast<const u32x4*>(K + (int64_t)key * a.ldk + c * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            int idx = tid + 256 * i;
+            if (idx < BKV * VCV) {
+                int row = idx / VCV, c = idx % VCV;
+                int key = kv0 + row; if (key > a.Sk - 1) key = a.Sk - 1;
+                rv[i] = *reinterpret_cast<const u32x4*>(V + (int64_t)key * a.ldv + c * 8);
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* Ks = smem + buf * TILE_BYTES;
+        unsigned char* Vs = Ks + BKV * KROW;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            int idx = tid + 256 * i;
+            if (idx < BKV * KCPR) {
+                int row = idx / KCPR, c = idx % KCPR;
+                *reinterpret_cast<u32x4*>(Ks + row * KROW + kswz<KCPR>(row, c) * 16) = rk[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            int idx = tid + 256 * i;
+            if (idx < BKV * VCV) {
+                int row = idx / VCV, c = idx % VCV;
+                *reinterpret_cast<u32x4*>(Vs + row * VROW + vswz<VCPR>(row, c) * 16) = rv[i];
+            }
+        }
+    };
+
+    f32x16 acc_o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[d][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (a.Sk + BKV - 1) / BKV;
+    gload(0); swrite(0);
+    __syncthreads();
+
+    // tr-read lane geometry (see header): 16-lane group g = lane>>4 -> (h = g>>1, d-half = g&1)
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const unsigned char* Ks = smem + buf * TILE_BYTES;
+        const unsigned char* Vs = Ks + BKV * KROW;
+        const int kv0 = t * BKV;
+
+        // ---- S^T = K . Q^T  (two 32-key blocks)
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+            const int row = kb * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * KROW + kswz<KCPR>(row, 2 * ks + h) * 16);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (per query column = lane&31; keys split over the two lane halves)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float x = sacc[kb][i] * sc2;
+                if (bias) x += bias[key < a.Sk ? key : a.Sk - 1] * LOG2E;
+                if (key >= a.Sk) x = -INFINITY;
+                sacc[kb][i] = x;
+                mt = fmaxf(mt, x);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float ls = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = __builtin_amdgcn_exp2f(sacc[kb][i] - m_new);
+                ls += p;
+                pf[kb][i >> 3][i & 7] = (bf16_t)p;
+            }
+        l_run = l_run * alpha + ls;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const int cv = d * 4 + trdh * 2 + (trp >> 1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int row0 = kb * 32 + 16 * s + 4 * h + trq;
+                    const int row1 = row0 + 8;
+                    bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + row0 * VROW + vswz<VCPR>(row0, cv) * 16 + (trp & 1) * 8));
+                    bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + row1 * VROW + vswz<VCPR>(row1, cv) * 16 + (trp & 1) * 8));
+                    bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], acc_o[d], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nt) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + r;
+    if (qr < a.Sq) {
+        bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;
+                if (dd < HD) {
+                    bf16x4 o4 = {(bf16_t)(acc_o[d][4 * g4 + 0] * inv), (bf16_t)(acc_o[d][4 * g4 + 1] * inv),
+                                 (bf16_t)(acc_o[d][4 * g4 + 2] * inv), (bf16_t)(acc_o[d][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(O + dd) = o4;
+                }
+            }
+    }
+}
+
+// ---- exact-f32 flash attention (parity mode): one query per lane, 64 queries per block ----
+template <int HD>
+__global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
+    constexpr int TK = 32;
+    __shared__ __attribute__((aligned(16))) float Ks[TK][HD];
+    __shared__ __attribute__((aligned(16))) float Vs[TK][HD];
+    const int lane = threadIdx.x;
+    const int head = blockIdx.y, b = blockIdx.z;
+    int qr = blockIdx.x * 64 + lane;
+    const bool active = qr < a.Sq;
+    if (!active) qr = a.Sq - 1;
+    const float* Q = reinterpret_cast<const float*>(a.q) + ((int64_t)b * a.Sq + qr) * a.ldq + head * HD;
+    const float* K = reinterpret_cast<const float*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
+    const float* V = reinterpret_cast<const float*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
+    const float* bias = a.bias ? a.bias + (int64_t)b * a.Sk : nullptr;
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Q + d);
+        q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
+        o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < a.Sk; k0 += TK) {
+        __syncthreads();
+        for (int i = lane; i < TK * HD / 4; i += 64) {
+            int row = i / (HD / 4), c = i % (HD / 4);
+            int key = k0 + row; if (key > a.Sk - 1) key = a.Sk - 1;
+            *reinterpret_cast<f32x4*>(&Ks[row][c * 4]) = *reinterpret_cast<const f32x4*>(K + (int64_t)key * a.ldk + c * 4);
+            *reinterpret_cast<f32x4*>(&Vs[row][c * 4]) = *reinterpret_cast<const f32x4*>(V + (int64_t)key * a.ldv + c * 4);
+        }
+        __syncthreads();
+        const int jmax = a.Sk - k0 < TK ? a.Sk - k0 : TK;
+        for (int j = 0; j < jmax; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[j][d]);
+                acc += q[d] * kv[0] + q[d + 1] * kv[1] + q[d + 2] * kv[2] + q[d + 3] * kv[3];
+            }
+            float x = acc * a.scale;
+            if (bias) x += bias[k0 + j];
+            const float mn = fmaxf(m, x);
+            const float alpha = expf(m - mn);
+            const float p = expf(x - mn);
+            m = mn; l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[j][d]);
+                o[d] = o[d] * alpha + p * vv[0]; o[d + 1] = o[d + 1] * alpha + p * vv[1];
+                o[d + 2] = o[d + 2] * alpha + p * vv[2]; o[d + 3] = o[d + 3] * alpha + p * vv[3];
+            }
+        }
+    }
+    if (active) {
+        float* O = reinterpret_cast<float*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            f32x4 v = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+            *reinterpret_cast<f32x4*>(O + d) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
+    if (a.Sq <= 0 || a.Sk <= 0 || a.heads <= 0) LTX_FAIL(LTX_ERR_ARG, "attention: empty problem");
+    if (dtype == LTX_DT_BF16) {
+        if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
+        dim3 grid((unsigned)cdiv(a.Sq, BQ), (unsigned)a.heads, (unsigned)a.B), block(256);
+        switch (a.hd) {
+            case 16: hipLaunchKernelGGL(attn_bf16_kernel<16>, grid, block, 0, s, a); break;
+            case 32: hipLaunchKernelGGL(attn_bf16_kernel<32>, grid, block, 0, s, a); break;
+            case 64: hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, block, 0, s, a); break;
+            default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
+        }
+    } else {
+        if (a.ldq % 4 || a.ldk % 4 || a.ldv % 4 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
+        dim3 grid((unsigned)cdiv(a.Sq, 64), (unsigned)a.heads, (unsigned)a.B), block(64);
+        switch (a.hd) {
+            case 16: hipLaunchKernelGGL(attn_f32_kernel<16>, grid, block, 0, s, a); break;
+            case 32: hipLaunchKernelGGL(attn_f32_kernel<32>, grid, block, 0, s, a); break;
+            case 64: hipLaunchKernelGGL(attn_f32_kernel<64>, grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL(attn_f32_kernel<128>, grid, block, 0, s, a); break;
+            default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
+        }
+    }
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}

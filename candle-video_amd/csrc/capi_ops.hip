@@ -1,0 +1,107 @@
+// Kernel-level C entry points (include/ltxhip_ops.h) — thin argument marshalling only.
+#include "model_util.h"
+#include "../../include/ltxhip_ops.h"
+
+static inline int dtc(int d) { return d == 1 ? LTX_DT_BF16 : LTX_DT_F32; }
+
+extern "C" int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, int epi,
+                             const void* resid, const float* gate, int rows_per_batch, ltx_stream stream) {
+    if (!x || !w || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear: null tensor");
+    if (epi < 0 || epi > 3) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear: epi must be 0..3");
+    if ((epi == 2 || epi == 3) && !resid) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear: residual epilogue needs resid");
+    if (epi == 2 && (!gate || rows_per_batch < 1)) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear: gated epilogue needs gate");
+    GemmArgs g; g.A = x; g.W = w; g.C = y; g.bias = bias; g.resid = resid; g.gate = gate;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.gate_stride = N;
+    return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
+}
+
+extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float eps, const void* weight,
+                              const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
+                              int dtype, ltx_stream stream) {
+    if (!x || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_rownorm: null tensor");
+    RowNormArgs a; a.x = x; a.y = y; a.rows = rows; a.D = D; a.ldx = D; a.ldy = D; a.kind = kind; a.eps = eps; a.weight = weight;
+    a.scale = scale; a.shift = shift; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; a.mod_stride = mod_stride; a.act = act;
+    return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
+}
+
+extern "C" int ltx_op_qknorm_rope(void* x, int64_t rows, int D, int ld, const void* weight, float eps,
+                                  const float* cos, const float* sin, int dtype, ltx_stream stream) {
+    if (!x || !weight) LTX_FAIL(LTX_ERR_ARG, "ltx_op_qknorm_rope: null tensor");
+    QkNormRopeArgs a; a.x = x; a.rows = rows; a.D = D; a.ld = ld; a.nseg = 1; a.w0 = weight; a.eps = eps; a.cos = cos; a.sin = sin;
+    return ltx_launch_qknorm_rope(a, dtc(dtype), (hipStream_t)stream);
+}
+
+extern "C" int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F, int H, int W, int D,
+                                 const float* rope_scale_host, ltx_stream stream) {
+    if (!cos || !sin) LTX_FAIL(LTX_ERR_ARG, "ltx_op_rope_table: null tensor");
+    int steps = D / 6; if (steps < 1) steps = 1;
+    std::vector<float> fr(steps);
+    const float theta_ln = (float)std::log(10000.0);
+    for (int i = 0; i < steps; ++i) {
+        float lin = steps <= 1 ? 0.0f : (float)i * (float)(1.0 / (double)(steps - 1));
+        fr[i] = (float)std::exp((double)(lin * theta_ln)) * (float)(M_PI / 2.0);
+    }
+    float* dfr = nullptr;
+    HIP_TRY(hipMalloc((void**)&dfr, sizeof(float) * steps));
+    HIP_TRY(hipMemcpy(dfr, fr.data(), sizeof(float) * steps, hipMemcpyHostToDevice));
+    RopeTableArgs r; r.cos = cos; r.sin = sin; r.freqs = dfr; r.B = B; r.D = D;
+    if (coords) { r.use_coords = 1; r.coords = coords; r.F = 1; r.H = 1; r.W = F * H * W;
+                  r.gscale[0] = (float)(1.0 / 20.0); r.gscale[1] = (float)(1.0 / 2048.0); r.gscale[2] = (float)(1.0 / 2048.0); }
+    else { r.F = F; r.H = H; r.W = W;
+           if (rope_scale_host) { r.gscale[0] = (float)((double)rope_scale_host[0] / 20.0); r.gscale[1] = (float)((double)rope_scale_host[1] / 2048.0); r.gscale[2] = (float)((double)rope_scale_host[2] / 2048.0); } }
+    int rc = ltx_launch_rope_table(r, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dfr);
+    if (rc != LTX_OK) return rc;
+    if (e != hipSuccess) { ltx_set_error(hipGetErrorString(e)); return LTX_ERR_HIP; }
+    return LTX_OK;
+}
+
+extern "C" int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                                int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias, int dtype, ltx_stream stream) {
+    if (!q || !k || !v || !o) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention: null tensor");
+    AttnArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.heads = heads; a.hd = hd; a.scale = scale; a.bias = key_bias;
+    return ltx_launch_attention(a, dtc(dtype), (hipStream_t)stream);
+}
+
+namespace {
+int conv_common(const void* x, const void* w, const void* bias, int wdtype, void* y, const void* resid,
+                int B, int T, int H, int W, int Cin, int Cout, int causal, int dtype, int epi, int mode, int post, hipStream_t s) {
+    if (!x || !w || !bias || !y) LTX_FAIL(LTX_ERR_ARG, "conv: null tensor");
+    const int dt = dtc(dtype); const size_t esz = ltx_dt_size(dt);
+    void *pw = nullptr, *pb = nullptr;
+    HIP_TRY(hipMalloc(&pw, (size_t)Cout * Cin * 27 * esz));
+    if (hipMalloc(&pb, (size_t)Cout * esz + 16) != hipSuccess) { (void)hipFree(pw); LTX_FAIL(LTX_ERR_HIP, "hipMalloc"); }
+    const int Cf = Cout / 8;
+    int rc = ltx_pack_conv(w, dtc(wdtype), pw, dt, Cout, Cin, 27, mode, Cf, s);
+    if (rc == LTX_OK) rc = ltx_pack_conv(bias, dtc(wdtype), pb, dt, Cout, 1, 1, mode, Cf, s);
+    if (rc == LTX_OK) {
+        GemmArgs g; g.A = x; g.W = pw; g.C = y; g.bias = pb; g.resid = resid;
+        g.M = B * T * H * W; g.N = Cout; g.K = Cin; g.ldc = Cout; g.ldr = Cout;
+        g.conv = 1; g.B = B; g.T = T; g.H = H; g.Wd = W; g.Cin = Cin; g.ntaps = 27; g.kh = 3; g.kw = 3; g.pad_t = causal ? 2 : 1; g.post = post;
+        if (epi == EPI_D2S) { g.Cf = Cf; g.Cr = Cin / 8; g.To = 2 * T - 1; g.Ho = 2 * H; g.Wo = 2 * W; }
+        rc = ltx_launch_gemm(g, dt, epi, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(pw); (void)hipFree(pb);
+    if (rc != LTX_OK) return rc;
+    if (e != hipSuccess) { ltx_set_error(hipGetErrorString(e)); return LTX_ERR_HIP; }
+    return LTX_OK;
+}
+}  // namespace
+
+extern "C" int ltx_op_conv3d(const void* x, const void* w, const void* bias, int wdtype, void* y, const void* resid,
+                             int B, int T, int H, int W, int Cin, int Cout, int causal, int dtype, ltx_stream stream) {
+    return conv_common(x, w, bias, wdtype, y, resid, B, T, H, W, Cin, Cout, causal, dtype, resid ? EPI_RESID : EPI_BIAS, LTX_PERM_NONE, 0, (hipStream_t)stream);
+}
+extern "C" int ltx_op_upsample3d(const void* x, const void* w, const void* bias, int wdtype, void* y,
+                                 int B, int T, int H, int W, int Cin, int Cout, int causal, int residual, int dtype, ltx_stream stream) {
+    if (Cout % 8 != 0 || Cin % 8 != 0) LTX_FAIL(LTX_ERR_ARG, "upsample3d: channels must be multiples of 8");
+    return conv_common(x, w, bias, wdtype, y, residual ? x : nullptr, B, T, H, W, Cin, Cout, causal, dtype, EPI_D2S, LTX_PERM_D2S, 0, (hipStream_t)stream);
+}
+extern "C" int ltx_op_conv_out_unpatchify(const void* x, const void* w, const void* bias, int wdtype, float* y,
+                                          int B, int T, int H, int W, int Cin, int Cout, int causal, int postprocess, int dtype, ltx_stream stream) {
+    if (Cout % 16 != 0) LTX_FAIL(LTX_ERR_ARG, "conv_out: Cout must be a multiple of 16 (patch 4x4)");
+    return conv_common(x, w, bias, wdtype, y, nullptr, B, T, H, W, Cin, Cout, causal, dtype, EPI_UNPATCH, LTX_PERM_UNPATCH, postprocess, (hipStream_t)stream);
+}

@@ -1,0 +1,86 @@
+// Shared device/host helpers for the ltxhip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LTX_WAVE 64
+
+// ---- error plumbing (thread-local last error, C-ABI returns int codes) ----
+enum { LTX_OK = 0, LTX_ERR_ARG = 1, LTX_ERR_HIP = 2, LTX_ERR_MISSING_WEIGHT = 3, LTX_ERR_UNSUPPORTED = 4 };
+void ltx_set_error(const std::string& s);
+#define LTX_FAIL(code, msg) do { ltx_set_error(std::string(msg)); return (code); } while (0)
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    ltx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return LTX_ERR_HIP; } } while (0)
+#define LTX_TRY(expr) do { int _rc = (expr); if (_rc != LTX_OK) return _rc; } while (0)
+#define LTX_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+// ---- element traits: T in {float, bf16_t}; a "chunk" is 16 bytes ----
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int CHUNK = 4; };
+template <> struct ElemTraits<bf16_t> { static constexpr int CHUNK = 8; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 16-byte vector of T viewed as raw words
+union Chunk16 {
+    u32x4 u;
+    float f[4];
+    bf16_t h[8];
+};
+
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const Chunk16& c, float* out);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const Chunk16& c, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c.f[i];
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const Chunk16& c, float* out) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)c.h[i];
+}
+template <typename T> __device__ __forceinline__ void f32_to_chunk(const float* in, Chunk16& c);
+template <> __device__ __forceinline__ void f32_to_chunk<float>(const float* in, Chunk16& c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.f[i] = in[i];
+}
+template <> __device__ __forceinline__ void f32_to_chunk<bf16_t>(const float* in, Chunk16& c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.h[i] = (bf16_t)in[i];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))   (ltx_transformer.rs:214-226)
+    const float k = 0.7978845608028654f;
+    float inner = k * (x + 0.044715f * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1)
+    float e = __expf(2.0f * inner);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

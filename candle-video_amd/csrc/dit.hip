@@ -1,0 +1,310 @@
+// LtxVideoTransformer3DModel on MI355X: weight ingestion + forward orchestration.
+// Reference: src/models/ltx_video/ltx_transformer.rs (:957-1022 ctor, :1029-1172 forward,
+// :820-937 block, :648-750 attention).  One kernel launch per fused stage:
+//   per block: rms+AdaLN | fused QKV GEMM | qk-RMSNorm+RoPE | flash attention | to_out GEMM (+gate*x+h)
+//              | q GEMM | q-norm | (k,v GEMM | k-norm) | cross attention (key bias) | to_out GEMM (+h)
+//              | rms+AdaLN | FF1 GEMM (+GELU-tanh) | FF2 GEMM (+gate*x+h)
+#include "model_util.h"
+
+struct DitBlock {
+    LinearW qkv1, o1, q2, kv2, o2, ff1, ff2;
+    void *nq1 = nullptr, *nk1 = nullptr, *nq2 = nullptr, *nk2 = nullptr;
+};
+
+struct ltx_dit {
+    ltx_dit_config cfg{};
+    int dtype = LTX_DT_BF16;
+    int device = 0;
+    int D = 0;
+    LinearW proj_in, te1, te2, te_lin, cap1, cap2, proj_out;
+    void* sst_final = nullptr;       // [2, D]
+    void* sst_blocks = nullptr;      // [L, 6, D]
+    std::vector<DitBlock> blocks;
+    float* rope_freqs = nullptr;     // [D/6]
+    float* inv_freq = nullptr;       // [128]
+    std::vector<int> skip_blocks;
+    std::vector<void*> owned;        // every hipMalloc'd weight pointer
+    // workspaces
+    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT;
+    void free_all() {
+        for (void* p : owned) if (p) (void)hipFree(p);
+        owned.clear();
+        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT};
+        for (DevBuf* b : bs) b->release();
+    }
+};
+
+namespace {
+
+int own_linear(ltx_dit* m, const WeightMap& wm, const std::string& prefix, int in, int out, LinearW* l) {
+    LTX_TRY(ltx_load_linear(wm, prefix, in, out, m->dtype, l));
+    m->owned.push_back(l->w); if (l->b) m->owned.push_back(l->b);
+    return LTX_OK;
+}
+int own_tensor(ltx_dit* m, const WeightMap& wm, const std::string& name, int64_t numel, void** out) {
+    LTX_TRY(ltx_load_tensor(wm, name, numel, m->dtype, out));
+    m->owned.push_back(*out);
+    return LTX_OK;
+}
+// fused [sum(out_i), in] linear from several reference linears sharing the same input
+int own_fused(ltx_dit* m, const WeightMap& wm, const std::vector<std::string>& prefixes, int in, int out_each, LinearW* l) {
+    const int n = (int)prefixes.size();
+    const size_t esz = ltx_dt_size(m->dtype);
+    l->in = in; l->out = out_each * n;
+    HIP_TRY(hipMalloc(&l->w, (size_t)l->out * in * esz)); m->owned.push_back(l->w);
+    bool has_bias = wm.find(prefixes[0] + ".bias") != nullptr;
+    if (has_bias) { HIP_TRY(hipMalloc(&l->b, (size_t)l->out * esz)); m->owned.push_back(l->b); }
+    for (int i = 0; i < n; ++i) {
+        const ltx_weight* w = wm.find(prefixes[i] + ".weight");
+        if (!w) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + prefixes[i] + ".weight'");
+        LTX_TRY(ltx_upload_cast(w, (char*)l->w + (size_t)i * out_each * in * esz, m->dtype, (int64_t)out_each * in, prefixes[i] + ".weight"));
+        if (has_bias) {
+            const ltx_weight* b = wm.find(prefixes[i] + ".bias");
+            if (!b) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + prefixes[i] + ".bias'");
+            LTX_TRY(ltx_upload_cast(b, (char*)l->b + (size_t)i * out_each * esz, m->dtype, out_each, prefixes[i] + ".bias"));
+        }
+    }
+    return LTX_OK;
+}
+
+int build(ltx_dit* m, const ltx_weight* weights, size_t n_weights) {
+    const ltx_dit_config& c = m->cfg;
+    const int D = m->D, L = c.num_layers;
+    WeightMap wm(weights, n_weights);
+    LTX_TRY(own_linear(m, wm, "proj_in", c.in_channels, D, &m->proj_in));
+    LTX_TRY(own_tensor(m, wm, "scale_shift_table", 2 * (int64_t)D, &m->sst_final));
+    LTX_TRY(own_linear(m, wm, "time_embed.emb.timestep_embedder.linear_1", 256, D, &m->te1));
+    LTX_TRY(own_linear(m, wm, "time_embed.emb.timestep_embedder.linear_2", D, D, &m->te2));
+    LTX_TRY(own_linear(m, wm, "time_embed.linear", D, 6 * D, &m->te_lin));
+    LTX_TRY(own_linear(m, wm, "caption_projection.linear_1", c.caption_channels, D, &m->cap1));
+    LTX_TRY(own_linear(m, wm, "caption_projection.linear_2", D, D, &m->cap2));
+    LTX_TRY(own_linear(m, wm, "proj_out", D, c.out_channels, &m->proj_out));
+    const size_t esz = ltx_dt_size(m->dtype);
+    HIP_TRY(hipMalloc(&m->sst_blocks, (size_t)L * 6 * D * esz)); m->owned.push_back(m->sst_blocks);
+    m->blocks.resize(L);
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+        DitBlock& b = m->blocks[i];
+        LTX_TRY(own_fused(m, wm, {p + "attn1.to_q", p + "attn1.to_k", p + "attn1.to_v"}, D, D, &b.qkv1));
+        LTX_TRY(own_linear(m, wm, p + "attn1.to_out.0", D, D, &b.o1));
+        LTX_TRY(own_tensor(m, wm, p + "attn1.norm_q.weight", D, &b.nq1));
+        LTX_TRY(own_tensor(m, wm, p + "attn1.norm_k.weight", D, &b.nk1));
+        LTX_TRY(own_linear(m, wm, p + "attn2.to_q", D, D, &b.q2));
+        LTX_TRY(own_fused(m, wm, {p + "attn2.to_k", p + "attn2.to_v"}, c.cross_attention_dim, D, &b.kv2));
+        LTX_TRY(own_linear(m, wm, p + "attn2.to_out.0", D, D, &b.o2));
+        LTX_TRY(own_tensor(m, wm, p + "attn2.norm_q.weight", D, &b.nq2));
+        LTX_TRY(own_tensor(m, wm, p + "attn2.norm_k.weight", D, &b.nk2));
+        LTX_TRY(own_linear(m, wm, p + "ff.net.0.proj", D, 4 * D, &b.ff1));
+        LTX_TRY(own_linear(m, wm, p + "ff.net.2", 4 * D, D, &b.ff2));
+        const ltx_weight* t = wm.find(p + "scale_shift_table");
+        if (!t) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + p + "scale_shift_table'");
+        LTX_TRY(ltx_upload_cast(t, (char*)m->sst_blocks + (size_t)i * 6 * D * esz, m->dtype, 6 * (int64_t)D, p + "scale_shift_table"));
+    }
+    // RoPE frequency table: theta^linspace(0,1,D/6) * pi/2 with the reference's f32 roundings
+    // (ltx_transformer.rs:475-488); exp evaluated correctly rounded (double -> f32).
+    {
+        int steps = D / 6; if (steps < 1) steps = 1;
+        std::vector<float> fr(steps);
+        const float theta_ln = (float)std::log(10000.0);
+        for (int i = 0; i < steps; ++i) {
+            float lin = steps <= 1 ? 0.0f : (float)i * (float)(1.0 / (double)(steps - 1));
+            float x = lin * theta_ln;
+            float e = (float)std::exp((double)x);
+            fr[i] = e * (float)(M_PI / 2.0);
+        }
+        HIP_TRY(hipMalloc((void**)&m->rope_freqs, sizeof(float) * steps)); m->owned.push_back(m->rope_freqs);
+        HIP_TRY(hipMemcpy(m->rope_freqs, fr.data(), sizeof(float) * steps, hipMemcpyHostToDevice));
+        // inv_freq_i = 1 / 10000^(i/128)  (ltx_transformer.rs:288-290)
+        std::vector<float> inv(128);
+        for (int i = 0; i < 128; ++i) {
+            float ex = (float)i / 128.0f;
+            float pw = (float)std::pow(10000.0, (double)ex);
+            inv[i] = 1.0f / pw;
+        }
+        HIP_TRY(hipMalloc((void**)&m->inv_freq, sizeof(float) * 128)); m->owned.push_back(m->inv_freq);
+        HIP_TRY(hipMemcpy(m->inv_freq, inv.data(), sizeof(float) * 128, hipMemcpyHostToDevice));
+    }
+    return LTX_OK;
+}
+
+}  // namespace
+
+extern "C" void ltx_dit_config_default(ltx_dit_config* c) {
+    c->in_channels = 128; c->out_channels = 128; c->patch_size = 1; c->patch_size_t = 1;
+    c->num_attention_heads = 32; c->attention_head_dim = 64; c->cross_attention_dim = 2048;
+    c->num_layers = 28; c->norm_eps = 1e-6f; c->caption_channels = 4096;
+}
+
+extern "C" int ltx_dit_create(const ltx_dit_config* cfg, const ltx_weight* weights, size_t n_weights,
+                              ltx_dtype model_dtype, int device, ltx_dit** out) {
+    if (!cfg || !weights || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_create: null argument");
+    *out = nullptr;
+    const int hd = cfg->attention_head_dim;
+    if (hd != 16 && hd != 32 && hd != 64 && hd != 128) LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention_head_dim must be 16/32/64/128");
+    const int D = cfg->num_attention_heads * hd;
+    if (D % 8 != 0 || cfg->in_channels % 8 != 0 || cfg->out_channels % 8 != 0 || cfg->caption_channels % 8 != 0 || cfg->cross_attention_dim % 8 != 0)
+        LTX_FAIL(LTX_ERR_UNSUPPORTED, "channel dims must be multiples of 8");
+    if (cfg->cross_attention_dim != D) LTX_FAIL(LTX_ERR_UNSUPPORTED, "cross_attention_dim must equal inner_dim (caption projection output feeds attn2)");
+    if (cfg->num_layers < 1) LTX_FAIL(LTX_ERR_ARG, "num_layers must be >= 1");
+    HIP_TRY(hipSetDevice(device));
+    ltx_dit* m = new ltx_dit();
+    m->cfg = *cfg; m->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32; m->device = device; m->D = D;
+    int rc = build(m, weights, n_weights);
+    if (rc != LTX_OK) { m->free_all(); delete m; return rc; }
+    *out = m;
+    return LTX_OK;
+}
+
+extern "C" void ltx_dit_destroy(ltx_dit* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    m->free_all();
+    delete m;
+}
+
+extern "C" int ltx_dit_set_skip_blocks(ltx_dit* m, const int* blocks, int n) {
+    if (!m || n < 0 || (n > 0 && !blocks)) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_set_skip_blocks: bad argument");
+    m->skip_blocks.assign(blocks, blocks + n);
+    return LTX_OK;
+}
+
+extern "C" int ltx_dit_get_config(const ltx_dit* m, ltx_dit_config* out) {
+    if (!m || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_get_config: null argument");
+    *out = m->cfg;
+    return LTX_OK;
+}
+
+extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
+                               const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
+                               const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
+                               ltx_dtype io_dtype, void* out, ltx_stream stream) {
+    if (!m || !hidden || !enc || !timestep || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: null argument");
+    if (B < 1 || B > 8) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: batch must be 1..8");
+    if (S < 1 || K < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: empty sequence");
+    if (!video_coords && (int64_t)num_frames * height * width != S)
+        LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: num_frames*height*width must equal S when video_coords is absent");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const ltx_dit_config& c = m->cfg;
+    const int dt = m->dtype, iodt = io_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32;
+    const size_t esz = ltx_dt_size(dt);
+    const int D = m->D, L = c.num_layers, H = c.num_attention_heads, hd = c.attention_head_dim;
+    const int64_t M = (int64_t)B * S, MK = (int64_t)B * K;
+
+    LTX_TRY(m->xin.ensure(M * c.in_channels * esz));
+    LTX_TRY(m->encin.ensure(MK * c.caption_channels * esz));
+    LTX_TRY(m->h.ensure(M * D * esz)); LTX_TRY(m->n.ensure(M * D * esz));
+    LTX_TRY(m->qkv.ensure(M * 3 * D * esz)); LTX_TRY(m->attn.ensure(M * D * esz));
+    LTX_TRY(m->ff.ensure(M * 4 * D * esz));
+    LTX_TRY(m->c1.ensure(MK * D * esz)); LTX_TRY(m->encp.ensure(MK * D * esz)); LTX_TRY(m->kv2.ensure(MK * 2 * D * esz));
+    LTX_TRY(m->tproj.ensure((size_t)B * 256 * esz)); LTX_TRY(m->e1.ensure((size_t)B * D * esz));
+    LTX_TRY(m->emb.ensure((size_t)B * D * esz)); LTX_TRY(m->embs.ensure((size_t)B * D * esz));
+    LTX_TRY(m->temb.ensure((size_t)B * 6 * D * esz));
+    LTX_TRY(m->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(m->adaf.ensure((size_t)2 * B * D * sizeof(float)));
+    LTX_TRY(m->cosb.ensure(M * (D / 2) * sizeof(float))); LTX_TRY(m->sinb.ensure(M * (D / 2) * sizeof(float)));
+    LTX_TRY(m->bias.ensure(MK * sizeof(float)));
+    LTX_TRY(m->outT.ensure(M * c.out_channels * esz));
+    if (skip_layer_mask) LTX_TRY(m->orig.ensure(M * D * esz));
+
+    // inputs -> model dtype (:1045-1047)
+    LTX_TRY(ltx_launch_cast(hidden, iodt, m->xin.p, dt, M * c.in_channels, s));
+    LTX_TRY(ltx_launch_cast(enc, iodt, m->encin.p, dt, MK * c.caption_channels, s));
+    LTX_TRY(ltx_linear(m->proj_in, m->xin.p, c.in_channels, m->h.p, D, (int)M, dt, EPI_BIAS, s));
+
+    // AdaLayerNormSingle (:262-267): sinusoid(256) -> Linear -> SiLU -> Linear = embedded_timestep ; SiLU -> Linear(6D) = temb
+    TimeVec tv; tv.n = B; for (int i = 0; i < 8; ++i) tv.t[i] = i < B ? timestep[i] : 0.f;
+    LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
+    LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
+    LTX_TRY(ltx_launch_silu(m->e1.p, m->e1.p, (int64_t)B * D, dt, s));
+    LTX_TRY(ltx_linear(m->te2, m->e1.p, D, m->emb.p, D, B, dt, EPI_BIAS, s));
+    LTX_TRY(ltx_launch_silu(m->emb.p, m->embs.p, (int64_t)B * D, dt, s));
+    LTX_TRY(ltx_linear(m->te_lin, m->embs.p, D, m->temb.p, 6 * D, B, dt, EPI_BIAS, s));
+    LTX_TRY(ltx_launch_ada(m->ada.as<float>(), m->sst_blocks, m->temb.p, L, B, 6 * D, dt, s));
+    LTX_TRY(ltx_launch_ada(m->adaf.as<float>(), m->sst_final, m->emb.p, 2, B, D, dt, s));
+
+    // caption projection (:186-190)
+    LTX_TRY(ltx_linear(m->cap1, m->encin.p, c.caption_channels, m->c1.p, D, (int)MK, dt, EPI_GELU, s));
+    LTX_TRY(ltx_linear(m->cap2, m->c1.p, D, m->encp.p, D, (int)MK, dt, EPI_BIAS, s));
+    const float* bias = nullptr;
+    if (enc_mask) { LTX_TRY(ltx_launch_mask_bias(m->bias.as<float>(), enc_mask, MK, s)); bias = m->bias.as<float>(); }
+
+    // RoPE tables (:436-524)
+    {
+        RopeTableArgs r;
+        r.cos = m->cosb.as<float>(); r.sin = m->sinb.as<float>(); r.freqs = m->rope_freqs;
+        r.B = B; r.D = D;
+        if (video_coords) {
+            r.use_coords = 1; r.coords = video_coords; r.F = 1; r.H = 1; r.W = S;
+            r.gscale[0] = (float)(1.0 / 20.0); r.gscale[1] = (float)(1.0 / 2048.0); r.gscale[2] = (float)(1.0 / 2048.0);
+        } else {
+            r.F = num_frames; r.H = height; r.W = width;
+            if (rope_scale) {
+                r.gscale[0] = (float)((double)rope_scale[0] * c.patch_size_t / 20.0);
+                r.gscale[1] = (float)((double)rope_scale[1] * c.patch_size / 2048.0);
+                r.gscale[2] = (float)((double)rope_scale[2] * c.patch_size / 2048.0);
+            }
+        }
+        LTX_TRY(ltx_launch_rope_table(r, s));
+    }
+
+    const float attn_scale = 1.0f / std::sqrt((float)hd);
+    for (int l = 0; l < L; ++l) {
+        bool skip = false;
+        for (int sb : m->skip_blocks) if (sb == l) skip = true;
+        if (skip) continue;                                        // :1094-1096
+        // skip_layer_mask (:1098-1123): all-ones rows make the block an exact identity
+        TimeVec mv; mv.n = B; bool any = false, all = true;
+        for (int i = 0; i < 8; ++i) mv.t[i] = 0.f;
+        if (skip_layer_mask) {
+            for (int b = 0; b < B; ++b) { mv.t[b] = skip_layer_mask[(size_t)l * B + b]; any |= mv.t[b] != 0.f; all &= mv.t[b] == 1.f; }
+            if (all) continue;
+            if (any) HIP_TRY(hipMemcpyAsync(m->orig.p, m->h.p, M * D * esz, hipMemcpyDeviceToDevice, s));
+        }
+        const DitBlock& b = m->blocks[l];
+        const float* ada = m->ada.as<float>() + (size_t)l * B * 6 * D;
+        // norm1 + AdaLN (shift_msa = row 0, scale_msa = row 1)
+        RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
+        rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
+        LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        // self attention
+        LTX_TRY(ltx_linear(b.qkv1, m->n.p, D, m->qkv.p, 3 * D, (int)M, dt, EPI_BIAS, s));
+        QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = 3 * D; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
+        qa.eps = 1e-5f; qa.cos = m->cosb.as<float>(); qa.sin = m->sinb.as<float>();
+        LTX_TRY(ltx_launch_qknorm_rope(qa, dt, s));
+        AttnArgs at; at.q = m->qkv.p; at.k = (char*)m->qkv.p + (size_t)D * esz; at.v = (char*)m->qkv.p + (size_t)2 * D * esz; at.o = m->attn.p;
+        at.ldq = at.ldk = at.ldv = 3 * D; at.ldo = D; at.B = B; at.Sq = S; at.Sk = S; at.heads = H; at.hd = hd; at.scale = attn_scale;
+        LTX_TRY(ltx_launch_attention(at, dt, s));
+        // h = h + gate_msa * to_out(attn)     (gate_msa = row 2)
+        LTX_TRY(ltx_linear(b.o1, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 2 * D, 6 * D, S));
+        // cross attention (no pre-norm, no RoPE, q/k RMSNorm, additive key bias)
+        LTX_TRY(ltx_linear(b.q2, m->h.p, D, m->qkv.p, D, (int)M, dt, EPI_BIAS, s));
+        QkNormRopeArgs q2; q2.x = m->qkv.p; q2.rows = M; q2.D = D; q2.ld = D; q2.nseg = 1; q2.w0 = b.nq2; q2.eps = 1e-5f;
+        LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
+        LTX_TRY(ltx_linear(b.kv2, m->encp.p, D, m->kv2.p, 2 * D, (int)MK, dt, EPI_BIAS, s));
+        QkNormRopeArgs k2; k2.x = m->kv2.p; k2.rows = MK; k2.D = D; k2.ld = 2 * D; k2.nseg = 1; k2.w0 = b.nk2; k2.eps = 1e-5f;
+        LTX_TRY(ltx_launch_qknorm_rope(k2, dt, s));
+        AttnArgs ax; ax.q = m->qkv.p; ax.k = m->kv2.p; ax.v = (char*)m->kv2.p + (size_t)D * esz; ax.o = m->attn.p;
+        ax.ldq = D; ax.ldk = ax.ldv = 2 * D; ax.ldo = D; ax.B = B; ax.Sq = S; ax.Sk = K; ax.heads = H; ax.hd = hd; ax.scale = attn_scale; ax.bias = bias;
+        LTX_TRY(ltx_launch_attention(ax, dt, s));
+        LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
+        // MLP (shift_mlp = row 3, scale_mlp = row 4, gate_mlp = row 5)
+        rn.shift = ada + 3 * D; rn.scale = ada + 4 * D;
+        LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        LTX_TRY(ltx_linear(b.ff1, m->n.p, D, m->ff.p, 4 * D, (int)M, dt, EPI_GELU, s));
+        LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S));
+        if (skip_layer_mask && any) LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s));
+    }
+
+    // final LayerNorm (no affine) + modulation (:1126-1161), proj_out (:1163)
+    {
+        RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
+        rn.kind = 1; rn.eps = 1e-6f; rn.shift = m->adaf.as<float>(); rn.scale = m->adaf.as<float>() + (size_t)B * D;
+        rn.rows_per_batch = S; rn.mod_stride = D;
+        LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        void* dst = iodt == dt ? out : m->outT.p;
+        LTX_TRY(ltx_linear(m->proj_out, m->n.p, D, dst, c.out_channels, (int)M, dt, EPI_BIAS, s));
+        if (iodt != dt) LTX_TRY(ltx_launch_cast(m->outT.p, dt, out, iodt, M * c.out_channels, s));
+    }
+    return LTX_OK;
+}

@@ -1,0 +1,119 @@
+// Internal launcher interface between the C++ orchestration (dit.hip / vae.hip /
+// pipeline.cpp / capi_ops.hip) and the HIP kernels.  Not part of the public C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { LTX_DT_F32 = 0, LTX_DT_BF16 = 1 };
+static inline size_t ltx_dt_size(int dt) { return dt == LTX_DT_BF16 ? 2 : 4; }
+
+// ---------------- GEMM / implicit-GEMM conv (gemm.hip) ----------------
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE_RESID = 2, EPI_RESID = 3, EPI_D2S = 4, EPI_UNPATCH = 5 };
+
+struct GemmArgs {
+    const void* A = nullptr;      // [M, lda] (linear) or channels-last activation [B,T,H,W,Cin] (conv)
+    const void* W = nullptr;      // [N, K] (linear) or [ntaps][N][K] (conv), K contiguous
+    void* C = nullptr;
+    const void* bias = nullptr;   // T [N] or null
+    const void* resid = nullptr;  // T [M, ldr] (GATE_RESID / RESID) or conv input x (D2S residual)
+    const float* gate = nullptr;  // f32 [batch, gate_stride] (GATE_RESID)
+    int M = 0, N = 0, K = 0;      // K = Cin in conv mode
+    int lda = 0, ldc = 0, ldr = 0;
+    int rows_per_batch = 1, gate_stride = 0;
+    // conv geometry
+    int conv = 0;
+    int B = 1, T = 1, H = 1, Wd = 1, Cin = 0;
+    int ntaps = 1, kh = 1, kw = 1, pad_t = 0;   // pad_t: frames of left temporal replicate padding
+    // D2S / UNPATCH
+    int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
+};
+int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
+
+// ---------------- row norms (rownorm.hip) ----------------
+struct RowNormArgs {
+    const void* x = nullptr; void* y = nullptr;
+    int64_t rows = 0; int D = 0; int ldx = 0, ldy = 0;
+    int kind = 0;                 // 0 = RMS (f32 stats), 1 = LayerNorm without affine
+    float eps = 1e-6f;
+    const void* weight = nullptr; // T [D] or null
+    const float* scale = nullptr; // f32 [batch, mod_stride]: y = n*(1+scale)+shift ; null = no modulation
+    const float* shift = nullptr;
+    int64_t rows_per_batch = 1; int mod_stride = 0;
+    int act = 0;                  // 0 none, 1 SiLU
+};
+int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
+
+struct QkNormRopeArgs {
+    void* x = nullptr;            // in place, nseg segments of width D at x + j*D in each row
+    int64_t rows = 0; int D = 0; int ld = 0; int nseg = 1;
+    const void* w0 = nullptr; const void* w1 = nullptr;   // T [D]
+    float eps = 1e-5f;
+    const float* cos = nullptr; const float* sin = nullptr;  // f32 [rows, D/2] or null (no RoPE)
+};
+int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s);
+
+struct RopeTableArgs {
+    float* cos = nullptr; float* sin = nullptr;   // [B*S, D/2]
+    const float* coords = nullptr;                // [B*S, 3] f32 (already pixel/second units) or null
+    const float* freqs = nullptr;                 // device f32 [D/6] = theta^linspace * pi/2
+    int B = 1, F = 1, H = 1, W = 1, D = 0;
+    int use_coords = 0;
+    float gscale[3] = {1.f, 1.f, 1.f};            // multiplies coords (1/base) or the raw grid
+};
+int ltx_launch_rope_table(const RopeTableArgs& a, hipStream_t s);
+
+// ---------------- attention (attention.hip) ----------------
+struct AttnArgs {
+    const void* q = nullptr; const void* k = nullptr; const void* v = nullptr; void* o = nullptr;
+    int ldq = 0, ldk = 0, ldv = 0, ldo = 0;      // row strides in elements
+    int B = 1, Sq = 0, Sk = 0, heads = 0, hd = 0;
+    float scale = 1.f;
+    const float* bias = nullptr;                  // f32 [B, Sk] additive key bias or null
+};
+int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+
+// ---------------- small elementwise kernels (elementwise.hip) ----------------
+struct TimeVec { float t[8]; int n; };
+// out[b][0:half] = cos(t_b*tab), out[b][half:] = sin(t_b*tab); t rounded to T first when round_t
+int ltx_launch_sinusoid(void* out, int dtype, const TimeVec& tv, const float* tab, int half, int round_t, float tmul, hipStream_t s);
+int ltx_launch_silu(const void* x, void* y, int64_t n, int dtype, hipStream_t s);
+int ltx_launch_cast(const void* x, int xdt, void* y, int ydt, int64_t n, hipStream_t s);
+// ada[l][b][j] = table_l[j] + temb[b][j]  (j < width), tables given as nl pointers packed contiguously [nl][width] (T), out f32
+int ltx_launch_ada(float* out, const void* tables, const void* temb, int nl, int B, int width, int dtype, hipStream_t s);
+int ltx_launch_mask_bias(float* out, const float* mask, int64_t n, hipStream_t s);
+// h = h*(1-m_b) + orig*m_b
+int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s);
+
+struct GuidanceArgs {
+    const void* text = nullptr; const void* uncond = nullptr; const void* pert = nullptr;  // model dtype (pred_dtype)
+    int pred_dtype = LTX_DT_F32;
+    float* latents = nullptr;      // f32 [B, n_per_batch], updated in place: x += dt * noise_pred
+    float* noise_out = nullptr;    // optional f32 copy of the combined prediction
+    int B = 1; int64_t n_per_batch = 0;
+    float guidance_scale = 1.f, guidance_rescale = 0.f, stg_scale = 0.f, dt = 0.f;
+    double* stats = nullptr;       // workspace [B][4] doubles (sum_t, sumsq_t, sum_c, sumsq_c)
+};
+int ltx_launch_guidance_step(const GuidanceArgs& a, hipStream_t s);
+
+// tokens [B,S,C] f32 -> channels-last T:  y = (x*std/sf + mean)*(1-ns) + noise*ns ; noise is NCTHW f32 [B,C,S] or null
+int ltx_launch_denorm_mix(const float* lat, const float* mean, const float* std_, float inv_sf, const float* noise,
+                          const TimeVec& nscale, void* out, int dtype, int B, int64_t S, int C, hipStream_t s);
+// NCTHW (src dtype) -> channels-last T
+int ltx_launch_ncthw_to_cl(const void* x, int xdt, void* y, int ydt, int B, int C, int64_t S, hipStream_t s);
+// tiled-decode blends on f32 NCTHW tiles (vae.rs:1927-2006); dim: 2=T,3=H,4=W
+struct BlendArgs {
+    const float* a = nullptr; const float* b = nullptr; float* dst = nullptr;   // dst may alias b
+    int BC = 1;                       // B*C
+    int at = 1, ah = 1, aw = 1;       // physical dims of a
+    int a_len = 1;                    // logical length of a along `dim` (its tail is blended)
+    int bt = 1, bh = 1, bw = 1;       // physical dims of b
+    int dt = 1, dh = 1, dw = 1;       // physical dims of dst
+    int ot = 0, oh = 0, ow = 0;       // where b's origin sits inside dst
+    int et = 1, eh = 1, ew = 1;       // extent of b to process (along `dim`: <= blend)
+    int dim = 3, blend = 0;
+};
+int ltx_launch_blend(const BlendArgs& a, hipStream_t s);
+// copy a [BC, st, sh, sw] window of src (dims [BC, t,h,w]) into dst at offset (ot,oh,ow) of dims [BC, T,H,W]
+int ltx_launch_copy_window(const float* src, int t, int h, int w, float* dst, int T, int H, int W, int BC,
+                           int st, int sh, int sw, int ot, int oh, int ow, hipStream_t s);
+int ltx_launch_postprocess(float* x, int64_t n, hipStream_t s);

@@ -1,0 +1,198 @@
+// Row-wise normalisation kernels (HBM-bound; algorithmic bytes = read x once + write y once).
+//
+//  rownorm      : y = act( norm(x) [*w] * (1+scale_b) + shift_b )
+//                 RMS  = RmsNorm::forward (ltx_transformer.rs:99-119; f32 statistics) fused with the
+//                        AdaLN modulate of LtxVideoTransformerBlock::forward (:874-889, :912-927),
+//                        and rmsnorm_channels_first + maybe_apply_scale_shift + SiLU of the VAE
+//                        resnet (vae.rs:148-153, 711-739, 755-800) on channels-last rows.
+//                 LN   = LayerNormNoParams (ltx_transformer.rs:72-79) + final modulation (:1149-1161).
+//  qknorm_rope  : q/k RMSNorm with weight over the FULL inner dim (ltx_transformer.rs:671-672)
+//                 fused with apply_rotary_emb (:314-339), in place, for 1 or 2 segments of a fused
+//                 QKV row.
+//  rope_table   : LtxVideoRotaryPosEmbed::forward (:436-524) -> half-width cos/sin tables.
+//
+// Mapping: LPR lanes per row (power of two, >= 16-B chunks per row, <= 64), 64/LPR rows per wave,
+// 4 waves per block; every lane moves 16 B per access; statistics reduced with xor-shuffles.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int lpr) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const bool active = row < a.rows;
+    const int64_t rr = active ? row : a.rows - 1;
+    const T* x = reinterpret_cast<const T*>(a.x) + rr * a.ldx;
+    T* y = reinterpret_cast<T*>(a.y) + rr * a.ldy;
+    const int nch = a.D / CH;
+    float mean = 0.f;
+    if (a.kind == 1) {
+        float s = 0.f;
+        for (int c = sub; c < nch; c += lpr) {
+            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+            float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) s += f[i];
+        }
+        mean = group_sum(s, lpr) / (float)a.D;
+    }
+    float ss = 0.f;
+    for (int c = sub; c < nch; c += lpr) {
+        Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+        float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { float d = f[i] - mean; ss += d * d; }
+    }
+    ss = group_sum(ss, lpr);
+    const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+    const int64_t b = rr / a.rows_per_batch;
+    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+    const T* w = reinterpret_cast<const T*>(a.weight);
+    for (int c = sub; c < nch; c += lpr) {
+        Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+        float f[CH]; chunk_to_f32<T>(v, f);
+        float wv[CH];
+        if (w) { Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH); chunk_to_f32<T>(wc, wv); }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            float n = (f[i] - mean) * rinv;
+            if (w) n *= wv[i];
+            if (sc) n = n * (1.0f + sc[c * CH + i]) + sh[c * CH + i];
+            if (a.act == 1) n = silu_f(n);
+            f[i] = n;
+        }
+        Chunk16 o; f32_to_chunk<T>(f, o);
+        if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a, int lpr) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const bool active = row < a.rows;
+    const int64_t rr = active ? row : a.rows - 1;
+    const int nch = a.D / CH;
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * a.D;
+        const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+        float ss = 0.f;
+        for (int c = sub; c < nch; c += lpr) {
+            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+            float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ss += f[i] * f[i];
+        }
+        ss = group_sum(ss, lpr);
+        const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+        const float* cs = a.cos ? a.cos + rr * (a.D / 2) : nullptr;
+        const float* sn = a.sin ? a.sin + rr * (a.D / 2) : nullptr;
+        for (int c = sub; c < nch; c += lpr) {
+            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+            float f[CH]; chunk_to_f32<T>(v, f);
+            Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
+            float wv[CH]; chunk_to_f32<T>(wc, wv);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) f[i] = f[i] * rinv * wv[i];
+            if (cs) {
+#pragma unroll
+                for (int p = 0; p < CH / 2; ++p) {
+                    float co = cs[c * (CH / 2) + p], si = sn[c * (CH / 2) + p];
+                    float re = f[2 * p], im = f[2 * p + 1];
+                    f[2 * p] = re * co - im * si;          // x*cos + (-x_imag)*sin
+                    f[2 * p + 1] = im * co + re * si;      // x*cos + ( x_real)*sin
+                }
+            }
+            Chunk16 o; f32_to_chunk<T>(f, o);
+            if (active) *reinterpret_cast<u32x4*>(x + c * CH) = o.u;
+        }
+    }
+}
+
+__global__ void rope_table_kernel(const RopeTableArgs a) {
+    const int half = a.D / 2;
+    const int64_t S = (int64_t)a.F * a.H * a.W;
+    const int64_t total = (int64_t)a.B * S * half;
+    const int rem_pairs = (a.D % 6) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % half);
+        const int64_t row = i / half;
+        float co = 1.0f, si = 0.0f;
+        if (p >= rem_pairs) {
+            const int fi = p - rem_pairs;
+            const int step = fi / 3, ax = fi - step * 3;
+            float g;
+            if (a.use_coords) {
+                g = a.coords[row * 3 + ax] * a.gscale[ax];
+            } else {
+                const int64_t s = row % S;
+                const int w = (int)(s % a.W); const int64_t t1 = s / a.W;
+                const int h = (int)(t1 % a.H); const int f = (int)(t1 / a.H);
+                const float idx = ax == 0 ? (float)f : (ax == 1 ? (float)h : (float)w);
+                g = idx * a.gscale[ax];
+            }
+            const float ang = a.freqs[step] * (g * 2.0f - 1.0f);
+            co = cosf(ang); si = sinf(ang);
+        }
+        a.cos[i] = co; a.sin[i] = si;
+    }
+}
+
+int pick_lpr(int nch) {
+    int lpr = 1;
+    while (lpr < nch && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+}  // namespace
+
+int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
+    const int ch = dtype == LTX_DT_BF16 ? 8 : 4;
+    if (a.rows <= 0) return LTX_OK;
+    if (a.D % ch != 0 || a.ldx % ch != 0 || a.ldy % ch != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: D/ld must be multiples of the 16-byte chunk");
+    if ((a.scale == nullptr) != (a.shift == nullptr)) LTX_FAIL(LTX_ERR_ARG, "rownorm: scale and shift go together");
+    const int lpr = pick_lpr(a.D / ch);
+    const int64_t rows_per_block = 4 * (64 / lpr);
+    dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
+    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(rownorm_kernel<bf16_t>, grid, block, 0, s, a, lpr);
+    else hipLaunchKernelGGL(rownorm_kernel<float>, grid, block, 0, s, a, lpr);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
+    const int ch = dtype == LTX_DT_BF16 ? 8 : 4;
+    if (a.rows <= 0) return LTX_OK;
+    if (a.D % ch != 0 || a.ld % ch != 0) LTX_FAIL(LTX_ERR_ARG, "qknorm: D/ld must be multiples of the 16-byte chunk");
+    if (a.nseg < 1 || a.nseg > 2 || !a.w0 || (a.nseg == 2 && !a.w1)) LTX_FAIL(LTX_ERR_ARG, "qknorm: bad segments/weights");
+    const int lpr = pick_lpr(a.D / ch);
+    const int64_t rows_per_block = 4 * (64 / lpr);
+    dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
+    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(qknorm_rope_kernel<bf16_t>, grid, block, 0, s, a, lpr);
+    else hipLaunchKernelGGL(qknorm_rope_kernel<float>, grid, block, 0, s, a, lpr);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+int ltx_launch_rope_table(const RopeTableArgs& a, hipStream_t s) {
+    if (a.D % 2 != 0 || a.D < 6) LTX_FAIL(LTX_ERR_ARG, "rope: dim must be even and >= 6");
+    const int64_t total = (int64_t)a.B * a.F * a.H * a.W * (a.D / 2);
+    int64_t blocks = cdiv64(total, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}

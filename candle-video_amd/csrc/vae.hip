@@ -1,0 +1,500 @@
+// AutoencoderKLLtxVideo::decode on MI355X (decoder side only; T2V never encodes).
+// Reference: src/models/ltx_video/vae.rs  (:1488-1727 decoder, :755-821 resnet, :1090-1169 upsampler,
+// :415-464 conv, :2037-2066 decode_z, :2225-2290 / :2358-2434 tiling, :1927-2006 blends).
+//
+// HBM layout: activations are CHANNELS-LAST [B,T,H,W,C] in the model dtype, so that
+//   * the conv3d is an implicit GEMM whose K dimension (C_in) is contiguous (16-B coalesced loads,
+//     MFMA operands straight from LDS rows), 27 taps accumulated in the same accumulators;
+//   * the per-voxel RMS norm over C is a contiguous row reduction;
+//   * depth-to-space (+ first-frame drop + tiled residual) and unpatchify are pure index math in
+//     the conv epilogues (weights' output channels are re-ordered once at load time so the 4
+//     accumulator values a lane owns are contiguous in the destination).
+// The packed token layout the denoise loop carries ([B, F*H*W, 128]) IS channels-last, so
+// unpack_latents is free on this path.
+#include "model_util.h"
+
+struct ConvW {
+    void* w = nullptr;   // [27][N][Cin] model dtype (N possibly permuted)
+    void* b = nullptr;   // [N]
+    int cin = 0, cout = 0;
+};
+struct TimeEmbW { LinearW l1, l2; int dim = 0; };
+struct ResnetW { ConvW c1, c2; void* sst = nullptr; };
+struct UpBlockW { ConvW up; TimeEmbW te; std::vector<ResnetW> res; int ch = 0, cin = 0; };
+
+struct ltx_vae {
+    ltx_vae_config cfg{};
+    int dtype = LTX_DT_BF16, device = 0;
+    ConvW conv_in, conv_out;
+    TimeEmbW mid_te, out_te;
+    std::vector<ResnetW> mid;
+    std::vector<UpBlockW> ups;
+    void* sst_out = nullptr;
+    float tsm = 1.0f; bool has_tsm = false;
+    float *mean = nullptr, *std_ = nullptr, *vtab = nullptr;
+    int mid_ch = 0, last_ch = 0;
+    std::vector<void*> owned;
+    DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats;
+    std::vector<DevBuf> tilebufs;
+    void free_all() {
+        for (void* p : owned) if (p) (void)hipFree(p);
+        owned.clear();
+        DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats};
+        for (DevBuf* b : bs) b->release();
+        for (auto& b : tilebufs) b.release();
+    }
+};
+
+namespace {
+
+enum { PERM_NONE = LTX_PERM_NONE, PERM_D2S = LTX_PERM_D2S, PERM_UNPATCH = LTX_PERM_UNPATCH };
+
+// dst[tap][n'][i] = src[o][i][tap] ; bias'[n'] = bias[o]
+__global__ void pack_conv_kernel(const void* src, int sdt, void* dst, int ddt, int O, int I, int ntaps, int mode, int Cf) {
+    const int64_t n = (int64_t)O * I * ntaps;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        int i = (int)(idx % I); int64_t r = idx / I; int np = (int)(r % O); int tap = (int)(r / O);
+        int o = np;
+        if (mode == PERM_D2S) { int s = np / Cf, c = np - s * Cf; o = c * 8 + s; }                    // n' = s*Cf + c'
+        else if (mode == PERM_UNPATCH) { int c = np >> 4, oh = (np >> 2) & 3, ow = np & 3; o = (c * 4 + ow) * 4 + oh; }  // n' = (c*4+oh)*4+ow
+        float v = sdt == LTX_DT_BF16 ? (float)reinterpret_cast<const bf16_t*>(src)[((int64_t)o * I + i) * ntaps + tap]
+                                     : reinterpret_cast<const float*>(src)[((int64_t)o * I + i) * ntaps + tap];
+        if (ddt == LTX_DT_BF16) reinterpret_cast<bf16_t*>(dst)[idx] = (bf16_t)v; else reinterpret_cast<float*>(dst)[idx] = v;
+    }
+}
+
+// crop a [t0:t1, h0:h1, w0:w1] window of a channels-last tensor (elements of esz bytes)
+__global__ void cl_window_kernel(const unsigned char* src, unsigned char* dst, int esz, int B, int T, int H, int W, int C,
+                                 int t0, int t1, int h0, int h1, int w0, int w1) {
+    const int nt = t1 - t0, nh = h1 - h0, nw = w1 - w0;
+    const int64_t rowb = (int64_t)C * esz;
+    const int64_t n = (int64_t)B * nt * nh * nw * rowb;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t bb = idx % rowb; int64_t r = idx / rowb;
+        int w = (int)(r % nw); r /= nw; int h = (int)(r % nh); r /= nh; int t = (int)(r % nt); int b = (int)(r / nt);
+        dst[idx] = src[((((int64_t)b * T + t0 + t) * H + h0 + h) * W + w0 + w) * rowb + bb];
+    }
+}
+
+}  // namespace
+int ltx_pack_conv(const void* src_dev, int sdt, void* dst, int ddt, int O, int I, int ntaps, int mode, int Cf, hipStream_t s) {
+    int64_t n = (int64_t)O * I * ntaps; int64_t blocks = cdiv64(n, 256); if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src_dev, sdt, dst, ddt, O, I, ntaps, mode, Cf);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+namespace {
+int load_conv(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int cin, int cout, int mode, int Cf, ConvW* c) {
+    const int dt = v->dtype; const size_t esz = ltx_dt_size(dt);
+    c->cin = cin; c->cout = cout;
+    const ltx_weight* w = wm.find(prefix + ".conv.weight");
+    const ltx_weight* b = wm.find(prefix + ".conv.bias");
+    if (!w) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + prefix + ".conv.weight'");
+    if (!b) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + prefix + ".conv.bias'");
+    if (ltx_numel(w) != (int64_t)cout * cin * 27) LTX_FAIL(LTX_ERR_ARG, "weight '" + prefix + ".conv.weight': wrong size");
+    if (ltx_numel(b) != cout) LTX_FAIL(LTX_ERR_ARG, "weight '" + prefix + ".conv.bias': wrong size");
+    HIP_TRY(hipMalloc(&c->w, (size_t)cout * cin * 27 * esz)); v->owned.push_back(c->w);
+    HIP_TRY(hipMalloc(&c->b, (size_t)cout * esz + 16)); v->owned.push_back(c->b);
+    const void* src = nullptr; void* tmp = nullptr;
+    LTX_TRY(ltx_stage_src(w, &src, &tmp));
+    int64_t n = (int64_t)cout * cin * 27; int64_t blocks = cdiv64(n, 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, src, w->dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32,
+                       c->w, dt, cout, cin, 27, mode, Cf);
+    hipError_t e = hipDeviceSynchronize(); if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) { ltx_set_error(std::string("pack conv: ") + hipGetErrorString(e)); return LTX_ERR_HIP; }
+    LTX_TRY(ltx_stage_src(b, &src, &tmp));
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)cdiv(cout, 256)), dim3(256), 0, 0, src, b->dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32,
+                       c->b, dt, cout, 1, 1, mode, Cf);
+    e = hipDeviceSynchronize(); if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) { ltx_set_error(std::string("pack bias: ") + hipGetErrorString(e)); return LTX_ERR_HIP; }
+    return LTX_OK;
+}
+
+int load_temb(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int dim, TimeEmbW* t) {
+    t->dim = dim;
+    LTX_TRY(ltx_load_linear(wm, prefix + ".timestep_embedder.linear_1", 256, dim, v->dtype, &t->l1));
+    v->owned.push_back(t->l1.w); if (t->l1.b) v->owned.push_back(t->l1.b);
+    LTX_TRY(ltx_load_linear(wm, prefix + ".timestep_embedder.linear_2", dim, dim, v->dtype, &t->l2));
+    v->owned.push_back(t->l2.w); if (t->l2.b) v->owned.push_back(t->l2.b);
+    return LTX_OK;
+}
+
+int load_resnet(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int ch, ResnetW* r) {
+    LTX_TRY(load_conv(v, wm, prefix + ".conv1", ch, ch, PERM_NONE, 0, &r->c1));
+    LTX_TRY(load_conv(v, wm, prefix + ".conv2", ch, ch, PERM_NONE, 0, &r->c2));
+    if (v->cfg.timestep_conditioning) {
+        LTX_TRY(ltx_load_tensor(wm, prefix + ".scale_shift_table", 4 * (int64_t)ch, v->dtype, &r->sst));
+        v->owned.push_back(r->sst);
+    }
+    return LTX_OK;
+}
+
+int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
+    const ltx_vae_config& c = v->cfg;
+    WeightMap wm0(weights, n_weights);
+    // accept both "decoder.xxx" and bare "xxx" names
+    std::vector<ltx_weight> renamed; std::vector<std::string> names;
+    names.reserve(n_weights); renamed.reserve(n_weights);
+    for (size_t i = 0; i < n_weights; ++i) {
+        std::string nm = weights[i].name ? weights[i].name : "";
+        if (nm.rfind("decoder.", 0) == 0) nm = nm.substr(8);
+        names.push_back(nm);
+    }
+    for (size_t i = 0; i < n_weights; ++i) { ltx_weight w = weights[i]; w.name = names[i].c_str(); renamed.push_back(w); }
+    WeightMap wm(renamed.data(), renamed.size());
+
+    const int nb = c.n_blocks;
+    std::vector<int> boc(nb), upf(nb), lpb(nb + 1);
+    for (int i = 0; i < nb; ++i) { boc[i] = c.decoder_block_out_channels[nb - 1 - i]; upf[i] = c.decoder_upsample_factor[nb - 1 - i]; }
+    for (int i = 0; i <= nb; ++i) lpb[i] = c.decoder_layers_per_block[nb - i];
+    v->mid_ch = boc[0];
+    LTX_TRY(load_conv(v, wm, "conv_in", c.latent_channels, v->mid_ch, PERM_NONE, 0, &v->conv_in));
+    if (c.timestep_conditioning) LTX_TRY(load_temb(v, wm, "mid_block.time_embedder", 4 * v->mid_ch, &v->mid_te));
+    v->mid.resize(lpb[0]);
+    for (int i = 0; i < lpb[0]; ++i) LTX_TRY(load_resnet(v, wm, "mid_block.resnets." + std::to_string(i), v->mid_ch, &v->mid[i]));
+    v->ups.resize(nb);
+    int cur = v->mid_ch;
+    for (int bi = 0; bi < nb; ++bi) {
+        UpBlockW& u = v->ups[bi];
+        const std::string p = "up_blocks." + std::to_string(bi);
+        u.ch = boc[bi] / upf[bi];                       // vae.rs:1548
+        u.cin = u.ch * upf[bi];                         // upsampler in-channels (vae.rs:1215)
+        if (u.cin != cur) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder up-block channel chain mismatch");
+        if ((u.ch * 8) % u.cin != 0 || u.cin % 8 != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "upsampler residual repeat must be integral");
+        LTX_TRY(load_conv(v, wm, p + ".upsamplers.0.conv", u.cin, u.ch * 8, PERM_D2S, u.ch, &u.up));
+        if (c.timestep_conditioning) LTX_TRY(load_temb(v, wm, p + ".time_embedder", 4 * u.ch, &u.te));
+        u.res.resize(lpb[bi + 1]);
+        for (int i = 0; i < lpb[bi + 1]; ++i) LTX_TRY(load_resnet(v, wm, p + ".resnets." + std::to_string(i), u.ch, &u.res[i]));
+        cur = u.ch;
+    }
+    v->last_ch = cur;
+    const int nout = c.out_channels * c.patch_size * c.patch_size;
+    LTX_TRY(load_conv(v, wm, "conv_out", cur, nout, PERM_UNPATCH, 0, &v->conv_out));
+    if (c.timestep_conditioning) {
+        LTX_TRY(load_temb(v, wm, "time_embedder", 2 * cur, &v->out_te));
+        LTX_TRY(ltx_load_tensor(wm, "scale_shift_table", 2 * (int64_t)cur, v->dtype, &v->sst_out)); v->owned.push_back(v->sst_out);
+        const ltx_weight* t = wm.find("timestep_scale_multiplier");
+        if (t) {
+            void* d = nullptr;
+            LTX_TRY(ltx_load_tensor(wm, "timestep_scale_multiplier", 1, LTX_DT_F32, &d));
+            HIP_TRY(hipMemcpy(&v->tsm, d, sizeof(float), hipMemcpyDeviceToHost)); (void)hipFree(d);
+            v->has_tsm = true;
+        }
+    }
+    // latents_mean / latents_std (vae.rs:1827-1838): from weights when present, else 0 / 1
+    {
+        const int C = c.latent_channels;
+        std::vector<float> z(C, 0.f), o(C, 1.f);
+        HIP_TRY(hipMalloc((void**)&v->mean, sizeof(float) * C)); v->owned.push_back(v->mean);
+        HIP_TRY(hipMalloc((void**)&v->std_, sizeof(float) * C)); v->owned.push_back(v->std_);
+        const ltx_weight* lm = wm0.find("latents_mean"); const ltx_weight* ls = wm0.find("latents_std");
+        if (lm) LTX_TRY(ltx_upload_cast(lm, v->mean, LTX_DT_F32, C, "latents_mean")); else HIP_TRY(hipMemcpy(v->mean, z.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+        if (ls) LTX_TRY(ltx_upload_cast(ls, v->std_, LTX_DT_F32, C, "latents_std")); else HIP_TRY(hipMemcpy(v->std_, o.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+    }
+    // sinusoid table exp(-ln(1e4) * i / 128) with the reference's f32 roundings (vae.rs:172-198)
+    {
+        std::vector<float> tab(128);
+        const float coef = (float)(-std::log(10000.0) / 128.0);
+        for (int i = 0; i < 128; ++i) { float x = (float)i * coef; tab[i] = (float)std::exp((double)x); }
+        HIP_TRY(hipMalloc((void**)&v->vtab, sizeof(float) * 128)); v->owned.push_back(v->vtab);
+        HIP_TRY(hipMemcpy(v->vtab, tab.data(), sizeof(float) * 128, hipMemcpyHostToDevice));
+    }
+    return LTX_OK;
+}
+
+struct Dims { int B, T, H, W; int64_t vox() const { return (int64_t)B * T * H * W; } };
+
+int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, int epi, const void* resid, int post, hipStream_t s) {
+    GemmArgs g;
+    g.A = x; g.W = cw.w; g.C = y; g.bias = cw.b; g.resid = resid;
+    g.M = (int)d.vox(); g.N = cw.cout; g.K = cw.cin; g.ldc = cw.cout; g.ldr = cw.cout;
+    g.conv = 1; g.B = d.B; g.T = d.T; g.H = d.H; g.Wd = d.W; g.Cin = cw.cin;
+    g.ntaps = 27; g.kh = 3; g.kw = 3;
+    g.pad_t = v->cfg.decoder_causal ? 2 : 1;          // vae.rs:383-412
+    g.post = post;
+    if (epi == EPI_D2S) { g.Cf = cw.cout / 8; g.Cr = cw.cin / 8; g.To = 2 * d.T - 1; g.Ho = 2 * d.H; g.Wo = 2 * d.W; }
+    return ltx_launch_gemm(g, v->dtype, epi, s);
+}
+
+// CombinedTimestepEmbedder (vae.rs:236-265) + "+ scale_shift_table" -> f32 [B][rows][C]
+int time_mod(ltx_vae* v, const TimeEmbW& te, const void* sst, const TimeVec& tv, float* out, hipStream_t s) {
+    const int dt = v->dtype; const int B = tv.n;
+    LTX_TRY(ltx_launch_sinusoid(v->tproj.p, dt, tv, v->vtab, 128, dt == LTX_DT_BF16, v->has_tsm ? v->tsm : 1.0f, s));
+    LTX_TRY(ltx_linear(te.l1, v->tproj.p, 256, v->e1.p, te.dim, B, dt, EPI_BIAS, s));
+    LTX_TRY(ltx_launch_silu(v->e1.p, v->e1.p, (int64_t)B * te.dim, dt, s));
+    LTX_TRY(ltx_linear(te.l2, v->e1.p, te.dim, v->te.p, te.dim, B, dt, EPI_BIAS, s));
+    LTX_TRY(ltx_launch_ada(out, sst, v->te.p, 1, B, te.dim, dt, s));
+    return LTX_OK;
+}
+
+int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims& d, const TimeVec* tv, hipStream_t s) {
+    const int dt = v->dtype;
+    const float* mod = nullptr;
+    if (tv && r.sst) { LTX_TRY(time_mod(v, te, r.sst, *tv, v->mod.as<float>(), s)); mod = v->mod.as<float>(); }
+    RowNormArgs rn; rn.x = v->X.p; rn.y = v->N.p; rn.rows = d.vox(); rn.D = ch; rn.ldx = ch; rn.ldy = ch;
+    rn.kind = 0; rn.eps = 1e-8f; rn.act = 1; rn.rows_per_batch = (int64_t)d.T * d.H * d.W; rn.mod_stride = 4 * ch;
+    if (mod) { rn.shift = mod; rn.scale = mod + ch; }
+    LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    LTX_TRY(conv3d(v, r.c1, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s));
+    rn.x = v->C.p;
+    if (mod) { rn.shift = mod + 2 * ch; rn.scale = mod + 3 * ch; }
+    LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    LTX_TRY(conv3d(v, r.c2, v->N.p, v->X.p, d, EPI_RESID, v->X.p, 0, s));   // X = conv2(..) + X, in place
+    return LTX_OK;
+}
+
+// LtxVideoDecoder3d::forward on a channels-last latent `z` [B,F,H,W,Clat] (model dtype) -> f32 NCTHW
+int decoder_forward(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, int post, float* out, hipStream_t s) {
+    const ltx_vae_config& c = v->cfg;
+    const int dt = v->dtype; const size_t esz = ltx_dt_size(dt);
+    // workspace sizing: the largest activation is the last stage
+    Dims d{B, F, H, W};
+    int64_t max_elems = d.vox() * v->mid_ch;
+    {
+        Dims q = d;
+        for (auto& u : v->ups) { q.T = 2 * q.T - 1; q.H *= 2; q.W *= 2; int64_t e = q.vox() * u.ch; if (e > max_elems) max_elems = e; }
+    }
+    LTX_TRY(v->X.ensure(max_elems * esz)); LTX_TRY(v->Y.ensure(max_elems * esz));
+    LTX_TRY(v->N.ensure(max_elems * esz)); LTX_TRY(v->C.ensure(max_elems * esz));
+    const int maxdim = 4 * v->mid_ch;
+    LTX_TRY(v->tproj.ensure((size_t)B * 256 * esz)); LTX_TRY(v->e1.ensure((size_t)B * maxdim * esz));
+    LTX_TRY(v->te.ensure((size_t)B * maxdim * esz)); LTX_TRY(v->mod.ensure((size_t)B * maxdim * sizeof(float)));
+    const TimeVec* tvc = (tv && c.timestep_conditioning) ? tv : nullptr;
+
+    LTX_TRY(conv3d(v, v->conv_in, z, v->X.p, d, EPI_BIAS, nullptr, 0, s));
+    for (auto& r : v->mid) LTX_TRY(resnet(v, r, v->mid_te, v->mid_ch, d, tvc, s));
+    for (auto& u : v->ups) {
+        LTX_TRY(conv3d(v, u.up, v->X.p, v->Y.p, d, EPI_D2S, v->X.p, 0, s));
+        std::swap(v->X, v->Y);
+        d.T = 2 * d.T - 1; d.H *= 2; d.W *= 2;
+        for (auto& r : u.res) LTX_TRY(resnet(v, r, u.te, u.ch, d, tvc, s));
+    }
+    // norm_out + global scale/shift + SiLU (vae.rs:1687-1723), conv_out + unpatchify
+    const int ch = v->last_ch;
+    const float* mod = nullptr;
+    if (tvc && v->sst_out) { LTX_TRY(time_mod(v, v->out_te, v->sst_out, *tvc, v->mod.as<float>(), s)); mod = v->mod.as<float>(); }
+    RowNormArgs rn; rn.x = v->X.p; rn.y = v->N.p; rn.rows = d.vox(); rn.D = ch; rn.ldx = ch; rn.ldy = ch;
+    rn.kind = 0; rn.eps = 1e-8f; rn.act = 1; rn.rows_per_batch = (int64_t)d.T * d.H * d.W; rn.mod_stride = 2 * ch;
+    if (mod) { rn.shift = mod; rn.scale = mod + ch; }
+    LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    LTX_TRY(conv3d(v, v->conv_out, v->N.p, out, d, EPI_UNPATCH, nullptr, post, s));
+    return LTX_OK;
+}
+
+int crop_cl(const void* src, void* dst, size_t esz, int B, int T, int H, int W, int C, int t0, int t1, int h0, int h1, int w0, int w1, hipStream_t s) {
+    int64_t n = (int64_t)B * (t1 - t0) * (h1 - h0) * (w1 - w0) * C * (int64_t)esz;
+    int64_t blocks = cdiv64(n, 256); if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cl_window_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, (int)esz,
+                       B, T, H, W, C, t0, t1, h0, h1, w0, w1);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+struct Tile { DevBuf* buf; int t, h, w; };   // decoded f32 NCTHW tile [B*3, t, h, w]
+
+// tiled_decode (vae.rs:2225-2290) of a channels-last latent window; result into `out` (dims oT,oH,oW given)
+int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, const ltx_tiling& tl,
+                 float* out, std::vector<DevBuf>& pool, size_t& pool_used, hipStream_t s) {
+    const ltx_vae_config& c = v->cfg;
+    const int r = c.spatial_compression_ratio, tr = c.temporal_compression_ratio;
+    const size_t esz = ltx_dt_size(v->dtype);
+    const int tmin_h = tl.tile_sample_min_height / r, tmin_w = tl.tile_sample_min_width / r;
+    const int ts_h = tl.tile_sample_stride_height / r, ts_w = tl.tile_sample_stride_width / r;
+    if (ts_h < 1 || ts_w < 1) LTX_FAIL(LTX_ERR_ARG, "tiling: stride must be >= one latent");
+    const int blend_h = std::max(tl.tile_sample_min_height - tl.tile_sample_stride_height, 0);
+    const int blend_w = std::max(tl.tile_sample_min_width - tl.tile_sample_stride_width, 0);
+    const int oT = (F - 1) * tr + 1, oH = H * r, oW = W * r, BC = B * c.out_channels;
+    auto take = [&](size_t bytes, DevBuf** b) -> int {
+        if (pool_used >= pool.size()) pool.emplace_back();
+        *b = &pool[pool_used++];
+        return (*b)->ensure(bytes);
+    };
+    std::vector<Tile> prev, cur;
+    int oy = 0;
+    for (int i = 0; i < H; i += ts_h) {
+        cur.clear();
+        int ox = 0; int row_h = 0;
+        for (int j = 0; j < W; j += ts_w) {
+            const int h1 = std::min(i + tmin_h, H), w1 = std::min(j + tmin_w, W);
+            const int th = h1 - i, tw = w1 - j;
+            LTX_TRY(v->tile_lat.ensure((size_t)B * F * th * tw * c.latent_channels * esz));
+            LTX_TRY(crop_cl(z, v->tile_lat.p, esz, B, F, H, W, c.latent_channels, 0, F, i, h1, j, w1, s));
+            Tile t; t.t = oT; t.h = th * r; t.w = tw * r;
+            LTX_TRY(take((size_t)BC * t.t * t.h * t.w * sizeof(float), &t.buf));
+            LTX_TRY(decoder_forward(v, v->tile_lat.p, B, F, th, tw, tv, 0, t.buf->as<float>(), s));
+            const size_t ci = cur.size();
+            if (!prev.empty()) {        // blend_v with the (already blended) tile above
+                BlendArgs ba; ba.a = prev[ci].buf->as<float>(); ba.b = t.buf->as<float>(); ba.dst = t.buf->as<float>(); ba.BC = BC;
+                ba.at = prev[ci].t; ba.ah = prev[ci].h; ba.aw = prev[ci].w; ba.a_len = prev[ci].h;
+                ba.bt = ba.dt = t.t; ba.bh = ba.dh = t.h; ba.bw = ba.dw = t.w;
+                ba.dim = 3; ba.blend = std::min(blend_h, std::min(prev[ci].h, t.h));
+                ba.et = t.t; ba.eh = ba.blend; ba.ew = std::min(t.w, prev[ci].w);
+                LTX_TRY(ltx_launch_blend(ba, s));
+            }
+            if (ci > 0) {               // blend_h with the (already blended) tile to the left
+                BlendArgs ba; ba.a = cur[ci - 1].buf->as<float>(); ba.b = t.buf->as<float>(); ba.dst = t.buf->as<float>(); ba.BC = BC;
+                ba.at = cur[ci - 1].t; ba.ah = cur[ci - 1].h; ba.aw = cur[ci - 1].w; ba.a_len = cur[ci - 1].w;
+                ba.bt = ba.dt = t.t; ba.bh = ba.dh = t.h; ba.bw = ba.dw = t.w;
+                ba.dim = 4; ba.blend = std::min(blend_w, std::min(cur[ci - 1].w, t.w));
+                ba.et = t.t; ba.eh = std::min(t.h, cur[ci - 1].h); ba.ew = ba.blend;
+                LTX_TRY(ltx_launch_blend(ba, s));
+            }
+            cur.push_back(t);
+            const int hs = std::min(tl.tile_sample_stride_height, t.h), ws = std::min(tl.tile_sample_stride_width, t.w);
+            const int ch = std::min(hs, oH - oy), cw_ = std::min(ws, oW - ox);
+            if (ch > 0 && cw_ > 0)
+                LTX_TRY(ltx_launch_copy_window(t.buf->as<float>(), t.t, t.h, t.w, out, oT, oH, oW, BC, oT, ch, cw_, 0, oy, ox, s));
+            ox += ws; row_h = hs;
+        }
+        oy += row_h;
+        prev = cur;
+    }
+    return LTX_OK;
+}
+
+int decode_cl(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, const ltx_tiling* tl, int post, float* out, hipStream_t s) {
+    const ltx_vae_config& c = v->cfg;
+    const int r = c.spatial_compression_ratio, tr = c.temporal_compression_ratio;
+    const size_t esz = ltx_dt_size(v->dtype);
+    const int BC = B * c.out_channels;
+    const int oT = (F - 1) * tr + 1, oH = H * r, oW = W * r;
+    const bool framewise = tl && tl->use_framewise_decoding && F > tl->tile_sample_min_num_frames / tr;
+    const bool spatial = tl && tl->use_tiling && (W > tl->tile_sample_min_width / r || H > tl->tile_sample_min_height / r);
+    if (!framewise && !spatial) return decoder_forward(v, z, B, F, H, W, tv, post, out, s);     // vae.rs:2065
+    size_t pool_used = 0;
+    if (!framewise) {
+        LTX_TRY(tiled_decode(v, z, B, F, H, W, tv, *tl, out, v->tilebufs, pool_used, s));
+    } else {
+        // temporal_tiled_decode (vae.rs:2358-2434)
+        const int tmin_t = tl->tile_sample_min_num_frames / tr, tstride_t = tl->tile_sample_stride_num_frames / tr;
+        if (tstride_t < 1) LTX_FAIL(LTX_ERR_ARG, "tiling: temporal stride must be >= one latent frame");
+        const int blend_t = std::max(tl->tile_sample_min_num_frames - tl->tile_sample_stride_num_frames, 0);
+        const int tmin_h = tl->tile_sample_min_height / r, tmin_w = tl->tile_sample_min_width / r;
+        DevBuf zt;                       // temporal latent window
+        int prev_t = 0, prev_stride = 0; int ot = 0; int li = 0;
+        for (int i = 0; i < F; i += tstride_t, ++li) {
+            const int t1 = std::min(i + tmin_t + 1, F), nf = t1 - i;
+            int rc = zt.ensure((size_t)B * nf * H * W * c.latent_channels * esz);
+            if (rc != LTX_OK) { zt.release(); return rc; }
+            rc = crop_cl(z, zt.p, esz, B, F, H, W, c.latent_channels, i, t1, 0, H, 0, W, s);
+            if (rc != LTX_OK) { zt.release(); return rc; }
+            const int dT = (nf - 1) * tr + 1;
+            DevBuf& cur = v->tiles[li & 1];
+            rc = cur.ensure((size_t)BC * dT * oH * oW * sizeof(float));
+            if (rc != LTX_OK) { zt.release(); return rc; }
+            const bool sp = tl->use_tiling && (H > tmin_h || W > tmin_w);
+            size_t pu = 0;
+            rc = sp ? tiled_decode(v, zt.p, B, nf, H, W, tv, *tl, cur.as<float>(), v->tilebufs, pu, s)
+                    : decoder_forward(v, zt.p, B, nf, H, W, tv, 0, cur.as<float>(), s);
+            if (rc != LTX_OK) { zt.release(); return rc; }
+            // "if i > 0: decoded = decoded[:, :, :-1]" — keep the buffer, shrink the logical length
+            int curT = dT; const int stride_full = dT;      // physical T stride of the buffer
+            if (li > 0 && curT > 1) curT -= 1;
+            // result_row: first tile keeps stride+1 frames, later tiles blend_t(row[idx-1], tile) then keep `stride`
+            const int keep = li > 0 ? std::min(tl->tile_sample_stride_num_frames, curT) : std::min(tl->tile_sample_stride_num_frames + 1, curT);
+            const int n = std::min(keep, oT - ot);
+            if (n > 0) {
+                rc = ltx_launch_copy_window(cur.as<float>(), stride_full, oH, oW, out, oT, oH, oW, BC, n, oH, oW, ot, 0, 0, s);
+                if (rc != LTX_OK) { zt.release(); return rc; }
+                if (li > 0) {       // blend against the RAW previous tile (row[idx-1]), written straight into `out`
+                    BlendArgs ba; ba.a = v->tiles[(li - 1) & 1].as<float>(); ba.b = cur.as<float>(); ba.dst = out; ba.BC = BC;
+                    ba.at = prev_stride; ba.ah = oH; ba.aw = oW; ba.a_len = prev_t;
+                    ba.bt = stride_full; ba.bh = oH; ba.bw = oW; ba.dt = oT; ba.dh = oH; ba.dw = oW; ba.ot = ot;
+                    ba.dim = 2; ba.blend = std::min(blend_t, std::min(prev_t, curT));
+                    ba.et = std::min(ba.blend, n); ba.eh = oH; ba.ew = oW;
+                    rc = ltx_launch_blend(ba, s);
+                    if (rc != LTX_OK) { zt.release(); return rc; }
+                }
+            }
+            ot += keep;
+            prev_t = curT; prev_stride = stride_full;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        zt.release();
+    }
+    if (post) LTX_TRY(ltx_launch_postprocess(out, (int64_t)BC * oT * oH * oW, s));
+    return LTX_OK;
+}
+
+}  // namespace
+
+extern "C" void ltx_vae_config_default(ltx_vae_config* c) {
+    c->latent_channels = 128; c->out_channels = 3; c->n_blocks = 3;
+    int boc[4] = {256, 512, 1024, 0}; int lpb[5] = {5, 5, 5, 5, 0}; int upf[4] = {2, 2, 2, 0};
+    for (int i = 0; i < 4; ++i) { c->decoder_block_out_channels[i] = boc[i]; c->decoder_upsample_factor[i] = upf[i]; }
+    for (int i = 0; i < 5; ++i) c->decoder_layers_per_block[i] = lpb[i];
+    c->patch_size = 4; c->patch_size_t = 1; c->timestep_conditioning = 1; c->decoder_causal = 0;
+    c->scaling_factor = 1.0f; c->spatial_compression_ratio = 32; c->temporal_compression_ratio = 8;
+}
+extern "C" void ltx_tiling_default(ltx_tiling* t) {
+    t->use_tiling = 1; t->use_framewise_decoding = 1;
+    t->tile_sample_min_height = 512; t->tile_sample_min_width = 512; t->tile_sample_min_num_frames = 16;
+    t->tile_sample_stride_height = 384; t->tile_sample_stride_width = 384; t->tile_sample_stride_num_frames = 8;
+}
+
+extern "C" int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t n_weights,
+                              ltx_dtype model_dtype, int device, ltx_vae** out) {
+    if (!cfg || !weights || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_create: null argument");
+    *out = nullptr;
+    if (cfg->n_blocks < 1 || cfg->n_blocks > 4) LTX_FAIL(LTX_ERR_ARG, "n_blocks must be 1..4");
+    if (cfg->patch_size != 4 || cfg->patch_size_t != 1) LTX_FAIL(LTX_ERR_UNSUPPORTED, "only patch_size=4, patch_size_t=1 are supported");
+    if (cfg->latent_channels % 8 != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "latent_channels must be a multiple of 8");
+    for (int i = 0; i < cfg->n_blocks; ++i) {
+        if (cfg->decoder_upsample_factor[i] < 1 || cfg->decoder_block_out_channels[i] % (8 * cfg->decoder_upsample_factor[i]) != 0)
+            LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder channels must be multiples of 8*upsample_factor");
+    }
+    HIP_TRY(hipSetDevice(device));
+    ltx_vae* v = new ltx_vae();
+    v->cfg = *cfg; v->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32; v->device = device;
+    int rc = build(v, weights, n_weights);
+    if (rc != LTX_OK) { v->free_all(); delete v; return rc; }
+    *out = v;
+    return LTX_OK;
+}
+extern "C" void ltx_vae_destroy(ltx_vae* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device); (void)hipDeviceSynchronize();
+    v->free_all(); delete v;
+}
+extern "C" int ltx_vae_get_config(const ltx_vae* v, ltx_vae_config* out) {
+    if (!v || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_get_config: null argument");
+    *out = v->cfg; return LTX_OK;
+}
+extern "C" const float* ltx_vae_latents_mean(const ltx_vae* v) { return v ? v->mean : nullptr; }
+extern "C" const float* ltx_vae_latents_std(const ltx_vae* v) { return v ? v->std_ : nullptr; }
+
+static int check_decode_args(ltx_vae* v, int B, int F, int H, int W) {
+    if (!v) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: null handle");
+    if (B < 1 || B > 8 || F < 1 || H < 1 || W < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: bad shape");
+    return LTX_OK;
+}
+
+extern "C" int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtype, const float* timestep,
+                              int B, int F, int H, int W, const ltx_tiling* tiling, int postprocess,
+                              float* out, ltx_stream stream) {
+    LTX_TRY(check_decode_args(v, B, F, H, W));
+    if (!latents || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: null tensor");
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
+    LTX_TRY(v->zin.ensure((size_t)B * S * C * ltx_dt_size(v->dtype)));
+    LTX_TRY(ltx_launch_ncthw_to_cl(latents, io_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32, v->zin.p, v->dtype, B, C, S, s));
+    TimeVec tv; tv.n = B; for (int i = 0; i < 8; ++i) tv.t[i] = (timestep && i < B) ? timestep[i] : 0.f;
+    return decode_cl(v, v->zin.p, B, F, H, W, timestep ? &tv : nullptr, tiling, postprocess, out, s);
+}
+
+extern "C" int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const float* noise, const float* noise_scale,
+                                     const float* timestep, int B, int F, int H, int W, const ltx_tiling* tiling,
+                                     int postprocess, float* out, ltx_stream stream) {
+    LTX_TRY(check_decode_args(v, B, F, H, W));
+    if (!tokens || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode_tokens: null tensor");
+    if (noise && !noise_scale) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode_tokens: noise needs noise_scale");
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
+    LTX_TRY(v->zin.ensure((size_t)B * S * C * ltx_dt_size(v->dtype)));
+    TimeVec ns; ns.n = B; for (int i = 0; i < 8; ++i) ns.t[i] = (noise && i < B) ? noise_scale[i] : 0.f;
+    LTX_TRY(ltx_launch_denorm_mix(tokens, v->mean, v->std_, 1.0f / v->cfg.scaling_factor, noise, ns, v->zin.p, v->dtype, B, S, C, s));
+    TimeVec tv; tv.n = B; for (int i = 0; i < 8; ++i) tv.t[i] = (timestep && i < B) ? timestep[i] : 0.f;
+    return decode_cl(v, v->zin.p, B, F, H, W, timestep ? &tv : nullptr, tiling, postprocess, out, s);
+}

@@ -1,0 +1,228 @@
+// Host side of the drop-in: LtxPipeline::call control flow, FlowMatchEulerDiscreteScheduler scalar
+// math, PCG32 latent generator and video_coords — C++ restatement above the kernel C ABI.
+// Reference: src/models/ltx_video/t2v_pipeline.rs (:627-1073), scheduler.rs (:172-207, 274-412, 495-595,
+// 646-668), src/utils/deterministic_rng.rs (:11-81), examples/ltx-video/main.rs (:567-646).
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../csrc/model_util.h"
+
+extern "C" void ltx_pipeline_params_default(ltx_pipeline_params* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->height = 512; p->width = 768; p->num_frames = 97; p->frame_rate = 25;   // main.rs:627
+    p->num_inference_steps = 7;                                                  // configs.rs:227
+    p->guidance_scale = 1.0f; p->guidance_rescale = 0.0f; p->stg_scale = 0.0f;
+    p->decode_timestep = 0.05f; p->decode_noise_scale = 0.025f;                  // configs.rs:233-234
+    p->shift_terminal = 0.1f; p->use_shift_terminal = 1;                         // configs.rs:101-121
+    p->postprocess = 1;
+}
+
+// calculate_shift (t2v_pipeline.rs:159-169), f32 arithmetic
+extern "C" float ltx_calculate_shift(int seq_len, int base_seq_len, int max_seq_len, float base_shift, float max_shift) {
+    float m = (max_shift - base_shift) / (float)(max_seq_len - base_seq_len);
+    float b = base_shift - m * (float)base_seq_len;
+    return (float)seq_len * m + b;
+}
+
+// set_timesteps with explicit sigmas (scheduler.rs:320-412) + i64 truncation of the trait wrapper (:658-659)
+extern "C" int ltx_sched_set_timesteps(const float* sigmas_in, int n, float mu, int use_mu, float shift,
+                                       float shift_terminal, int use_shift_terminal, float* sigmas_out, int64_t* timesteps_out) {
+    if (!sigmas_in || n < 1 || !sigmas_out) LTX_FAIL(LTX_ERR_ARG, "ltx_sched_set_timesteps: bad argument");
+    std::vector<float> s(sigmas_in, sigmas_in + n);
+    if (use_mu) {                                   // time_shift_scalar, exponential (:172-179), sigma = 1
+        const float emu = std::exp(mu);
+        for (float& v : s) { float base = std::pow(1.0f / v - 1.0f, 1.0f); v = emu / (emu + base); }
+    } else {
+        for (float& v : s) v = shift * v / (1.0f + (shift - 1.0f) * v);
+    }
+    if (use_shift_terminal) {                       // stretch_shift_to_terminal_vec (:188-207)
+        const float one_minus_last = 1.0f - s[n - 1];
+        const float denom = 1.0f - shift_terminal;
+        if (std::fabs(denom) < 1e-12f) LTX_FAIL(LTX_ERR_ARG, "shift_terminal too close to 1.0");
+        const float scale = one_minus_last / denom;
+        for (float& v : s) v = 1.0f - ((1.0f - v) / scale);
+    }
+    for (int i = 0; i < n; ++i) {
+        sigmas_out[i] = s[i];
+        if (timesteps_out) timesteps_out[i] = (int64_t)(s[i] * 1000.0f);
+    }
+    sigmas_out[n] = 0.0f;                           // terminal sigma (:398)
+    return LTX_OK;
+}
+
+// ---- PCG32 (deterministic_rng.rs) ----
+namespace {
+struct Pcg32 {
+    uint64_t state, inc;
+    Pcg32(uint64_t seed, uint64_t inc_) : state(0), inc((inc_ << 1) | 1) { next_u32(); state += seed; next_u32(); }
+    uint32_t next_u32() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t)(old >> 59);
+        return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31));
+    }
+    float next_f32() { return (float)(next_u32() >> 8) * 5.9604645e-8f; }
+    void next_gaussian(float& z0, float& z1) {
+        float u1;
+        do { u1 = next_f32(); } while (!(u1 > 1e-7f));
+        float u2 = next_f32();
+        float mag = std::sqrt(-2.0f * std::log(u1));
+        const float two_pi_u2 = 2.0f * 3.14159265358979323846f * u2;
+        z0 = mag * std::cos(two_pi_u2); z1 = mag * std::sin(two_pi_u2);
+    }
+};
+}  // namespace
+
+extern "C" int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out) {
+    if (!out) LTX_FAIL(LTX_ERR_ARG, "ltx_pcg32_randn: null output");
+    Pcg32 r(seed, inc);
+    for (size_t i = 0; i < n; i += 2) {
+        float a, b; r.next_gaussian(a, b);
+        out[i] = a; if (i + 1 < n) out[i + 1] = b;
+    }
+    return LTX_OK;
+}
+
+// video_coords (t2v_pipeline.rs:798-847): f' = clamp(8f-7, 0, 1000)/frame_rate ; h' = 32h ; w' = 32w
+extern "C" int ltx_build_video_coords(int F, int H, int W, int frame_rate, int ts_ratio, int sp_ratio, float* out) {
+    if (!out || F < 1 || H < 1 || W < 1 || frame_rate < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_build_video_coords: bad argument");
+    const float inv_fr = (float)(1.0 / (double)frame_rate);
+    size_t i = 0;
+    for (int f = 0; f < F; ++f)
+        for (int h = 0; h < H; ++h)
+            for (int w = 0; w < W; ++w) {
+                float vf = (float)f * (float)ts_ratio + (1.0f - (float)ts_ratio);
+                vf = std::fmin(std::fmax(vf, 0.0f), 1000.0f) * inv_fr;
+                out[i++] = vf; out[i++] = (float)h * (float)sp_ratio; out[i++] = (float)w * (float)sp_ratio;
+            }
+    return LTX_OK;
+}
+
+extern "C" int ltx_guidance_step(const void* text, const void* uncond, const void* perturbed, ltx_dtype pred_dtype,
+                                 float* latents, float* noise_pred_out, int B, int64_t n,
+                                 float guidance_scale, float guidance_rescale, float stg_scale, float dt,
+                                 void* stats_ws, ltx_stream stream) {
+    GuidanceArgs a;
+    a.text = text; a.uncond = uncond; a.pert = perturbed; a.pred_dtype = pred_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32;
+    a.latents = latents; a.noise_out = noise_pred_out; a.B = B; a.n_per_batch = n;
+    a.guidance_scale = guidance_scale; a.guidance_rescale = guidance_rescale; a.stg_scale = stg_scale; a.dt = dt;
+    a.stats = reinterpret_cast<double*>(stats_ws);
+    return ltx_launch_guidance_step(a, (hipStream_t)stream);
+}
+
+// ---- LtxPipeline::call ----
+static thread_local float g_timing[4] = {0, 0, 0, 0};
+extern "C" int ltx_pipeline_last_timing(float ms[4]) {
+    if (!ms) LTX_FAIL(LTX_ERR_ARG, "null output");
+    for (int i = 0; i < 4; ++i) ms[i] = g_timing[i];
+    return LTX_OK;
+}
+
+namespace {
+struct PipeScratch {
+    void *p_text = nullptr, *p_uncond = nullptr, *p_pert = nullptr, *coords = nullptr, *stats = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> dit_ev, gs_ev;
+    ~PipeScratch() {
+        void* ps[] = {p_text, p_uncond, p_pert, coords, stats};
+        for (void* p : ps) if (p) (void)hipFree(p);
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& pr : dit_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto& pr : gs_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    }
+};
+}  // namespace
+
+extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
+                                 float* latents, const float* prompt_embeds, const float* prompt_mask,
+                                 const float* neg_embeds, const float* neg_mask, const float* decode_noise,
+                                 int B, int K, float* out_video, ltx_stream stream) {
+    if (!dit || !p || !latents || !prompt_embeds || !prompt_mask) LTX_FAIL(LTX_ERR_ARG, "ltx_pipeline_call: null argument");
+    if (!p->output_latent && (!vae || !out_video)) LTX_FAIL(LTX_ERR_ARG, "ltx_pipeline_call: decode requested without vae/out_video");
+    // check_inputs (:313-365)
+    if (p->height % 32 != 0 || p->width % 32 != 0) LTX_FAIL(LTX_ERR_ARG, "`height` and `width` must be divisible by 32");
+    if (p->num_inference_steps < 1) LTX_FAIL(LTX_ERR_ARG, "num_inference_steps must be >= 1");
+    const bool do_cfg = p->guidance_scale > 1.0f, do_stg = p->stg_scale > 0.0f;      // :304-310
+    if (do_cfg && (!neg_embeds || !neg_mask)) LTX_FAIL(LTX_ERR_ARG, "classifier-free guidance needs negative embeddings and mask");
+    hipStream_t s = (hipStream_t)stream;
+    ltx_dit_config dc; LTX_TRY(ltx_dit_get_config(dit, &dc));
+    int ts_ratio = 8, sp_ratio = 32;
+    if (vae) { ltx_vae_config vc; LTX_TRY(ltx_vae_get_config(vae, &vc)); ts_ratio = vc.temporal_compression_ratio; sp_ratio = vc.spatial_compression_ratio; }
+    const int F = (p->num_frames - 1) / ts_ratio + 1, H = p->height / sp_ratio, W = p->width / sp_ratio;   // :743-745
+    const int S = F * H * W, C = dc.in_channels, L = dc.num_layers;
+    const int64_t n = (int64_t)S * C;
+
+    // skip blocks: permanent iff STG is off (:691-697)
+    if (p->skip_block_list) {
+        if (!do_stg) LTX_TRY(ltx_dit_set_skip_blocks(dit, p->skip_block_list, p->n_skip_blocks));
+        else LTX_TRY(ltx_dit_set_skip_blocks(dit, nullptr, 0));
+    }
+    // sigmas / mu / timesteps (:750-791)
+    const int N = p->num_inference_steps;
+    std::vector<float> sig_in(N), sig(N + 1); std::vector<int64_t> ts(N);
+    const bool custom = p->sigmas != nullptr;
+    for (int i = 0; i < N; ++i)
+        sig_in[i] = custom ? p->sigmas[i] : (N == 1 ? 1.0f : 1.0f + (1.0f / (float)N - 1.0f) * (float)i / (float)(N - 1));
+    const float mu = custom ? 0.0f : ltx_calculate_shift(S, 256, 4096, 0.5f, 1.15f);      // static default cfg (scheduler.rs:638-639)
+    LTX_TRY(ltx_sched_set_timesteps(sig_in.data(), N, mu, 1, 1.0f, p->shift_terminal, p->use_shift_terminal, sig.data(), ts.data()));
+
+    PipeScratch sc;
+    const size_t pred_bytes = (size_t)B * n * sizeof(float);
+    HIP_TRY(hipMalloc(&sc.p_text, pred_bytes));
+    if (do_cfg) HIP_TRY(hipMalloc(&sc.p_uncond, pred_bytes));
+    if (do_stg) HIP_TRY(hipMalloc(&sc.p_pert, pred_bytes));
+    HIP_TRY(hipMalloc(&sc.stats, 64 * B));
+    // video_coords [B,S,3] (:798-847)
+    {
+        std::vector<float> vc((size_t)S * 3), all((size_t)B * S * 3);
+        LTX_TRY(ltx_build_video_coords(F, H, W, p->frame_rate, ts_ratio, sp_ratio, vc.data()));
+        for (int b = 0; b < B; ++b) std::memcpy(all.data() + (size_t)b * S * 3, vc.data(), sizeof(float) * S * 3);
+        HIP_TRY(hipMalloc(&sc.coords, all.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(sc.coords, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(sc.ev[0], s));
+    std::vector<float> stg_mask;
+    if (do_stg) {                                    // :911-923
+        stg_mask.assign((size_t)L * B, 0.0f);
+        for (int i = 0; i < p->n_skip_blocks; ++i) { int li = p->skip_block_list[i]; if (li >= 0 && li < L) for (int b = 0; b < B; ++b) stg_mask[(size_t)li * B + b] = 1.0f; }
+    }
+    const float* coords = reinterpret_cast<const float*>(sc.coords);
+    // denoising loop (:860-994)
+    for (int i = 0; i < N; ++i) {
+        float tvals[8]; for (int b = 0; b < 8; ++b) tvals[b] = (float)ts[i];       // Tensor::full(t as f32, (b,))
+        hipEvent_t e0, e1, e2;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+        sc.dit_ev.emplace_back(e0, e1); sc.gs_ev.emplace_back(e1, e2);
+        HIP_TRY(hipEventRecord(e0, s));
+        if (do_cfg) LTX_TRY(ltx_dit_forward(dit, latents, neg_embeds, tvals, neg_mask, B, S, K, F, H, W, nullptr, coords, nullptr, LTX_F32, sc.p_uncond, s));
+        LTX_TRY(ltx_dit_forward(dit, latents, prompt_embeds, tvals, prompt_mask, B, S, K, F, H, W, nullptr, coords, nullptr, LTX_F32, sc.p_text, s));
+        if (do_stg) LTX_TRY(ltx_dit_forward(dit, latents, prompt_embeds, tvals, prompt_mask, B, S, K, F, H, W, nullptr, coords, stg_mask.data(), LTX_F32, sc.p_pert, s));
+        HIP_TRY(hipEventRecord(e1, s));
+        // guidance mix (:941-962) + scheduler.step (:987; scheduler.rs:544-581): dt = sigma_next - sigma
+        const float dts = sig[i + 1] - sig[i];
+        LTX_TRY(ltx_guidance_step(sc.p_text, do_cfg ? sc.p_uncond : nullptr, do_stg ? sc.p_pert : nullptr, LTX_F32, latents, nullptr, B, n,
+                                  p->guidance_scale, p->guidance_rescale, p->stg_scale, dts, sc.stats, s));
+        HIP_TRY(hipEventRecord(e2, s));
+    }
+    HIP_TRY(hipEventRecord(sc.ev[1], s));
+    if (!p->output_latent) {
+        // unpack + denormalize + noise mix + decode + postprocess (:1002-1070)
+        float tdec[8], nsc[8];
+        for (int b = 0; b < 8; ++b) { tdec[b] = p->decode_timestep; nsc[b] = p->decode_noise_scale; }
+        ltx_vae_config vc; LTX_TRY(ltx_vae_get_config(vae, &vc));
+        const bool tc = vc.timestep_conditioning != 0;
+        LTX_TRY(ltx_vae_decode_tokens(vae, latents, tc ? decode_noise : nullptr, nsc, tc ? tdec : nullptr, B, F, H, W, p->tiling, p->postprocess, out_video, s));
+    }
+    HIP_TRY(hipEventRecord(sc.ev[2], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float dit_ms = 0, gs_ms = 0, t = 0;
+    for (auto& pr : sc.dit_ev) { HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second)); dit_ms += t; }
+    for (auto& pr : sc.gs_ev) { HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second)); gs_ms += t; }
+    g_timing[0] = dit_ms; g_timing[1] = gs_ms;
+    HIP_TRY(hipEventElapsedTime(&g_timing[2], sc.ev[1], sc.ev[2]));
+    HIP_TRY(hipEventElapsedTime(&g_timing[3], sc.ev[0], sc.ev[2]));
+    return LTX_OK;
+}

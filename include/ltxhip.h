@@ -1,0 +1,176 @@
+/* ltxhip.h — C ABI of the MI355X-native LTX-Video denoise + decode engine.
+ *
+ * Drop-in boundary: the two Rust traits candle-video's `LtxPipeline` consumes as
+ * `Box<dyn ...>` (reference: src/models/ltx_video/t2v_pipeline.rs)
+ *     VideoTransformer3D  (:63-83)   ->  ltx_dit_*
+ *     VaeLtxVideo         (:91-103)  ->  ltx_vae_*
+ * plus the device-side pieces of `LtxPipeline::call` (:627-1073) and of
+ * `FlowMatchEulerDiscreteScheduler` (scheduler.rs) that touch tensors
+ *     guidance mix + rescale + Euler step  (t2v_pipeline.rs:941-964, 227-243; scheduler.rs:576-581)
+ *     denormalize + decode-noise mix       (t2v_pipeline.rs:573-594, 1049-1062)
+ * and a whole-pipeline entry (`ltx_pipeline_call`) that reproduces `LtxPipeline::call`
+ * with text embeddings supplied (what examples/ltx-video/main.rs:620-646 does).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero error class otherwise;
+ *     `ltx_last_error()` gives the thread-local message (reference: candle_core::Result / bail!).
+ *   - tensor pointers are DEVICE pointers unless a parameter says "host".
+ *   - the caller owns all tensors it passes; the library owns weights + workspaces.
+ *   - one handle = one device; a handle is not re-entrant (reference: `&mut self`, single stream).
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued on it, nothing blocks
+ *     except workspace (re)allocation on a first/larger call.
+ *   - model dtype: LTX_BF16 is the production path (bf16 storage, f32 accumulate — the reference's
+ *     GPU dtype, main.rs:226); LTX_F32 is the parity path (exact f32 MFMA, reference CPU dtype).
+ */
+#ifndef LTXHIP_H
+#define LTXHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LTX_F32 = 0, LTX_BF16 = 1 } ltx_dtype;
+typedef struct ltx_dit ltx_dit;
+typedef struct ltx_vae ltx_vae;
+typedef void* ltx_stream;   /* hipStream_t */
+
+/* A named weight tensor as found in a safetensors file (host or device memory). */
+typedef struct {
+    const char* name;       /* diffusers-layout name, e.g. "transformer_blocks.0.attn1.to_q.weight" */
+    const void* data;
+    ltx_dtype dtype;        /* dtype of `data` */
+    int ndim;
+    int64_t shape[5];
+    int on_device;          /* 0: host pointer, 1: device pointer */
+} ltx_weight;
+
+/* Mirrors LtxVideoTransformer3DModelConfig (ltx_transformer.rs:23-58). */
+typedef struct {
+    int in_channels, out_channels;
+    int patch_size, patch_size_t;
+    int num_attention_heads, attention_head_dim;
+    int cross_attention_dim;
+    int num_layers;
+    float norm_eps;
+    int caption_channels;
+} ltx_dit_config;
+
+/* Mirrors the decoder-side fields of AutoencoderKLLtxVideoConfig (vae.rs:32-103). */
+typedef struct {
+    int latent_channels, out_channels;
+    int n_blocks;                        /* len(decoder_block_out_channels), <= 4 */
+    int decoder_block_out_channels[4];
+    int decoder_layers_per_block[5];     /* n_blocks + 1 entries */
+    int decoder_upsample_factor[4];
+    int patch_size, patch_size_t;
+    int timestep_conditioning;
+    int decoder_causal;
+    float scaling_factor;
+    int spatial_compression_ratio, temporal_compression_ratio;
+} ltx_vae_config;
+
+/* Tiling parameters of AutoencoderKLLtxVideo (vae.rs:1849-1861); NULL = untiled decode. */
+typedef struct {
+    int use_tiling, use_framewise_decoding;
+    int tile_sample_min_height, tile_sample_min_width, tile_sample_min_num_frames;
+    int tile_sample_stride_height, tile_sample_stride_width, tile_sample_stride_num_frames;
+} ltx_tiling;
+
+const char* ltx_last_error(void);
+void ltx_dit_config_default(ltx_dit_config* cfg);      /* Default impl, ltx_transformer.rs:40-58 */
+void ltx_vae_config_default(ltx_vae_config* cfg);      /* Default impl, vae.rs:68-103 */
+void ltx_tiling_default(ltx_tiling* t);                /* vae.rs:1849-1861 */
+
+/* ---- VideoTransformer3D (LtxVideoTransformer3DModel::new, ltx_transformer.rs:957-1022) ---- */
+int ltx_dit_create(const ltx_dit_config* cfg, const ltx_weight* weights, size_t n_weights,
+                   ltx_dtype model_dtype, int device, ltx_dit** out);
+void ltx_dit_destroy(ltx_dit* m);
+/* VideoTransformer3D::set_skip_block_list (t2v_pipeline.rs:82; ltx_transformer.rs:1024-1026); host ints */
+int ltx_dit_set_skip_blocks(ltx_dit* m, const int* blocks, int n);
+/* VideoTransformer3D::config (t2v_pipeline.rs:55-64) */
+int ltx_dit_get_config(const ltx_dit* m, ltx_dit_config* out);
+/* VideoTransformer3D::forward (t2v_pipeline.rs:68-80; ltx_transformer.rs:1029-1172).
+ *   hidden   [B,S,in_channels]  io_dtype         enc  [B,K,caption_channels] io_dtype
+ *   timestep [B] HOST f32                         enc_mask [B,K] f32 (1 keep / 0 pad) or NULL
+ *   rope_scale: HOST float[3] or NULL             video_coords [B,S,3] f32 or NULL
+ *   skip_layer_mask: HOST f32 [num_layers,B] or NULL (1 = skip)
+ *   out      [B,S,out_channels] io_dtype
+ * B <= 8. */
+int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
+                    const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
+                    const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
+                    ltx_dtype io_dtype, void* out, ltx_stream stream);
+
+/* ---- VaeLtxVideo (AutoencoderKLLtxVideo::new decoder side, vae.rs:1765-1869) ---- */
+/* weight names are the `decoder.*`, `latents_mean`, `latents_std` keys (vae.rs:1521-1608, 1827-1838) */
+int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t n_weights,
+                   ltx_dtype model_dtype, int device, ltx_vae** out);
+void ltx_vae_destroy(ltx_vae* v);
+int ltx_vae_get_config(const ltx_vae* v, ltx_vae_config* out);
+const float* ltx_vae_latents_mean(const ltx_vae* v);   /* device f32 [latent_channels] */
+const float* ltx_vae_latents_std(const ltx_vae* v);
+/* VaeLtxVideo::decode (t2v_pipeline.rs:102; vae.rs:2101-2136, 2459-2462).
+ *   latents  [B,C,F,H,W] io_dtype;  timestep HOST f32 [B] or NULL;  tiling NULL = direct decode
+ *   out      [B,3,8F-7,32H,32W] f32, approx [-1,1]  (or [0,255] when postprocess != 0:
+ *            LtxVideoProcessor::postprocess_video, t2v_pipeline.rs:146-155) */
+int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtype, const float* timestep,
+                   int B, int F, int H, int W, const ltx_tiling* tiling, int postprocess,
+                   float* out, ltx_stream stream);
+/* Same, but from packed tokens [B, F*H*W, C] f32 (the layout the denoise loop carries) with
+ * unpack + denormalize + decode-noise mix fused in (t2v_pipeline.rs:1002-1067).
+ *   noise: [B,C,F,H,W] f32 or NULL;  noise_scale HOST f32 [B] (ignored when noise NULL) */
+int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const float* noise, const float* noise_scale,
+                          const float* timestep, int B, int F, int H, int W, const ltx_tiling* tiling,
+                          int postprocess, float* out, ltx_stream stream);
+
+/* ---- pipeline pieces that touch tensors ---- */
+/* noise_pred = guidance(text, uncond?, perturbed?) ; latents += dt * noise_pred   (all f32 math)
+ *   preds: [B, n] pred_dtype (uncond / perturbed may be NULL); latents [B, n] f32 in place (may be NULL);
+ *   noise_pred_out optional f32 [B,n]; stats_ws: device workspace >= 32*B bytes (needed iff rescale > 0) */
+int ltx_guidance_step(const void* text, const void* uncond, const void* perturbed, ltx_dtype pred_dtype,
+                      float* latents, float* noise_pred_out, int B, int64_t n,
+                      float guidance_scale, float guidance_rescale, float stg_scale, float dt,
+                      void* stats_ws, ltx_stream stream);
+
+/* ---- host-side scalar restatements (no device work) ---- */
+/* FlowMatchEulerDiscreteScheduler::set_timesteps via the Scheduler trait (scheduler.rs:274-412, 646-660).
+ * sigmas_in: n values (custom list or linspace(1, 1/n, n)); writes n+1 sigmas and n truncated timesteps. */
+int ltx_sched_set_timesteps(const float* sigmas_in, int n, float mu, int use_mu, float shift,
+                            float shift_terminal, int use_shift_terminal, float* sigmas_out, int64_t* timesteps_out);
+float ltx_calculate_shift(int seq_len, int base_seq_len, int max_seq_len, float base_shift, float max_shift);
+/* Pcg32::new(seed, inc).randn(n) (utils/deterministic_rng.rs:11-81) into HOST memory */
+int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out_host);
+/* video_coords of LtxPipeline::call (t2v_pipeline.rs:798-847) into HOST memory [F*H*W, 3] */
+int ltx_build_video_coords(int F, int H, int W, int frame_rate, int ts_ratio, int sp_ratio, float* out_host);
+
+/* ---- LtxPipeline::call (t2v_pipeline.rs:627-1073) with embeddings supplied ---- */
+typedef struct {
+    int height, width, num_frames, frame_rate;
+    int num_inference_steps;
+    const float* sigmas;            /* HOST custom sigma list (len num_inference_steps) or NULL */
+    float guidance_scale, guidance_rescale, stg_scale;
+    const int* skip_block_list;     /* HOST */
+    int n_skip_blocks;
+    float decode_timestep, decode_noise_scale;
+    int output_latent;              /* OutputType::Latent: stop before decode */
+    int postprocess;                /* apply postprocess_video */
+    const ltx_tiling* tiling;       /* NULL = untiled */
+    float shift_terminal; int use_shift_terminal;   /* scheduler config (configs.rs:101-121) */
+} ltx_pipeline_params;
+void ltx_pipeline_params_default(ltx_pipeline_params* p);
+/*   latents [B,S,128] f32 packed, updated in place;  prompt_embeds [B,K,4096] f32;  prompt_mask [B,K] f32;
+ *   neg_* may be NULL when guidance_scale <= 1;  decode_noise [B,128,F,H,W] f32 or NULL;
+ *   out_video [B,3,frames,height,width] f32 (ignored when output_latent) */
+int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
+                      float* latents, const float* prompt_embeds, const float* prompt_mask,
+                      const float* neg_embeds, const float* neg_mask, const float* decode_noise,
+                      int B, int K, float* out_video, ltx_stream stream);
+/* per-stage wall time of the last ltx_pipeline_call on this thread, measured with hipEvents:
+ * ms[0] = all DiT forwards, ms[1] = guidance+Euler, ms[2] = VAE decode (+denorm), ms[3] = total */
+int ltx_pipeline_last_timing(float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

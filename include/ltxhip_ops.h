@@ -1,0 +1,58 @@
+/* ltxhip_ops.h — kernel-level C entry points of libltxhip.so.
+ *
+ * These expose the individual fused HIP kernels behind `ltx_dit_forward` / `ltx_vae_decode`
+ * so that parity tests and micro-benchmarks can drive each one through the C ABI with plain
+ * device pointers.  Each entry cites the reference code the kernel replaces
+ * (FerrisMind/candle-video, src/models/ltx_video/...).  dtype: 0 = f32, 1 = bf16 (ltx_dtype).
+ */
+#ifndef LTXHIP_OPS_H
+#define LTXHIP_OPS_H
+#include "ltxhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn::Linear (+ fused epilogue): y[M,N] = epi(x[M,K] @ w[N,K]^T + bias)
+ *   epi 0: none | 1: GELU-tanh (ltx_transformer.rs:214-226) | 2: resid + gate[b,:]*y (:900,:934)
+ *   | 3: resid + y (:909).  gate f32 [M/rows_per_batch, N]. */
+int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, int epi,
+                  const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);
+
+/* RmsNorm / LayerNormNoParams + AdaLN modulate (+SiLU) on rows (ltx_transformer.rs:72-119, 874-889;
+ * vae.rs:148-153, 711-739): y = act(norm(x)[*weight]*(1+scale_b)+shift_b). kind 0 RMS / 1 LN. */
+int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float eps, const void* weight,
+                   const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
+                   int dtype, ltx_stream stream);
+
+/* q/k RMSNorm(weight, eps) over the full inner dim + apply_rotary_emb, in place (ltx_transformer.rs:671-678, 314-339).
+ * cos/sin: f32 [rows, D/2] half-width tables or NULL. */
+int ltx_op_qknorm_rope(void* x, int64_t rows, int D, int ld, const void* weight, float eps,
+                       const float* cos, const float* sin, int dtype, ltx_stream stream);
+
+/* LtxVideoRotaryPosEmbed::forward (ltx_transformer.rs:436-524): half-width tables [B*F*H*W, D/2];
+ * coords f32 [B*S,3] or NULL (then the (f,h,w) grid scaled by rope_scale*patch/base or raw). */
+int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F, int H, int W, int D,
+                      const float* rope_scale_host, ltx_stream stream);
+
+/* LtxAttention core (ltx_transformer.rs:699-741): o = softmax(scale q k^T + bias) v, q [B,Sq,heads*hd] etc. */
+int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                     int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias, int dtype, ltx_stream stream);
+
+/* LtxVideoCausalConv3d 3x3x3 (vae.rs:415-464) on channels-last x [B,T,H,W,Cin] with reference-layout weight
+ * [Cout,Cin,3,3,3] (any dtype `wdtype`); y channels-last [B,T,H,W,Cout]; resid optional [.., Cout]. */
+int ltx_op_conv3d(const void* x, const void* w, const void* bias, int wdtype, void* y, const void* resid,
+                  int B, int T, int H, int W, int Cin, int Cout, int causal, int dtype, ltx_stream stream);
+
+/* LtxVideoUpsampler3d (vae.rs:1090-1169): conv + depth-to-space(2,2,2) + drop first frame + tiled residual.
+ * x [B,T,H,W,Cin] -> y [B,2T-1,2H,2W,Cout/8] channels-last. */
+int ltx_op_upsample3d(const void* x, const void* w, const void* bias, int wdtype, void* y,
+                      int B, int T, int H, int W, int Cin, int Cout, int causal, int residual, int dtype, ltx_stream stream);
+
+/* conv_out + unpatchify(4) (vae.rs:1626-1654, 1724-1725): x [B,T,H,W,Cin] -> f32 NCTHW [B,Cout/16,T,4H,4W]. */
+int ltx_op_conv_out_unpatchify(const void* x, const void* w, const void* bias, int wdtype, float* y,
+                               int B, int T, int H, int W, int Cin, int Cout, int causal, int postprocess, int dtype, ltx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
