@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — end-to-end LTX-Video-2B hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full pass of the hot path over one batch of synthetic input: the distilled
+0.9.8-2B preset's 7 denoise steps (one DiT forward + Euler step each) + denormalize/noise-mix +
+3D-VAE decode + postprocess, producing one 512x768x97 video (configs[1] of BASELINE.json).
+`value` = frames/sec over the whole job; inputs (latents, embeddings, weights) are resident in
+HBM before the timed region.  Multi-GPU: the distilled preset has one forward per step, so the
+denoise loop does not shard ("replicas only") — every rank generates its own video,
+no data-path collective, scaling = weak.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "candle-video_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1]: LTX-Video-0.9.8-2B-distilled bf16, 512x768, 97 frames
+    "c2": dict(height=512, width=768, num_frames=97, name="LTX-Video-0.9.8-2B-distilled 512x768x97, 7 steps (configs.rs:223-240), untiled VAE decode"),
+    # BASELINE.json configs[0]: 256x384, 25 frames (the reference's CPU-runnable case)
+    "c1": dict(height=256, width=384, num_frames=25, name="LTX-Video-0.9.8-2B-distilled 256x384x25, 7 steps"),
+}
+DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232
+PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def dit_flops(S, D=2048, L=28, K=128, Cin=128, Cout=128, Dc=4096):
+    """SURVEY §8d algorithmic FLOPs of one DiT forward."""
+    per_layer = 8 * S * D * D + 4 * S * S * D + 4 * S * D * D + 4 * K * D * D + 4 * S * K * D + 16 * S * D * D
+    return L * per_layer + 2 * S * Cin * D + 2 * S * D * Cout + 2 * K * Dc * D + 2 * K * D * D + (2 * 256 * D + 2 * D * D + 12 * D * D)
+
+
+def vae_flops(F, H, W):
+    """Σ 54·Cin·Cout·T·H·W over the decoder's 45 convs (SURVEY §8a stage table)."""
+    tot = 54 * 128 * 1024 * F * H * W + 10 * 54 * 1024 * 1024 * F * H * W
+    t, h, w, cin = F, H, W, 1024
+    for ch in (512, 256, 128):
+        tot += 54 * cin * (8 * ch) * t * h * w
+        t, h, w = 2 * t - 1, 2 * h, 2 * w
+        tot += 10 * 54 * ch * ch * t * h * w
+        cin = ch
+    return tot + 54 * 128 * 48 * t * h * w
+
+
+def synth_on_device(shapes, dev, seed):
+    """Random-init weights of the real architecture directly in HBM (no checkpoints offline); same
+    scaling rules as oracle.synth_weights so activations stay O(1)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = {}
+    for name, shp in shapes.items():
+        if name.endswith("timestep_scale_multiplier"):
+            w = torch.tensor(1000.0, device=dev)
+        elif "norm_q" in name or "norm_k" in name:
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g, device=dev)
+        elif name.endswith("scale_shift_table"):
+            w = torch.randn(shp, generator=g, device=dev) / math.sqrt(shp[-1])
+        elif name.endswith(".bias"):
+            w = 0.02 * torch.randn(shp, generator=g, device=dev)
+        else:
+            fan_in = 1
+            for s in shp[1:]:
+                fan_in *= s
+            w = torch.randn(shp, generator=g, device=dev, dtype=torch.bfloat16) / math.sqrt(fan_in)
+        out[name] = w
+    return out
+
+
+def cpu_baseline(cfg):
+    """The oracle (a port of the reference's CPU path: f32, un-fused, materialised attention scores,
+    conv3d as per-frame sums of conv2d) timed on this box's host cores on a bounded sample of the SAME
+    workload, scaled to frames/sec:  1 of 28 DiT layers at the full token count (x28 x7 steps) and a
+    VAE decode of a latent crop (scaled by voxel count)."""
+    import ltx_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    F, H, W = (cfg["num_frames"] - 1) // 8 + 1, cfg["height"] // 32, cfg["width"] // 32
+    S = F * H * W
+    dcfg = O.DitConfig(num_layers=1)
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, S, 128, generator=g); enc = torch.randn(1, 128, 4096, generator=g)
+    mask = torch.zeros(1, 128); mask[:, :32] = 1
+    coords = O.build_video_coords(1, F, H, W)
+    t0 = time.time()
+    O.dit_forward(dw, dcfg, x, enc, torch.tensor([1000.0]), mask, F, H, W, None, coords)
+    t_layer = time.time() - t0
+    vcfg = O.VaeConfig()
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=2)
+    cf, chh, cww = 2, 2, 3
+    z = torch.randn(1, 128, cf, chh, cww, generator=g)
+    t0 = time.time()
+    O.decoder_forward(vw, vcfg, z, torch.tensor([0.05]))
+    t_crop = time.time() - t0
+    t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
+    total = 28 * 7 * t_layer + t_vae
+    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"oracle f32 on host: 1 of 28 DiT layers at S={S} ({t_layer:.2f}s, x28x7) + VAE decode of a {cf}x{chh}x{cww} latent crop "
+                      f"({t_crop:.2f}s, scaled by conv FLOPs to {F}x{H}x{W}); estimated {total:.1f}s per video"}
+
+
+def rank_plan(world, rank):
+    """Replicas-only sharding (one forward per step in the distilled preset, so the denoise
+    loop does not partition): every rank owns an independent video; seeds differ per rank."""
+    return {"latent_seed": 42 + rank, "dit_weight_seed": 1 + rank, "vae_weight_seed": 100 + rank, "videos_per_step": 1,
+            "total_videos_per_step": world}
+
+
+def reduce_elapsed(elapsed, dist, device):
+    """max over ranks of the timed region (contract: barrier + sync on both sides, MAX over ranks)."""
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_fps(world, steps, frames, elapsed):
+    return world * steps * frames / elapsed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing pass")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    import ltxhip
+    import ltx_oracle as O
+
+    cfg = CONFIGS[a.config]
+    F, H, W = (cfg["num_frames"] - 1) // 8 + 1, cfg["height"] // 32, cfg["width"] // 32
+    S = F * H * W
+    dcfg = O.DitConfig()
+    plan = rank_plan(world, rank)
+    dit = ltxhip.LtxVideoTransformer3DModel(ltxhip.LtxVideoTransformer3DModelConfig(), synth_on_device(O.dit_weight_shapes(dcfg), dev, plan["dit_weight_seed"]), torch.bfloat16, local)
+    vw = {"decoder." + k: v for k, v in synth_on_device(O.vae_decoder_weight_shapes(O.VaeConfig()), dev, plan["vae_weight_seed"]).items()}
+    vae = ltxhip.AutoencoderKLLtxVideo(ltxhip.AutoencoderKLLtxVideoConfig(), vw, torch.bfloat16, local)
+    del vw
+    torch.cuda.empty_cache()
+    pipe = ltxhip.LtxPipeline(dit, vae)
+    # synthetic inputs per BASELINE.md §3: PCG32 latents seed 42, embeddings N(0,1) seed 42, mask 32 ones, noise seed 44
+    lat = ltxhip.pack_latents(ltxhip.pcg32_randn(plan["latent_seed"], (1, 128, F, H, W))).to(dev)
+    g = torch.Generator().manual_seed(42)
+    pe = torch.randn(1, 128, 4096, generator=g).to(dev)
+    pm = torch.zeros(1, 128); pm[:, :32] = 1; pm = pm.to(dev)
+    noise = torch.randn(1, 128, F, H, W, generator=torch.Generator().manual_seed(44)).to(dev)
+    call = ltxhip.PipelineCall(height=cfg["height"], width=cfg["width"], num_frames=cfg["num_frames"], num_inference_steps=7,
+                               sigmas=DISTILLED_SIGMAS, guidance_scale=1.0, stg_scale=0.0, skip_block_list=[], postprocess=True)
+
+    def step():
+        return pipe.call(call, lat, pe, pm, decode_noise=noise)
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    dit_ms = vae_ms = 0.0
+    for _ in range(a.steps):
+        _, video = step()
+        dit_ms += pipe.last_timing_ms[0]; vae_ms += pipe.last_timing_ms[2]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = reduce_elapsed(elapsed, dist, dev)
+    assert torch.isfinite(video).all()
+
+    out = None
+    if rank == 0:
+        fps = job_fps(world, a.steps, cfg["num_frames"], elapsed)
+        fl_dit, fl_vae = dit_flops(S), vae_flops(F, H, W)
+        out = {"metric": "frames/sec end-to-end LTX-Video-2B 512x768x97; DiT step ms; VAE decode ms", "value": fps, "unit": "frames/sec",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * elapsed / a.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": cfg["name"], "latent_grid": [F, H, W], "tokens": S, "text_tokens": 128,
+                          "denoise_steps": 7, "parallelism": f"replicas x{world} (no data-path collective)"},
+               "dit_step_ms": dit_ms / (7 * a.steps), "vae_decode_ms": vae_ms / a.steps,
+               "dit_tflops": fl_dit / (dit_ms / (7 * a.steps) * 1e-3) / 1e12, "vae_tflops": fl_vae / (vae_ms / a.steps * 1e-3) / 1e12,
+               "algorithmic_tflop_per_video": (7 * fl_dit + fl_vae) / 1e12}
+        if not a.no_prof:
+            # separate, untimed pass with hipEvents around every launch of the heavy kernel classes (on their stream)
+            ltxhip.prof_enable(True)
+            step()
+            kinds = {"gemm_kernel<bf16> (Linear)": 0, "gemm_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_bf16_kernel<64> (self)": 2,
+                     "attn_bf16_kernel<64> (cross)": 3, "rownorm_kernel<bf16>": 4}
+            per = {}
+            for name, k in kinds.items():
+                ms, work, cnt = ltxhip.prof_report(k)
+                per[name] = {"ms_total": ms, "launches": cnt, "avg_ms": ms / max(cnt, 1),
+                             ("GB/s" if k == 4 else "TFLOP/s"): (work / 1e9 if k == 4 else work / 1e12) / max(ms * 1e-3, 1e-12)}
+            ltxhip.prof_enable(False)
+            dom = max((n for n in per if "rownorm" not in n), key=lambda n: per[n]["ms_total"])
+            ach = per[dom]["TFLOP/s"]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": per[dom]["avg_ms"],
+                               "launches_per_video": per[dom]["launches"]}
+            out["kernels"] = per
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -284,6 +284,9 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.Sq <= 0 || a.Sk <= 0 || a.heads <= 0) LTX_FAIL(LTX_ERR_ARG, "attention: empty problem");
+    void* tok = nullptr;
+    ltx_prof_begin(a.bias || a.Sq != a.Sk ? LTX_PROF_ATTN_CROSS : LTX_PROF_ATTN_SELF, 4.0 * a.B * a.heads * (double)a.Sq * a.Sk * a.hd, s, &tok);
+    struct End { void* t; hipStream_t s; ~End() { ltx_prof_end(t, s); } } end_{tok, s};
     if (dtype == LTX_DT_BF16) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         dim3 grid((unsigned)cdiv(a.Sq, BQ), (unsigned)a.heads, (unsigned)a.B), block(256);

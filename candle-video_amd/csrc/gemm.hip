@@ -284,6 +284,11 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     if (g.N % 4 != 0) LTX_FAIL(LTX_ERR_ARG, "gemm: N must be a multiple of 4");
     if (!g.conv && g.lda % ch != 0) LTX_FAIL(LTX_ERR_ARG, "gemm: lda must be 16-byte aligned");
     if ((epi == EPI_D2S || epi == EPI_UNPATCH) && !g.conv) LTX_FAIL(LTX_ERR_ARG, "gemm: d2s/unpatch need conv mode");
-    if (dtype == LTX_DT_BF16) return g.conv ? launch_t<bf16_t, true>(g, epi, s) : launch_t<bf16_t, false>(g, epi, s);
-    return g.conv ? launch_t<float, true>(g, epi, s) : launch_t<float, false>(g, epi, s);
+    void* tok = nullptr;
+    ltx_prof_begin(g.conv ? LTX_PROF_CONV : LTX_PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * (g.conv ? g.ntaps : 1), s, &tok);
+    int rc;
+    if (dtype == LTX_DT_BF16) rc = g.conv ? launch_t<bf16_t, true>(g, epi, s) : launch_t<bf16_t, false>(g, epi, s);
+    else rc = g.conv ? launch_t<float, true>(g, epi, s) : launch_t<float, false>(g, epi, s);
+    ltx_prof_end(tok, s);
+    return rc;
 }

@@ -7,6 +7,11 @@
 enum { LTX_DT_F32 = 0, LTX_DT_BF16 = 1 };
 static inline size_t ltx_dt_size(int dt) { return dt == LTX_DT_BF16 ? 2 : 4; }
 
+// ---------------- optional per-kernel-class event timing (prof.hip) ----------------
+enum { LTX_PROF_GEMM = 0, LTX_PROF_CONV = 1, LTX_PROF_ATTN_SELF = 2, LTX_PROF_ATTN_CROSS = 3, LTX_PROF_ROWNORM = 4, LTX_PROF_NKINDS = 5 };
+bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token);   // work: algorithmic flops (or bytes for ROWNORM)
+void ltx_prof_end(void* token, hipStream_t s);
+
 // ---------------- GEMM / implicit-GEMM conv (gemm.hip) ----------------
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE_RESID = 2, EPI_RESID = 3, EPI_D2S = 4, EPI_UNPATCH = 5 };
 

@@ -1,0 +1,59 @@
+// Optional per-kernel-class timing with HIP events on the launch stream (used by bench.py for the
+// `roofline` object).  Disabled by default: zero overhead on the product path.
+#include <mutex>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "../../include/ltxhip.h"
+
+namespace {
+struct Rec { int kind; hipEvent_t a, b; double work; };
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+bool g_on = false;
+double g_ms[LTX_PROF_NKINDS], g_work[LTX_PROF_NKINDS];
+long long g_cnt[LTX_PROF_NKINDS];
+}  // namespace
+
+bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token) {
+    *token = nullptr;
+    if (!g_on) return false;
+    Rec* r = new Rec{kind, nullptr, nullptr, work};
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return false; }
+    (void)hipEventRecord(r->a, s);
+    *token = r;
+    return true;
+}
+void ltx_prof_end(void* token, hipStream_t s) {
+    if (!token) return;
+    Rec* r = reinterpret_cast<Rec*>(token);
+    (void)hipEventRecord(r->b, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.push_back(*r);
+    delete r;
+}
+
+extern "C" int ltx_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_recs.clear();
+    for (int i = 0; i < LTX_PROF_NKINDS; ++i) { g_ms[i] = 0; g_work[i] = 0; g_cnt[i] = 0; }
+    return LTX_OK;
+}
+// Synchronises the device, folds all recorded launches into per-kind totals and returns one kind.
+extern "C" int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count) {
+    if (kind < 0 || kind >= LTX_PROF_NKINDS) LTX_FAIL(LTX_ERR_ARG, "ltx_prof_report: bad kind");
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.kind] += ms; g_work[r.kind] += r.work; g_cnt[r.kind] += 1; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    if (total_ms) *total_ms = g_ms[kind];
+    if (total_work) *total_work = g_work[kind];
+    if (count) *count = g_cnt[kind];
+    return LTX_OK;
+}

@@ -168,8 +168,11 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     const int lpr = pick_lpr(a.D / ch);
     const int64_t rows_per_block = 4 * (64 / lpr);
     dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
+    void* tok = nullptr;
+    ltx_prof_begin(LTX_PROF_ROWNORM, 2.0 * (double)a.rows * a.D * (dtype == LTX_DT_BF16 ? 2 : 4), s, &tok);
     if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(rownorm_kernel<bf16_t>, grid, block, 0, s, a, lpr);
     else hipLaunchKernelGGL(rownorm_kernel<float>, grid, block, 0, s, a, lpr);
+    ltx_prof_end(tok, s);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

@@ -1,0 +1,595 @@
+"""Host-side mirror of candle-video's LTX pipeline interface over libltxhip.so (C ABI).
+
+Classes and argument meaning follow the reference (FerrisMind/candle-video,
+src/models/ltx_video/):
+
+    LtxVideoTransformer3DModel.forward      ltx_transformer.rs:1029-1172 / trait t2v_pipeline.rs:63-83
+    AutoencoderKLLtxVideo.decode            vae.rs:2101-2136 / trait t2v_pipeline.rs:91-103
+    FlowMatchEulerDiscreteScheduler         scheduler.rs:646-668 (Scheduler trait)
+    LtxPipeline.call                        t2v_pipeline.rs:627-1073
+
+torch is used ONLY as the device-memory / stream provider (tensors in, tensors
+out); every computation happens in the HIP library.  There is no CPU fallback:
+importing this module without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libltxhip.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"ltxhip: {_LIB_PATH} is missing — build it with `make -C candle-video_amd` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+lib = C.CDLL(_LIB_PATH)
+
+LTX_F32, LTX_BF16 = 0, 1
+
+
+class LtxError(RuntimeError):
+    pass
+
+
+lib.ltx_last_error.restype = C.c_char_p
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise LtxError(f"[ltxhip rc={rc}] {lib.ltx_last_error().decode()}")
+
+
+class _Weight(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int), ("ndim", C.c_int),
+                ("shape", C.c_int64 * 5), ("on_device", C.c_int)]
+
+
+class DitConfigC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("in_channels", "out_channels", "patch_size", "patch_size_t",
+                                       "num_attention_heads", "attention_head_dim", "cross_attention_dim", "num_layers")] + \
+               [("norm_eps", C.c_float), ("caption_channels", C.c_int)]
+
+
+class VaeConfigC(C.Structure):
+    _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
+                ("decoder_block_out_channels", C.c_int * 4), ("decoder_layers_per_block", C.c_int * 5),
+                ("decoder_upsample_factor", C.c_int * 4), ("patch_size", C.c_int), ("patch_size_t", C.c_int),
+                ("timestep_conditioning", C.c_int), ("decoder_causal", C.c_int), ("scaling_factor", C.c_float),
+                ("spatial_compression_ratio", C.c_int), ("temporal_compression_ratio", C.c_int)]
+
+
+class TilingC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("use_tiling", "use_framewise_decoding", "tile_sample_min_height", "tile_sample_min_width",
+                                       "tile_sample_min_num_frames", "tile_sample_stride_height", "tile_sample_stride_width",
+                                       "tile_sample_stride_num_frames")]
+
+
+class PipelineParamsC(C.Structure):
+    _fields_ = [("height", C.c_int), ("width", C.c_int), ("num_frames", C.c_int), ("frame_rate", C.c_int),
+                ("num_inference_steps", C.c_int), ("sigmas", C.POINTER(C.c_float)),
+                ("guidance_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
+                ("skip_block_list", C.POINTER(C.c_int)), ("n_skip_blocks", C.c_int),
+                ("decode_timestep", C.c_float), ("decode_noise_scale", C.c_float),
+                ("output_latent", C.c_int), ("postprocess", C.c_int), ("tiling", C.POINTER(TilingC)),
+                ("shift_terminal", C.c_float), ("use_shift_terminal", C.c_int)]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+_SIGS = {
+    "ltx_dit_config_default": [_vp], "ltx_vae_config_default": [_vp], "ltx_tiling_default": [_vp],
+    "ltx_dit_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_dit_destroy": [_vp],
+    "ltx_dit_set_skip_blocks": [_vp, _vp, _i], "ltx_dit_get_config": [_vp, _vp],
+    "ltx_dit_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ltx_vae_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_vae_destroy": [_vp], "ltx_vae_get_config": [_vp, _vp],
+    "ltx_vae_latents_mean": [_vp], "ltx_vae_latents_std": [_vp],
+    "ltx_vae_decode": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    "ltx_vae_decode_tokens": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    "ltx_guidance_step": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp, _vp],
+    "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
+    "ltx_calculate_shift": [_i, _i, _i, _f, _f],
+    "ltx_pcg32_randn": [C.c_uint64, C.c_uint64, _sz, _vp],
+    "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
+    "ltx_pipeline_params_default": [_vp],
+    "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "ltx_pipeline_last_timing": [_vp],
+    "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp],
+    "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
+    "ltx_op_rope_table": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ltx_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "ltx_op_conv3d": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_upsample3d": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
+for _name, _sig in _SIGS.items():
+    _fn = getattr(lib, _name)          # raises AttributeError if the library lacks a declared symbol
+    _fn.argtypes = _sig
+    if _name not in ("ltx_calculate_shift", "ltx_vae_latents_mean", "ltx_vae_latents_std"):
+        _fn.restype = C.c_int
+lib.ltx_calculate_shift.restype = C.c_float
+lib.ltx_vae_latents_mean.restype = C.c_void_p
+lib.ltx_vae_latents_std.restype = C.c_void_p
+
+
+def _dt(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return LTX_F32
+    if t == torch.bfloat16:
+        return LTX_BF16
+    raise LtxError(f"unsupported dtype {t}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise LtxError("tensor must live on the GPU (the library takes device pointers)")
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _make_weights(weights: Dict[str, torch.Tensor]):
+    arr = (_Weight * len(weights))()
+    keep = []
+    for i, (name, t) in enumerate(weights.items()):
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        t = t.contiguous()
+        keep.append(t)
+        nb = name.encode()
+        keep.append(nb)
+        arr[i].name = nb
+        arr[i].data = t.data_ptr()
+        arr[i].dtype = _dt(t.dtype)
+        arr[i].ndim = t.dim()
+        for j in range(t.dim()):
+            arr[i].shape[j] = t.shape[j]
+        arr[i].on_device = 1 if t.is_cuda else 0
+    return arr, keep
+
+
+def _floats(vals) -> "C.Array":
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+# ------------------------------------------------------------------ DiT
+@dataclass
+class LtxVideoTransformer3DModelConfig:          # ltx_transformer.rs:23-58
+    in_channels: int = 128
+    out_channels: int = 128
+    patch_size: int = 1
+    patch_size_t: int = 1
+    num_attention_heads: int = 32
+    attention_head_dim: int = 64
+    cross_attention_dim: int = 2048
+    num_layers: int = 28
+    norm_eps: float = 1e-6
+    caption_channels: int = 4096
+
+
+class LtxVideoTransformer3DModel:
+    """impl VideoTransformer3D (t2v_pipeline.rs:63-83) over ltx_dit_*."""
+
+    def __init__(self, config: LtxVideoTransformer3DModelConfig, weights: Dict[str, torch.Tensor],
+                 dtype: torch.dtype = torch.bfloat16, device: int = 0):
+        self.config = config
+        self.dtype = dtype
+        c = DitConfigC(config.in_channels, config.out_channels, config.patch_size, config.patch_size_t,
+                       config.num_attention_heads, config.attention_head_dim, config.cross_attention_dim,
+                       config.num_layers, config.norm_eps, config.caption_channels)
+        arr, keep = _make_weights(weights)
+        self._h = C.c_void_p()
+        _check(lib.ltx_dit_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.ltx_dit_destroy(h)
+            self._h = None
+
+    def set_skip_block_list(self, blocks: Sequence[int]):
+        arr = (C.c_int * max(len(blocks), 1))(*blocks)
+        _check(lib.ltx_dit_set_skip_blocks(self._h, arr, len(blocks)))
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep,
+                encoder_attention_mask: Optional[torch.Tensor], num_frames: int, height: int, width: int,
+                rope_interpolation_scale: Optional[Tuple[float, float, float]] = None,
+                video_coords: Optional[torch.Tensor] = None,
+                skip_layer_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        io = hidden_states.dtype if hidden_states.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        h = _dev(hidden_states, io)
+        e = _dev(encoder_hidden_states, io)
+        if h.dim() != 3 or e.dim() != 3:
+            raise LtxError("hidden_states must be [B,S,C] and encoder_hidden_states [B,K,C]")
+        B, S, _ = h.shape
+        K = e.shape[1]
+        t = timestep.detach().float().flatten().cpu().tolist() if torch.is_tensor(timestep) else list(timestep)
+        if len(t) != B:
+            raise LtxError(f"timestep must have {B} entries")
+        m = _dev(encoder_attention_mask, torch.float32) if encoder_attention_mask is not None else None
+        vc = _dev(video_coords, torch.float32) if video_coords is not None else None
+        slm = None
+        if skip_layer_mask is not None:
+            slm = _floats(skip_layer_mask.detach().float().cpu().flatten().tolist())
+        rs = _floats(rope_interpolation_scale) if rope_interpolation_scale is not None else None
+        out = torch.empty(B, S, self.config.out_channels, dtype=io, device=h.device)
+        _check(lib.ltx_dit_forward(self._h, _ptr(h), _ptr(e), _floats(t), _ptr(m), B, S, K, num_frames, height, width,
+                                   rs, _ptr(vc), slm, _dt(io), _ptr(out), _stream()))
+        return out
+
+
+# ------------------------------------------------------------------ VAE
+@dataclass
+class AutoencoderKLLtxVideoConfig:               # vae.rs:32-103 (decoder side)
+    latent_channels: int = 128
+    out_channels: int = 3
+    decoder_block_out_channels: Tuple[int, ...] = (256, 512, 1024)
+    decoder_layers_per_block: Tuple[int, ...] = (5, 5, 5, 5)
+    decoder_upsample_factor: Tuple[int, ...] = (2, 2, 2)
+    patch_size: int = 4
+    patch_size_t: int = 1
+    timestep_conditioning: bool = True
+    decoder_causal: bool = False
+    scaling_factor: float = 1.0
+    spatial_compression_ratio: int = 32
+    temporal_compression_ratio: int = 8
+
+
+class AutoencoderKLLtxVideo:
+    """impl VaeLtxVideo (t2v_pipeline.rs:91-103) over ltx_vae_*; tiling fields as vae.rs:1744-1758."""
+
+    def __init__(self, config: AutoencoderKLLtxVideoConfig, weights: Dict[str, torch.Tensor],
+                 dtype: torch.dtype = torch.bfloat16, device: int = 0):
+        self.config = config
+        self.dtype = dtype
+        c = VaeConfigC()
+        c.latent_channels, c.out_channels = config.latent_channels, config.out_channels
+        nb = len(config.decoder_block_out_channels)
+        c.n_blocks = nb
+        for i in range(nb):
+            c.decoder_block_out_channels[i] = config.decoder_block_out_channels[i]
+            c.decoder_upsample_factor[i] = config.decoder_upsample_factor[i]
+        for i in range(nb + 1):
+            c.decoder_layers_per_block[i] = config.decoder_layers_per_block[i]
+        c.patch_size, c.patch_size_t = config.patch_size, config.patch_size_t
+        c.timestep_conditioning = int(config.timestep_conditioning)
+        c.decoder_causal = int(config.decoder_causal)
+        c.scaling_factor = config.scaling_factor
+        c.spatial_compression_ratio = config.spatial_compression_ratio
+        c.temporal_compression_ratio = config.temporal_compression_ratio
+        arr, keep = _make_weights(weights)
+        self._h = C.c_void_p()
+        _check(lib.ltx_vae_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
+        del keep
+        # defaults of examples/ltx-video/main.rs:514-516 (tiling off unless asked)
+        self.use_tiling = False
+        self.use_framewise_decoding = False
+        self.tile_sample_min_height = 512
+        self.tile_sample_min_width = 512
+        self.tile_sample_min_num_frames = 16
+        self.tile_sample_stride_height = 384
+        self.tile_sample_stride_width = 384
+        self.tile_sample_stride_num_frames = 8
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.ltx_vae_destroy(h)
+            self._h = None
+
+    def _tiling(self) -> Optional[TilingC]:
+        if not (self.use_tiling or self.use_framewise_decoding):
+            return None
+        return TilingC(int(self.use_tiling), int(self.use_framewise_decoding), self.tile_sample_min_height,
+                       self.tile_sample_min_width, self.tile_sample_min_num_frames, self.tile_sample_stride_height,
+                       self.tile_sample_stride_width, self.tile_sample_stride_num_frames)
+
+    def decode(self, latents: torch.Tensor, timestep=None, postprocess: bool = False) -> torch.Tensor:
+        io = latents.dtype if latents.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        z = _dev(latents, io)
+        if z.dim() != 5 or z.shape[1] != self.config.latent_channels:
+            raise LtxError("latents must be [B, latent_channels, F, H, W]")
+        B, _, F, H, W = z.shape
+        t = None
+        if timestep is not None:
+            tv = timestep.detach().float().flatten().cpu().tolist() if torch.is_tensor(timestep) else list(timestep)
+            if len(tv) != B:
+                raise LtxError(f"timestep must have {B} entries")
+            t = _floats(tv)
+        r, tr = self.config.spatial_compression_ratio, self.config.temporal_compression_ratio
+        out = torch.empty(B, self.config.out_channels, (F - 1) * tr + 1, H * r, W * r, dtype=torch.float32, device=z.device)
+        tl = self._tiling()
+        _check(lib.ltx_vae_decode(self._h, _ptr(z), _dt(io), t, B, F, H, W, C.byref(tl) if tl else None, int(postprocess),
+                                  _ptr(out), _stream()))
+        return out
+
+    def decode_tokens(self, tokens: torch.Tensor, F: int, H: int, W: int, timestep=None, noise: Optional[torch.Tensor] = None,
+                      noise_scale=None, postprocess: bool = False) -> torch.Tensor:
+        x = _dev(tokens, torch.float32)
+        B = x.shape[0]
+        t = _floats(list(timestep)) if timestep is not None else None
+        ns = _floats(list(noise_scale)) if noise_scale is not None else None
+        nz = _dev(noise, torch.float32) if noise is not None else None
+        r, tr = self.config.spatial_compression_ratio, self.config.temporal_compression_ratio
+        out = torch.empty(B, self.config.out_channels, (F - 1) * tr + 1, H * r, W * r, dtype=torch.float32, device=x.device)
+        tl = self._tiling()
+        _check(lib.ltx_vae_decode_tokens(self._h, _ptr(x), _ptr(nz), ns, t, B, F, H, W, C.byref(tl) if tl else None,
+                                         int(postprocess), _ptr(out), _stream()))
+        return out
+
+    def latents_mean(self) -> torch.Tensor:
+        lib.ltx_vae_latents_mean.restype = C.c_void_p
+        p = lib.ltx_vae_latents_mean(self._h)
+        out = torch.empty(self.config.latent_channels, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        _hip_memcpy_d2d(out.data_ptr(), p, 4 * self.config.latent_channels)
+        return out
+
+    def latents_std(self) -> torch.Tensor:
+        lib.ltx_vae_latents_std.restype = C.c_void_p
+        p = lib.ltx_vae_latents_std(self._h)
+        out = torch.empty(self.config.latent_channels, dtype=torch.float32, device="cuda")
+        _hip_memcpy_d2d(out.data_ptr(), p, 4 * self.config.latent_channels)
+        return out
+
+
+def _hip_memcpy_d2d(dst: int, src: int, nbytes: int):
+    hip = C.CDLL("libamdhip64.so")
+    rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise LtxError(f"hipMemcpy failed rc={rc}")
+
+
+# ------------------------------------------------------------------ scheduler / host helpers
+lib.ltx_calculate_shift.restype = C.c_float
+
+
+def calculate_shift(seq_len: int, base_seq_len: int = 256, max_seq_len: int = 4096,
+                    base_shift: float = 0.5, max_shift: float = 1.15) -> float:
+    return float(lib.ltx_calculate_shift(seq_len, base_seq_len, max_seq_len, C.c_float(base_shift), C.c_float(max_shift)))
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """Scheduler trait (t2v_pipeline.rs:28-37) as implemented at scheduler.rs:646-668."""
+
+    def __init__(self, shift: float = 1.0, shift_terminal: Optional[float] = 0.1):
+        self.shift = shift
+        self.shift_terminal = shift_terminal
+        self.sigmas: List[float] = []
+        self.timesteps: List[int] = []
+        self.step_index = 0
+
+    def set_timesteps(self, sigmas: Sequence[float], mu: Optional[float]) -> List[int]:
+        n = len(sigmas)
+        sin = _floats(sigmas)
+        sout = (C.c_float * (n + 1))()
+        tout = (C.c_int64 * n)()
+        _check(lib.ltx_sched_set_timesteps(sin, n, C.c_float(mu if mu is not None else 0.0), int(mu is not None),
+                                           C.c_float(self.shift), C.c_float(self.shift_terminal or 0.0),
+                                           int(self.shift_terminal is not None), sout, tout))
+        self.sigmas = list(sout)
+        self.timesteps = list(tout)
+        self.step_index = 0
+        return self.timesteps
+
+    def step(self, noise_pred: torch.Tensor, timestep: int, latents: torch.Tensor) -> torch.Tensor:
+        """x + (sigma_next - sigma) * v, f32, in place on a copy (scheduler.rs:544-581)."""
+        dt = C.c_float(self.sigmas[self.step_index + 1]).value - C.c_float(self.sigmas[self.step_index]).value
+        x = _dev(latents, torch.float32).clone()
+        p = _dev(noise_pred)
+        B = x.shape[0]
+        _check(lib.ltx_guidance_step(_ptr(p), None, None, _dt(p.dtype), _ptr(x), None, B, C.c_int64(x[0].numel()),
+                                     C.c_float(1.0), C.c_float(0.0), C.c_float(0.0), C.c_float(dt), None, _stream()))
+        self.step_index += 1
+        return x
+
+
+def guidance_combine(text, uncond=None, perturbed=None, guidance_scale=1.0, guidance_rescale=0.0, stg_scale=0.0):
+    """CFG/STG mix of t2v_pipeline.rs:941-964 (returns the f32 combined prediction)."""
+    t = _dev(text)
+    u = _dev(uncond, t.dtype) if uncond is not None else None
+    p = _dev(perturbed, t.dtype) if perturbed is not None else None
+    B = t.shape[0]
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    ws = torch.zeros(8 * B, dtype=torch.float64, device=t.device)
+    _check(lib.ltx_guidance_step(_ptr(t), _ptr(u), _ptr(p), _dt(t.dtype), None, _ptr(out), B, C.c_int64(t[0].numel()),
+                                 C.c_float(guidance_scale), C.c_float(guidance_rescale), C.c_float(stg_scale), C.c_float(0.0),
+                                 _ptr(ws), _stream()))
+    return out
+
+
+def pcg32_randn(seed: int, shape: Sequence[int], inc: int = 1442695040888963407) -> torch.Tensor:
+    """Pcg32::new(seed, inc).randn(shape) (deterministic_rng.rs; main.rs:568) -> CPU f32 tensor."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    out = torch.empty(n, dtype=torch.float32)
+    _check(lib.ltx_pcg32_randn(C.c_uint64(seed), C.c_uint64(inc), C.c_size_t(n), C.c_void_p(out.data_ptr())))
+    return out.reshape(*shape)
+
+
+def build_video_coords(F: int, H: int, W: int, frame_rate: int = 25, ts_ratio: int = 8, sp_ratio: int = 32) -> torch.Tensor:
+    out = torch.empty(F * H * W, 3, dtype=torch.float32)
+    _check(lib.ltx_build_video_coords(F, H, W, frame_rate, ts_ratio, sp_ratio, C.c_void_p(out.data_ptr())))
+    return out
+
+
+def pack_latents(x: torch.Tensor) -> torch.Tensor:
+    """LtxPipeline::pack_latents with patch sizes 1 (t2v_pipeline.rs:474-504): a pure layout view."""
+    b, c, f, h, w = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c).contiguous()
+
+
+# ------------------------------------------------------------------ pipeline
+@dataclass
+class PipelineCall:
+    height: int = 512
+    width: int = 768
+    num_frames: int = 97
+    frame_rate: int = 25
+    num_inference_steps: int = 7
+    sigmas: Optional[List[float]] = None
+    guidance_scale: float = 1.0
+    guidance_rescale: float = 0.0
+    stg_scale: float = 0.0
+    skip_block_list: Optional[List[int]] = None
+    decode_timestep: float = 0.05
+    decode_noise_scale: float = 0.025
+    output_latent: bool = False
+    postprocess: bool = True
+    shift_terminal: Optional[float] = 0.1
+
+
+class LtxPipeline:
+    """LtxPipeline (t2v_pipeline.rs:245-302) holding the two boxed components that matter here."""
+
+    def __init__(self, transformer: LtxVideoTransformer3DModel, vae: Optional[AutoencoderKLLtxVideo]):
+        self.transformer = transformer
+        self.vae = vae
+        self.last_timing_ms = (0.0, 0.0, 0.0, 0.0)
+
+    def call(self, args: PipelineCall, latents: torch.Tensor, prompt_embeds: torch.Tensor, prompt_attention_mask: torch.Tensor,
+             negative_prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_attention_mask: Optional[torch.Tensor] = None,
+             decode_noise: Optional[torch.Tensor] = None):
+        """Returns (final_latents [B,S,C] f32, video [B,3,frames,H,W] f32 or None)."""
+        lat = _dev(latents, torch.float32).clone()
+        pe = _dev(prompt_embeds, torch.float32)
+        pm = _dev(prompt_attention_mask, torch.float32)
+        ne = _dev(negative_prompt_embeds, torch.float32) if negative_prompt_embeds is not None else None
+        nm = _dev(negative_prompt_attention_mask, torch.float32) if negative_prompt_attention_mask is not None else None
+        dn = _dev(decode_noise, torch.float32) if decode_noise is not None else None
+        B, K = pe.shape[0], pe.shape[1]
+        p = PipelineParamsC()
+        lib.ltx_pipeline_params_default(C.byref(p))
+        p.height, p.width, p.num_frames, p.frame_rate = args.height, args.width, args.num_frames, args.frame_rate
+        p.num_inference_steps = args.num_inference_steps
+        keep = []
+        if args.sigmas is not None:
+            s = _floats(args.sigmas); keep.append(s)
+            p.sigmas = C.cast(s, C.POINTER(C.c_float))
+        p.guidance_scale, p.guidance_rescale, p.stg_scale = args.guidance_scale, args.guidance_rescale, args.stg_scale
+        if args.skip_block_list is not None:
+            sb = (C.c_int * max(len(args.skip_block_list), 1))(*args.skip_block_list); keep.append(sb)
+            p.skip_block_list = C.cast(sb, C.POINTER(C.c_int))
+            p.n_skip_blocks = len(args.skip_block_list)
+        p.decode_timestep, p.decode_noise_scale = args.decode_timestep, args.decode_noise_scale
+        p.output_latent, p.postprocess = int(args.output_latent), int(args.postprocess)
+        p.shift_terminal = args.shift_terminal if args.shift_terminal is not None else 0.0
+        p.use_shift_terminal = int(args.shift_terminal is not None)
+        tl = self.vae._tiling() if self.vae is not None else None
+        if tl is not None:
+            keep.append(tl)
+            p.tiling = C.pointer(tl)
+        video = None
+        if not args.output_latent:
+            if self.vae is None:
+                raise LtxError("decode requested but the pipeline has no VAE")
+            video = torch.empty(B, 3, args.num_frames, args.height, args.width, dtype=torch.float32, device=lat.device)
+        _check(lib.ltx_pipeline_call(self.transformer._h, self.vae._h if self.vae is not None else None, C.byref(p),
+                                     _ptr(lat), _ptr(pe), _ptr(pm), _ptr(ne), _ptr(nm), _ptr(dn), B, K,
+                                     _ptr(video), _stream()))
+        ms = (C.c_float * 4)()
+        _check(lib.ltx_pipeline_last_timing(ms))
+        self.last_timing_ms = tuple(ms)
+        return lat, video
+
+
+# ------------------------------------------------------------------ kernel-level ops (include/ltxhip_ops.h)
+class ops:
+    @staticmethod
+    def linear(x, w, bias=None, epi=0, resid=None, gate=None, rows_per_batch=1):
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        _check(lib.ltx_op_linear(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), M, N, K, _dt(x.dtype), epi,
+                                 _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
+        return y
+
+    @staticmethod
+    def rownorm(x, kind=0, eps=1e-6, weight=None, scale=None, shift=None, rows_per_batch=1, act=0):
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        ms = scale.shape[-1] if scale is not None else 0
+        _check(lib.ltx_op_rownorm(_ptr(x.contiguous()), _ptr(y), C.c_int64(rows), D, kind, C.c_float(eps), _ptr(weight),
+                                  _ptr(scale), _ptr(shift), C.c_int64(rows_per_batch), ms, act, _dt(x.dtype), _stream()))
+        return y
+
+    @staticmethod
+    def qknorm_rope(x, weight, eps=1e-5, cos=None, sin=None):
+        x = x.clone().contiguous()
+        rows, D = x.shape
+        _check(lib.ltx_op_qknorm_rope(_ptr(x), C.c_int64(rows), D, D, _ptr(weight), C.c_float(eps), _ptr(cos), _ptr(sin),
+                                      _dt(x.dtype), _stream()))
+        return x
+
+    @staticmethod
+    def rope_table(B, F, H, W, D, coords=None, rope_scale=None, device="cuda"):
+        cos = torch.empty(B * F * H * W, D // 2, dtype=torch.float32, device=device)
+        sin = torch.empty_like(cos)
+        _check(lib.ltx_op_rope_table(_ptr(cos), _ptr(sin), _ptr(coords), B, F, H, W, D,
+                                     _floats(rope_scale) if rope_scale is not None else None, _stream()))
+        return cos, sin
+
+    @staticmethod
+    def attention(q, k, v, heads, scale, key_bias=None):
+        B, Sq, D = q.shape
+        Sk = k.shape[1]
+        o = torch.empty_like(q)
+        _check(lib.ltx_op_attention(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, Sk, heads, D // heads,
+                                    D, D, D, D, C.c_float(scale), _ptr(key_bias), _dt(q.dtype), _stream()))
+        return o
+
+    @staticmethod
+    def conv3d(x_cl, w, bias, causal=False, resid=None):
+        B, T, H, W, Cin = x_cl.shape
+        Cout = w.shape[0]
+        y = torch.empty(B, T, H, W, Cout, dtype=x_cl.dtype, device=x_cl.device)
+        _check(lib.ltx_op_conv3d(_ptr(x_cl.contiguous()), _ptr(w.contiguous()), _ptr(bias.to(w.dtype).contiguous()), _dt(w.dtype), _ptr(y), _ptr(resid),
+                                 B, T, H, W, Cin, Cout, int(causal), _dt(x_cl.dtype), _stream()))
+        return y
+
+    @staticmethod
+    def upsample3d(x_cl, w, bias, causal=False, residual=True):
+        B, T, H, W, Cin = x_cl.shape
+        Cout = w.shape[0]
+        y = torch.empty(B, 2 * T - 1, 2 * H, 2 * W, Cout // 8, dtype=x_cl.dtype, device=x_cl.device)
+        _check(lib.ltx_op_upsample3d(_ptr(x_cl.contiguous()), _ptr(w.contiguous()), _ptr(bias.to(w.dtype).contiguous()), _dt(w.dtype), _ptr(y),
+                                     B, T, H, W, Cin, Cout, int(causal), int(residual), _dt(x_cl.dtype), _stream()))
+        return y
+
+    @staticmethod
+    def conv_out_unpatchify(x_cl, w, bias, causal=False, postprocess=False):
+        B, T, H, W, Cin = x_cl.shape
+        Cout = w.shape[0]
+        y = torch.empty(B, Cout // 16, T, 4 * H, 4 * W, dtype=torch.float32, device=x_cl.device)
+        _check(lib.ltx_op_conv_out_unpatchify(_ptr(x_cl.contiguous()), _ptr(w.contiguous()), _ptr(bias.to(w.dtype).contiguous()), _dt(w.dtype), _ptr(y),
+                                              B, T, H, W, Cin, Cout, int(causal), int(postprocess), _dt(x_cl.dtype), _stream()))
+        return y
+
+
+def prof_enable(on: bool):
+    _check(lib.ltx_prof_enable(int(on)))
+
+
+def prof_report(kind: int):
+    """-> (total_ms, total_work, count) for kernel class `kind` since prof_enable(True)."""
+    ms, work, cnt = C.c_double(), C.c_double(), C.c_longlong()
+    _check(lib.ltx_prof_report(kind, C.byref(ms), C.byref(work), C.byref(cnt)))
+    return ms.value, work.value, cnt.value

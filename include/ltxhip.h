@@ -170,6 +170,14 @@ int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
  * ms[0] = all DiT forwards, ms[1] = guidance+Euler, ms[2] = VAE decode (+denorm), ms[3] = total */
 int ltx_pipeline_last_timing(float ms[4]);
 
+/* ---- optional measurement hooks (bench.py roofline object) ----
+ * kinds: 0 linear GEMM, 1 conv3d implicit GEMM, 2 self-attention, 3 cross-attention, 4 row norms.
+ * When enabled, every launch of those kernels is bracketed by hipEvents on ITS stream; report()
+ * synchronises and returns the accumulated kernel time, algorithmic work (flops; bytes for kind 4)
+ * and launch count since the last enable(). */
+int ltx_prof_enable(int on);
+int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count);
+
 #ifdef __cplusplus
 }
 #endif

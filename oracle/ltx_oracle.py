@@ -974,9 +974,8 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
     if vae_cfg.timestep_conditioning:
         temb = torch.full((b,), args.decode_timestep, dtype=torch.float32)
         sc = args.decode_timestep if args.decode_noise_scale is None else args.decode_noise_scale
-        if decode_noise is None:
-            decode_noise = torch.zeros_like(x)
-        x = x * (1.0 - sc) + decode_noise.to(x.dtype) * sc
+        if decode_noise is not None:      # caller-supplied noise; None = skip the mix (API extension)
+            x = x * (1.0 - sc) + decode_noise.to(x.dtype) * sc
     x = x.to(dtype)
     v = vae_decode(vae_p, vae_cfg, x, temb, dtype, args.use_tiling, args.use_framewise_decoding)
     return postprocess_video(v)

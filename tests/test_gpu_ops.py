@@ -1,0 +1,237 @@
+"""GPU suite, part 1: every fused HIP kernel, driven through the C ABI (include/ltxhip_ops.h), against
+the CPU oracle's restatement of the reference op it replaces.
+
+Tolerances (stated once):
+  f32 mode  : max|hip - oracle| / max|oracle| <= 1e-3   (north_star bar; in practice ~1e-6..1e-5)
+  bf16 mode : inputs are rounded to bf16 first and the oracle is evaluated IN F32 on those rounded
+              inputs; the HIP result (bf16 storage, f32 accumulate) must be within rel-L2 <= 1.5e-2
+              (two bf16 roundings: eps_bf16 = 2^-8 = 3.9e-3 per rounding).
+"""
+import math
+
+import pytest
+import torch
+
+import ltx_oracle as O
+from conftest import rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+F32_TOL = 1e-3
+BF16_TOL = 1.5e-2
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    assert torch.cuda.is_available()
+    return ltxhip
+
+
+def rnd(dt, *shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dt)
+
+
+def check(out, ref, dt):
+    out = out.float().cpu()
+    assert torch.isfinite(out).all()
+    if dt == torch.float32:
+        assert rel_max(out, ref) <= F32_TOL, rel_max(out, ref)
+    else:
+        assert rel_l2(out, ref) <= BF16_TOL, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(384, 256, 128), (130, 96, 72), (1, 512, 256), (10, 32, 32), (4992, 256, 2048)])
+def test_linear_bias(hip, dt, M, N, K):
+    x, w, b = rnd(dt, M, K), rnd(dt, N, K, scale=K ** -0.5), rnd(dt, N, scale=0.1)
+    y = hip.ops.linear(x.cuda(), w.cuda(), b.cuda())
+    check(y, O.linear(x.float(), w.float(), b.float()), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_linear_epilogues(hip, dt):
+    M, N, K, S = 256, 192, 160, 128
+    x, w, b = rnd(dt, M, K), rnd(dt, N, K, scale=K ** -0.5), rnd(dt, N, scale=0.1)
+    r = rnd(dt, M, N, seed=3)
+    gate = rnd(torch.float32, M // S, N, seed=4)
+    lin = O.linear(x.float(), w.float(), b.float())
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=1), O.gelu_approximate(lin), dt)
+    want = r.float() + gate.repeat_interleave(S, 0) * lin
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=2, resid=r.cuda(), gate=gate.cuda(), rows_per_batch=S), want, dt)
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=3, resid=r.cuda()), r.float() + lin, dt)
+    check(hip.ops.linear(x.cuda(), w.cuda(), None), O.linear(x.float(), w.float(), None), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,D", [(200, 2048), (77, 128), (33, 16), (5, 4096)])
+def test_rownorm_rms_modulate(hip, dt, rows, D):
+    x = rnd(dt, rows, D, scale=3.0)
+    B = 1
+    scale, shift = rnd(torch.float32, B, D, seed=1), rnd(torch.float32, B, D, seed=2)
+    y = hip.ops.rownorm(x.cuda(), 0, 1e-6, None, scale.cuda(), shift.cuda(), rows, 0)
+    ref = O.rms_norm(x.float(), None, 1e-6) * (1 + scale) + shift
+    check(y, ref, dt)
+    y2 = hip.ops.rownorm(x.cuda(), 0, 1e-8, None, scale.cuda(), shift.cuda(), rows, 1)          # VAE: eps 1e-8 + SiLU
+    check(y2, torch.nn.functional.silu(O.rms_norm(x.float(), None, 1e-8) * (1 + scale) + shift), dt)
+    y3 = hip.ops.rownorm(x.cuda(), 0, 1e-6)                                                     # plain RMS
+    check(y3, O.rms_norm(x.float(), None, 1e-6), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rownorm_layernorm_batched_mod(hip, dt):
+    B, S, D = 2, 40, 256
+    x = rnd(dt, B * S, D, scale=2.0) + 0.5
+    scale, shift = rnd(torch.float32, B, D, seed=1), rnd(torch.float32, B, D, seed=2)
+    y = hip.ops.rownorm(x.cuda(), 1, 1e-6, None, scale.cuda(), shift.cuda(), S, 0)
+    ref = O.layer_norm_no_params(x.float().reshape(B, S, D), 1e-6) * (1 + scale[:, None]) + shift[:, None]
+    check(y, ref.reshape(B * S, D), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("grid,D", [((2, 8, 8), 2048), ((4, 8, 12), 128), ((2, 4, 4), 64), ((1, 2, 3), 32)])
+def test_rope_table_and_qknorm_rope(hip, dt, grid, D):
+    Fr, H, W = grid
+    S = Fr * H * W
+    coords = O.build_video_coords(1, Fr, H, W)
+    cos, sin = O.rope_cos_sin(D, 1, Fr, H, W, None, coords)
+    c, s = hip.ops.rope_table(1, Fr, H, W, D, coords=coords[0].cuda())
+    # bar: tests/verify_rope_parity.rs:253-254 MSE < 1e-5 (angles reach ~1.5e4 rad in f32: ulp-level freq noise is visible)
+    assert ((c.cpu() - cos[0, :, ::2]) ** 2).mean() < 1e-5 and ((s.cpu() - sin[0, :, ::2]) ** 2).mean() < 1e-5
+    assert torch.equal(c.cpu()[:, : (D % 6) // 2], torch.ones(S, (D % 6) // 2))
+    x = rnd(dt, S, D, scale=2.0)
+    w = (1 + 0.1 * rnd(torch.float32, D, seed=9)).to(dt)
+    y = hip.ops.qknorm_rope(x.cuda(), w.cuda(), 1e-5, c, s)
+    # reference semantics with the SAME tables (isolates the kernel from trig noise)
+    ref = O.apply_rotary_emb(O.rms_norm(x.float()[None], w.float(), 1e-5), c.cpu().repeat_interleave(2, -1)[None], s.cpu().repeat_interleave(2, -1)[None])[0]
+    check(y, ref, dt)
+    check(hip.ops.qknorm_rope(x.cuda(), w.cuda(), 1e-5), O.rms_norm(x.float(), w.float(), 1e-5), dt)
+
+
+def test_rope_table_grid_path(hip):
+    # prepare_video_coords path (ltx_transformer.rs:373-433) with rope_interpolation_scale (1,1,1), tests/verify_dit_parity.rs
+    Fr, H, W, D = 3, 4, 5, 64
+    cos, sin = O.rope_cos_sin(D, 2, Fr, H, W, (1.0, 1.0, 1.0), None)
+    c, s = hip.ops.rope_table(2, Fr, H, W, D, rope_scale=(1.0, 1.0, 1.0))
+    assert (c.cpu() - cos.reshape(-1, D)[:, ::2]).abs().max() < 1e-4 and (s.cpu() - sin.reshape(-1, D)[:, ::2]).abs().max() < 1e-4
+
+
+def ref_attention(q, k, v, heads, scale, bias):
+    B, Sq, D = q.shape
+    hd = D // heads
+    qf = q.float().reshape(B, Sq, heads, hd).transpose(1, 2)
+    kf = k.float().reshape(B, -1, heads, hd).transpose(1, 2)
+    vf = v.float().reshape(B, -1, heads, hd).transpose(1, 2)
+    att = qf @ kf.transpose(-1, -2) * scale
+    if bias is not None:
+        att = att + bias[:, None, None, :]
+    return (torch.softmax(att, -1) @ vf).transpose(1, 2).reshape(B, Sq, D)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd,heads,Sq,Sk,B,biased", [(64, 2, 384, 384, 1, False), (64, 3, 200, 128, 2, True), (16, 4, 256, 10, 1, False),
+                                                     (32, 2, 130, 70, 1, True), (128, 2, 160, 192, 1, False), (16, 2, 2048, 2048, 1, False)])
+def test_attention(hip, dt, hd, heads, Sq, Sk, B, biased):
+    D = hd * heads
+    q, k, v = rnd(dt, B, Sq, D), rnd(dt, B, Sk, D, seed=1), rnd(dt, B, Sk, D, seed=2)
+    bias = None
+    if biased:
+        bias = torch.zeros(B, Sk); bias[:, Sk // 4:] = -10000.0; bias[0, 3] = -2.5
+    scale = 1.0 / math.sqrt(hd)
+    o = hip.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, scale, bias.cuda() if biased else None)
+    check(o, ref_attention(q, k, v, heads, scale, bias), dt)
+
+
+def test_attention_online_softmax_rescale_branch(hip):
+    # force the running max to jump late (rule: a rare data-dependent path needs its own input)
+    hd, heads, S = 64, 1, 320
+    q = torch.randn(1, S, hd).bfloat16(); k = torch.randn(1, S, hd).bfloat16(); v = torch.randn(1, S, hd).bfloat16()
+    k[0, 300] = q[0, 5] * 8.0            # key 300 (last tile) dominates query 5
+    o = hip.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, 0.125)
+    ref = ref_attention(q, k, v, heads, 0.125, None)
+    assert rel_l2(o.float().cpu(), ref) <= BF16_TOL
+    assert (o.float().cpu()[0, 5] - v.float()[0, 300]).abs().max() < 0.05
+
+
+def cl(x):            # NCTHW -> channels-last
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncthw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("causal", [False, True])
+def test_conv3d_known_answer(hip, golden, dt, causal):
+    g = golden("oracle_ops.safetensors")
+    x, w, b = g["conv_x"].to(dt), g["conv_w"].to(dt), g["conv_b"].to(dt)
+    y = hip.ops.conv3d(cl(x).cuda(), w.cuda(), b.cuda(), causal)
+    ref = O.causal_conv3d(x.float(), w.float(), b.float(), causal)
+    check(ncthw(y), ref, dt)
+    if dt == torch.float32:
+        assert rel_max(ncthw(y).cpu(), g["conv_y_causal" if causal else "conv_y_noncausal"]) <= F32_TOL
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,Cin,Cout,T,H,W", [(1, 128, 128, 3, 9, 11), (2, 16, 40, 2, 5, 6), (1, 256, 64, 1, 16, 16)])
+def test_conv3d_shapes_and_residual(hip, dt, B, Cin, Cout, T, H, W):
+    x, w, b = rnd(dt, B, Cin, T, H, W), rnd(dt, Cout, Cin, 3, 3, 3, scale=(27 * Cin) ** -0.5), rnd(dt, Cout, scale=0.1)
+    r = rnd(dt, B, Cout, T, H, W, seed=5)
+    ref = O.causal_conv3d(x.float(), w.float(), b.float(), False)
+    check(ncthw(hip.ops.conv3d(cl(x).cuda(), w.cuda(), b.cuda(), False)), ref, dt)
+    check(ncthw(hip.ops.conv3d(cl(x).cuda(), w.cuda(), b.cuda(), False, resid=cl(r).cuda())), ref + r.float(), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_upsampler_axis_order_and_values(hip, golden, dt):
+    g = golden("oracle_ops.safetensors")
+    x = g["up_x"].to(dt)
+    w = torch.zeros(32, 16, 3, 3, 3, dtype=dt)
+    y = hip.ops.upsample3d(cl(x).cuda(), w.cuda(), g["up_bias"].to(dt).cuda())
+    if dt == torch.float32:
+        assert (ncthw(y).cpu() - g["up_y"]).abs().max() < 1e-3          # exact index algebra (vae.rs:1106-1123, 1142-1161)
+    # random weights: conv + d2s + first-frame drop + tiled residual
+    x2, w2, b2 = rnd(dt, 1, 32, 2, 3, 4), rnd(dt, 128, 32, 3, 3, 3, scale=0.03), rnd(dt, 128, scale=0.1)
+    p = {"conv.conv.weight": w2.float(), "conv.conv.bias": b2.float()}
+    ref = O.upsampler(p, "", x2.float(), 16, False)
+    check(ncthw(hip.ops.upsample3d(cl(x2).cuda(), w2.cuda(), b2.cuda())), ref, dt)
+    ref_nores = O.upsampler(p, "", x2.float(), 16, False, residual=False)
+    check(ncthw(hip.ops.upsample3d(cl(x2).cuda(), w2.cuda(), b2.cuda(), residual=False)), ref_nores, dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv_out_unpatchify_postprocess(hip, dt):
+    x, w, b = rnd(dt, 1, 16, 2, 3, 5), rnd(dt, 48, 16, 3, 3, 3, scale=0.05), rnd(dt, 48, scale=0.1)
+    ref = O.unpatchify(O.causal_conv3d(x.float(), w.float(), b.float(), False), 4, 1)
+    y = hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda())
+    check(y, ref, dt)
+    yp = hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda(), postprocess=True)
+    assert (yp.cpu() - O.postprocess_video(y.cpu())).abs().max() < 1e-3
+
+
+def test_guidance_and_scheduler_step_reference_vectors(hip, golden):
+    g = golden("ref_guidance.safetensors")           # produced by the reference's scripts/gen_guidance_ref.py
+    t, u, p = g["noise_pred_text"].cuda(), g["noise_pred_uncond"].cuda(), g["noise_pred_perturb"].cuda()
+    gs, ss = float(g["guidance_scale"]), float(g["stg_scale"])
+    assert (hip.guidance_combine(t, u, None, gs).cpu() - g["combined_cfg"]).abs().max() < 1e-5       # tests/verify_cfg_parity.rs:82-88
+    assert (hip.guidance_combine(t, u, p, gs, 0.0, ss).cpu() - g["combined_final"]).abs().max() < 1e-5  # tests/verify_guidance_parity.rs:58-67
+    resc = hip.guidance_combine(t, u, p, gs, 0.7, ss).cpu()
+    want = O.guidance_combine(g["noise_pred_text"], g["noise_pred_uncond"], g["noise_pred_perturb"], gs, 0.7, ss)
+    assert (resc - want).abs().max() < 1e-3 and ((resc - want) ** 2).mean() < 1e-6                  # tests/verify_cfg_parity.rs:148-157
+    # bf16 predictions, f32 latents; Euler step x + (sigma_next - sigma) v
+    s = hip.FlowMatchEulerDiscreteScheduler()
+    ts = s.set_timesteps([1.0, 0.9937, 0.9875], 0.0)
+    lat = torch.randn(1, 256, 128)
+    out = s.step(t.bfloat16(), ts[0], lat.cuda()).cpu()
+    ref = lat + (s.sigmas[1] - s.sigmas[0]) * t.bfloat16().float().cpu()
+    assert (out - ref).abs().max() < 1e-6
+
+
+def test_errors_are_reported_not_crashed(hip):
+    x = torch.randn(8, 30, device="cuda")           # K=30 is not a multiple of the 16-byte chunk
+    with pytest.raises(hip.LtxError, match="multiple"):
+        hip.ops.linear(x, torch.randn(16, 30, device="cuda"))
+    with pytest.raises(hip.LtxError, match="head_dim"):
+        hip.ops.attention(torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), 2, 1.0)

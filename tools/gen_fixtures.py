@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/.
+
+Run IN THE BUILD CONTAINER (needs /root/reference for the two reference-script pins):
+
+    python tools/gen_fixtures.py
+
+Two kinds of vectors:
+  * ref_*.safetensors    — outputs of the reference's own runnable torch-only scripts
+                           (scripts/gen_guidance_ref.py, scripts/gen_latent_norm_ref.py), executed
+                           from /root/reference in a temp dir; these PIN the oracle.
+  * oracle_*.safetensors — inputs + weights + outputs of oracle/ltx_oracle.py (f32 and bf16
+                           modes) for tiny DiT / VAE / pipeline configs modelled on the
+                           reference's tests (tests/verify_dit_parity.rs:24-39,
+                           tests/verify_rope_parity.rs:537-552, tests/vae_tests.rs:119-180);
+                           these pin the oracle against drift and are what the GPU path is
+                           compared with on a box where /root/reference does not exist.
+Nothing here copies reference source; fixtures are data only.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import torch
+from safetensors.torch import load_file, save_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ltx_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def c(t):
+    return t.detach().contiguous().clone()
+
+
+def weights_checksum(w):
+    """Order-independent fingerprint so a test can tell 'RNG stream changed' from 'kernel is wrong'."""
+    return torch.tensor([sum(float(v.double().sum()) for v in w.values()), sum(float(v.double().abs().sum()) for v in w.values())],
+                        dtype=torch.float64)
+
+
+def ref_scripts():
+    """Run the reference's torch-only generators and keep (slices of) their outputs."""
+    with tempfile.TemporaryDirectory() as td:
+        for s in ("gen_guidance_ref.py", "gen_latent_norm_ref.py"):
+            subprocess.run([sys.executable, os.path.join(REF, "scripts", s)], cwd=td, check=True, stdout=subprocess.DEVNULL)
+        g = load_file(os.path.join(td, "gen_guidance_ref.safetensors"))
+        save_file({k: c(v) for k, v in g.items()}, os.path.join(GOLD, "ref_guidance.safetensors"),
+                  metadata={"source": "reference scripts/gen_guidance_ref.py (seed 42), executed unmodified"})
+        n = load_file(os.path.join(td, "gen_latent_norm_ref.safetensors"))
+        sl = (slice(None), slice(None), slice(0, 3), slice(0, 4), slice(0, 6))
+        keep = {"latents": c(n["latents"][sl]), "normalized": c(n["normalized"][sl]), "denormalized": c(n["denormalized"][sl]),
+                "latents_mean": c(n["latents_mean"]), "latents_std": c(n["latents_std"]), "scaling_factor": c(n["scaling_factor"])}
+        save_file(keep, os.path.join(GOLD, "ref_latent_norm.safetensors"),
+                  metadata={"source": "reference scripts/gen_latent_norm_ref.py (seed 42), executed unmodified; tensors sliced [:, :, :3, :4, :6]"})
+
+
+DIT_CASES = {
+    # tests/verify_dit_parity.rs:24-39 config (2 layers, 2 heads x 16, dims 32), smaller grid, no mask, rope scale (1,1,1)
+    "A": dict(cfg=dict(in_channels=32, out_channels=32, num_attention_heads=2, attention_head_dim=16, cross_attention_dim=32,
+                       num_layers=2, caption_channels=32), B=1, grid=(8, 16, 16), K=10, mask=None, rope_scale=(1.0, 1.0, 1.0),
+              coords=False, t=500.0),
+    # tests/verify_rope_parity.rs:537-552 config (2 layers, 4 heads x 16), grid (4,8,8), K=16, partially masked, video_coords
+    "B": dict(cfg=dict(in_channels=32, out_channels=32, num_attention_heads=4, attention_head_dim=16, cross_attention_dim=64,
+                       num_layers=2, caption_channels=32), B=2, grid=(4, 8, 8), K=16, mask=[16, 5], rope_scale=None,
+              coords=True, t=979.0, skip_layer_mask=True),
+    # production head_dim 64, C1's latent grid 4x8x12 (S=384), K=128 with 32 valid tokens (BASELINE.md synthetic inputs)
+    "C": dict(cfg=dict(in_channels=128, out_channels=128, num_attention_heads=2, attention_head_dim=64, cross_attention_dim=128,
+                       num_layers=2, caption_channels=64), B=1, grid=(4, 8, 12), K=128, mask=[32], rope_scale=None,
+              coords=True, t=918.0, skip_blocks=[1]),
+}
+
+
+def dit_case(name, spec):
+    cfg = O.DitConfig(**spec["cfg"])
+    w = O.synth_weights(O.dit_weight_shapes(cfg), seed=ord(name))
+    g = torch.Generator().manual_seed(100 + ord(name))
+    B, (F, H, W), K = spec["B"], spec["grid"], spec["K"]
+    S = F * H * W
+    hidden = torch.randn(B, S, cfg.in_channels, generator=g)
+    enc = torch.randn(B, K, cfg.caption_channels, generator=g)
+    mask = None
+    if spec["mask"] is not None:
+        mask = torch.zeros(B, K)
+        for b, nv in enumerate(spec["mask"]):
+            mask[b, :nv] = 1.0
+    coords = O.build_video_coords(B, F, H, W) if spec["coords"] else None
+    t = torch.full((B,), spec["t"])
+    slm = None
+    if spec.get("skip_layer_mask"):
+        slm = torch.zeros(cfg.num_layers, B)
+        slm[0, 1] = 1.0            # layer 0 skipped for batch row 1 only (mixed row -> blend path)
+        slm[1, :] = 1.0            # layer 1 skipped for everyone (identity shortcut)
+    skip = spec.get("skip_blocks", [])
+    out = {"hidden": hidden, "enc": enc, "timestep": t}
+    if mask is not None:
+        out["mask"] = mask
+    if coords is not None:
+        out["coords"] = coords
+    if slm is not None:
+        out["skip_layer_mask"] = slm
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        wd = {k: v.to(dt) for k, v in w.items()}
+        y = O.dit_forward(wd, cfg, hidden, enc, t, mask, F, H, W, spec["rope_scale"], coords, slm, skip, dt)
+        out["out_" + tag] = y.float()
+    for k, v in w.items():
+        out["w." + k] = v
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, f"oracle_dit_{name}.safetensors"),
+              metadata={"cfg": repr(spec["cfg"]), "grid": repr(spec["grid"]), "rope_scale": repr(spec["rope_scale"]),
+                        "skip_blocks": repr(skip), "source": "oracle/ltx_oracle.py dit_forward"})
+
+
+VAE_CFG = dict(latent_channels=8, decoder_block_out_channels=(32, 64, 128), decoder_layers_per_block=(1, 1, 1, 2))
+
+
+def vae_case():
+    cfg = O.VaeConfig(**VAE_CFG)
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=7)
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(1, 8, 2, 3, 4, generator=g)
+    out = {"z": z, "timestep": torch.tensor([0.05])}
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        wd = {k: v.to(dt) for k, v in w.items()}
+        out["out_" + tag] = O.decoder_forward(wd, cfg, z, torch.tensor([0.05]), dt).float()
+    # tiled + framewise decode with shrunken tile parameters (latent tile 2x2, stride 1; temporal min 1 / stride 1 latent frame)
+    z2 = torch.randn(1, 8, 4, 3, 3, generator=g)
+    tcfg = O.VaeConfig(**VAE_CFG, tile_sample_min_height=64, tile_sample_min_width=64, tile_sample_stride_height=32,
+                       tile_sample_stride_width=32, tile_sample_min_num_frames=16, tile_sample_stride_num_frames=8)
+    out["z_tiled"] = z2
+    out["out_tiled_f32"] = O.vae_decode(w, tcfg, z2, torch.tensor([0.05]), torch.float32, use_tiling=True, use_framewise_decoding=True)
+    out["out_spatial_tiled_f32"] = O.vae_decode(w, tcfg, z2[:, :, :2], torch.tensor([0.05]), torch.float32, use_tiling=True, use_framewise_decoding=False)
+    out["out_tiled_f32"] = out["out_tiled_f32"][..., ::2, ::2]
+    out["out_spatial_tiled_f32"] = out["out_spatial_tiled_f32"][..., ::2, ::2]
+    out["weights_checksum"] = weights_checksum(w)       # weights are re-derived from seed 7 (O.synth_weights)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_vae.safetensors"),
+              metadata={"cfg": repr(VAE_CFG), "source": "oracle/ltx_oracle.py decoder_forward / vae_decode"})
+
+
+def ops_case():
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    # conv3d known-answer [1,8,5,6,6] -> 16, causal and non-causal
+    x = torch.randn(1, 8, 5, 6, 6, generator=g)
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) / 14.7
+    b = torch.randn(16, generator=g) * 0.1
+    out.update({"conv_x": x, "conv_w": w, "conv_b": b,
+                "conv_y_noncausal": O.causal_conv3d(x, w, b, False), "conv_y_causal": O.causal_conv3d(x, w, b, True)})
+    # upsampler axis-order KAT modelled on tests/vae_tests.rs:119-180: identity-free conv (zero weight) so the
+    # output is exactly bias + residual; x value = src_t*100 + packed_channel makes every permutation visible
+    cin, cout = 16, 8 * 4     # residual repeats = 32/16 = 2
+    xs = torch.zeros(1, cin, 2, 2, 3)
+    for t in range(2):
+        for ch in range(cin):
+            xs[0, ch, t] = t * 100 + ch + 0.01 * torch.arange(6).reshape(2, 3)
+    pw = {"conv.conv.weight": torch.zeros(cout, cin, 3, 3, 3), "conv.conv.bias": torch.arange(cout, dtype=torch.float32) * 1000.0}
+    out.update({"up_x": xs, "up_bias": pw["conv.conv.bias"], "up_y": O.upsampler(pw, "", xs, cout // 8, False)})
+    # RoPE rows for the grids of tests/verify_rope_parity.rs (dim 2048): checksums + a 64-row slice
+    for gi, (F, H, W) in enumerate([(2, 8, 8), (13, 16, 24)]):
+        coords = O.build_video_coords(1, F, H, W)
+        cos, sin = O.rope_cos_sin(2048, 1, F, H, W, None, coords)
+        idx = torch.linspace(0, F * H * W - 1, 64).long()
+        out[f"rope{gi}_rows"] = idx
+        out[f"rope{gi}_cos"] = cos[0, idx]
+        out[f"rope{gi}_sin"] = sin[0, idx]
+        out[f"rope{gi}_sum"] = torch.stack([cos.double().sum(), sin.double().sum()]).float()
+    # PCG32: first u32s and gaussians for seed 42 (main.rs:568 increment)
+    r = O.Pcg32(42, 1442695040888963407)
+    out["pcg_u32"] = torch.tensor([r.next_u32() for _ in range(16)], dtype=torch.int64)
+    out["pcg_randn"] = O.Pcg32(42, 1442695040888963407).randn((32,))
+    # scheduler: distilled sigma list (configs.rs:232) and 40-step linspace with mu(S) for the three BASELINE grids
+    s = O.FlowMatchEulerScheduler()
+    ts = s.set_timesteps(sigmas=[1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250], mu=0.0)
+    out["sched_distilled_sigmas"] = torch.from_numpy(s.sigmas.copy())
+    out["sched_distilled_timesteps"] = torch.tensor(ts, dtype=torch.int64)
+    for S in (384, 4992, 17556):
+        lin = list(O.FlowMatchEulerScheduler._linspace(1.0, 1.0 / 40, 40))
+        ts = s.set_timesteps(sigmas=lin, mu=O.calculate_shift(S))
+        out[f"sched40_S{S}_sigmas"] = torch.from_numpy(s.sigmas.copy())
+        out[f"sched40_S{S}_timesteps"] = torch.tensor(ts, dtype=torch.int64)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_ops.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py primitives"})
+
+
+def pipeline_case():
+    """3-step CFG(3.0)+STG(1.0)+rescale(0.7) trajectory on tiny models (the 0.9.5 preset's guidance, configs.rs:163-180)."""
+    dcfg = O.DitConfig(in_channels=8, out_channels=8, num_attention_heads=2, attention_head_dim=16, cross_attention_dim=32,
+                       num_layers=3, caption_channels=32)
+    vcfg = O.VaeConfig(**VAE_CFG)
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=12)
+    g = torch.Generator().manual_seed(13)
+    args = O.PipelineArgs(height=64, width=96, num_frames=9, num_inference_steps=3, guidance_scale=3.0, guidance_rescale=0.7,
+                          stg_scale=1.0, skip_block_list=[1], decode_timestep=0.05, decode_noise_scale=0.025)
+    F, H, W = 2, 2, 3
+    lat = O.pack_latents(O.Pcg32(42, 1442695040888963407).randn((1, 8, F, H, W)))
+    pe = torch.randn(1, 16, 32, generator=g); pm = torch.zeros(1, 16); pm[:, :9] = 1
+    ne = torch.randn(1, 16, 32, generator=g); nm = torch.zeros(1, 16); nm[:, :4] = 1
+    noise = torch.randn(1, 8, F, H, W, generator=g)
+    mean = torch.randn(8, generator=g) * 0.1
+    std = 1.0 + 0.1 * torch.randn(8, generator=g).abs()
+    traj = []
+    video = O.pipeline_call(dw, dcfg, vw, vcfg, mean, std, args, lat, pe, pm, ne, nm, noise, torch.float32, trajectory=traj)
+    out = {"latents": lat, "prompt_embeds": pe, "prompt_mask": pm, "neg_embeds": ne, "neg_mask": nm, "decode_noise": noise,
+           "latents_mean": mean, "latents_std": std, "video": video, "trajectory": torch.stack(traj)}
+    out["dit_weights_checksum"] = weights_checksum(dw)  # seeds 11 / 12 (O.synth_weights)
+    out["vae_weights_checksum"] = weights_checksum(vw)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_pipeline.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py pipeline_call", "args": repr(args)})
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_scripts()
+    for n, s in DIT_CASES.items():
+        dit_case(n, s)
+    vae_case()
+    ops_case()
+    pipeline_case()
+    tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
