@@ -85,7 +85,10 @@ def cpu_baseline(cfg):
     workload, scaled to frames/sec:  1 of 28 DiT layers at the full token count (x28 x7 steps) and a
     VAE decode of a latent crop (scaled by voxel count)."""
     import ltx_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 16 threads: torch's small-conv2d / bmm paths get SLOWER with hundreds of threads (measured: the VAE crop
+    # took 488 s with 256 threads vs ~1 s with 8); `cores` reports what was actually used.
+    ncores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
     F, H, W = (cfg["num_frames"] - 1) // 8 + 1, cfg["height"] // 32, cfg["width"] // 32
     S = F * H * W
     dcfg = O.DitConfig(num_layers=1)
@@ -106,7 +109,7 @@ def cpu_baseline(cfg):
     t_crop = time.time() - t0
     t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
     total = 28 * 7 * t_layer + t_vae
-    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": os.cpu_count() or 1, "kind": "port",
+    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port",
             "sample": f"oracle f32 on host: 1 of 28 DiT layers at S={S} ({t_layer:.2f}s, x28x7) + VAE decode of a {cf}x{chh}x{cww} latent crop "
                       f"({t_crop:.2f}s, scaled by conv FLOPs to {F}x{H}x{W}); estimated {total:.1f}s per video"}
 

@@ -105,3 +105,15 @@ extern "C" int ltx_op_conv_out_unpatchify(const void* x, const void* w, const vo
     if (Cout % 16 != 0) LTX_FAIL(LTX_ERR_ARG, "conv_out: Cout must be a multiple of 16 (patch 4x4)");
     return conv_common(x, w, bias, wdtype, y, nullptr, B, T, H, W, Cin, Cout, causal, dtype, EPI_UNPATCH, LTX_PERM_UNPATCH, postprocess, (hipStream_t)stream);
 }
+
+extern "C" int ltx_op_blend(const float* a, float* b, int BC, int at, int ah, int aw, int bt, int bh, int bw, int dim, int blend_extent, ltx_stream stream) {
+    if (!a || !b || dim < 2 || dim > 4) LTX_FAIL(LTX_ERR_ARG, "ltx_op_blend: bad argument");
+    const int ad[3] = {at, ah, aw}, bd[3] = {bt, bh, bw};
+    BlendArgs ba; ba.a = a; ba.b = b; ba.dst = b; ba.BC = BC;
+    ba.at = at; ba.ah = ah; ba.aw = aw; ba.a_len = ad[dim - 2];
+    ba.bt = ba.dt = bt; ba.bh = ba.dh = bh; ba.bw = ba.dw = bw;
+    ba.dim = dim; ba.blend = std::min(blend_extent, std::min(ad[dim - 2], bd[dim - 2]));
+    ba.et = std::min(at, bt); ba.eh = std::min(ah, bh); ba.ew = std::min(aw, bw);
+    if (dim == 2) ba.et = ba.blend; else if (dim == 3) ba.eh = ba.blend; else ba.ew = ba.blend;
+    return ltx_launch_blend(ba, (hipStream_t)stream);
+}

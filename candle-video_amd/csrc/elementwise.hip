@@ -127,13 +127,12 @@ __global__ void blend_kernel(BlendArgs a) {
     const int64_t n = (int64_t)a.BC * a.et * a.eh * a.ew;
     GRID_STRIDE(i, n) {
         int w = (int)(i % a.ew); int64_t r = i / a.ew; int h = (int)(r % a.eh); r /= a.eh; int t = (int)(r % a.et); int bc = (int)(r / a.et);
-        int at = t, ah = h, aw = w, x;
-        if (a.dim == 2) { x = t; at = a.a_len - a.blend + t; }
-        else if (a.dim == 3) { x = h; ah = a.a_len - a.blend + h; }
-        else { x = w; aw = a.a_len - a.blend + w; }
+        const int off = a.a_len - a.blend;
+        const int x = a.dim == 2 ? t : (a.dim == 3 ? h : w);
+        const int ta = t + (a.dim == 2 ? off : 0), ha = h + (a.dim == 3 ? off : 0), wa = w + (a.dim == 4 ? off : 0);
         float wgt = (float)x * (1.0f / (float)a.blend);
         int64_t ib = (((int64_t)bc * a.bt + t) * a.bh + h) * a.bw + w;
-        int64_t ia = (((int64_t)bc * a.at + at) * a.ah + ah) * a.aw + aw;
+        int64_t ia = (((int64_t)bc * a.at + ta) * a.ah + ha) * a.aw + wa;
         int64_t id = (((int64_t)bc * a.dt + a.ot + t) * a.dh + a.oh + h) * a.dw + a.ow + w;
         a.dst[id] = a.a[ia] * (1.0f - wgt) + a.b[ib] * wgt;
     }

@@ -33,6 +33,10 @@ struct GemmArgs {
     int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
 };
 int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
+// large-tile LDS-DMA bf16 variant (gemm_big.hip); ltx_launch_gemm dispatches to it when eligible
+bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype);
+int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
+void ltx_gemm_big_pick_tile(int M, int N, int* bm_out, int* bn_out);
 
 // ---------------- row norms (rownorm.hip) ----------------
 struct RowNormArgs {

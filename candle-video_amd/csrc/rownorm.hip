@@ -12,11 +12,19 @@
 //  rope_table   : LtxVideoRotaryPosEmbed::forward (:436-524) -> half-width cos/sin tables.
 //
 // Mapping: LPR lanes per row (power of two, >= 16-B chunks per row, <= 64), 64/LPR rows per wave,
-// 4 waves per block; every lane moves 16 B per access; statistics reduced with xor-shuffles.
+// 4 waves per block; every lane moves 16 B per access.  The row lives in registers between the
+// statistics pass and the write pass (one HBM read, one HBM write), and every lane issues all of
+// its loads before the first reduction (memory-level parallelism instead of a dependent loop):
+//   WIDE   rows (> LPR chunks): up to NSLOT chunks of ONE row per lane;
+//   NARROW rows (<= LPR chunks, e.g. the VAE's 128..1024-channel voxels): NSLOT different rows per
+//          lane group, one chunk each.
+// Rows that do not fit NSLOT chunks per lane fall back to a re-reading variant (second read hits L2).
 #include "common.h"
 #include "kernels.h"
 
 namespace {
+
+constexpr int NSLOT = 8;
 
 __device__ __forceinline__ float group_sum(float v, int lpr) {
     for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -24,60 +32,152 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 }
 
 template <typename T>
+__device__ __forceinline__ void finish_chunk(const RowNormArgs& a, const float* f_in, float mean, float rinv, int c, const float* sc,
+                                             const float* sh, T* y, bool active) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    const T* w = reinterpret_cast<const T*>(a.weight);
+    float f[CH], wv[CH], scv[CH], shv[CH];
+    if (w) { Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH); chunk_to_f32<T>(wc, wv); }
+    if (sc) {
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(sc + c * CH + 4 * q), b4 = *reinterpret_cast<const f32x4*>(sh + c * CH + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { scv[4 * q + i] = a4[i]; shv[4 * q + i] = b4[i]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        float n = (f_in[i] - mean) * rinv;
+        if (w) n *= wv[i];
+        if (sc) n = n * (1.0f + scv[i]) + shv[i];
+        if (a.act == 1) n = silu_f(n);
+        f[i] = n;
+    }
+    Chunk16 o; f32_to_chunk<T>(f, o);
+    if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+}
+
+// MODE 0: WIDE (row cached in registers), 1: NARROW (NSLOT rows per lane group), 2: re-read fallback
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rpw = 64 / lpr;
-    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
     const int sub = lane % lpr;
-    const bool active = row < a.rows;
-    const int64_t rr = active ? row : a.rows - 1;
-    const T* x = reinterpret_cast<const T*>(a.x) + rr * a.ldx;
-    T* y = reinterpret_cast<T*>(a.y) + rr * a.ldy;
     const int nch = a.D / CH;
-    float mean = 0.f;
-    if (a.kind == 1) {
-        float s = 0.f;
-        for (int c = sub; c < nch; c += lpr) {
-            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
-            float f[CH]; chunk_to_f32<T>(v, f);
+    const float invD = 1.0f / (float)a.D;
+    if constexpr (MODE == 1) {
+        // lane group handles rows base + i*rpw*4*gridDim? -> contiguous block of NSLOT*rpw rows per wave
+        const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (rpw * NSLOT) + lane / lpr;
+        Chunk16 v[NSLOT];
+        const bool has = sub < nch;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) s += f[i];
+        for (int i = 0; i < NSLOT; ++i) {
+            int64_t row = row0 + (int64_t)i * rpw;
+            int64_t rr = row < a.rows ? row : a.rows - 1;
+            v[i].u = (u32x4){0u, 0u, 0u, 0u};
+            if (has) v[i].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + rr * a.ldx + sub * CH);
         }
-        mean = group_sum(s, lpr) / (float)a.D;
-    }
-    float ss = 0.f;
-    for (int c = sub; c < nch; c += lpr) {
-        Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
-        float f[CH]; chunk_to_f32<T>(v, f);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { float d = f[i] - mean; ss += d * d; }
-    }
-    ss = group_sum(ss, lpr);
-    const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
-    const int64_t b = rr / a.rows_per_batch;
-    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
-    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
-    const T* w = reinterpret_cast<const T*>(a.weight);
-    for (int c = sub; c < nch; c += lpr) {
-        Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
-        float f[CH]; chunk_to_f32<T>(v, f);
-        float wv[CH];
-        if (w) { Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH); chunk_to_f32<T>(wc, wv); }
+        for (int i = 0; i < NSLOT; ++i) {
+            int64_t row = row0 + (int64_t)i * rpw;
+            const bool active = row < a.rows;
+            int64_t rr = active ? row : a.rows - 1;
+            float f[CH]; chunk_to_f32<T>(v[i], f);
+            float mean = 0.f;
+            if (a.kind == 1) {
+                float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            float n = (f[i] - mean) * rinv;
-            if (w) n *= wv[i];
-            if (sc) n = n * (1.0f + sc[c * CH + i]) + sh[c * CH + i];
-            if (a.act == 1) n = silu_f(n);
-            f[i] = n;
+                for (int j = 0; j < CH; ++j) s += f[j];
+                mean = group_sum(s, lpr) * invD;
+            }
+            float ss = 0.f;
+            if (has) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) { float d = f[j] - mean; ss += d * d; }
+            }
+            ss = group_sum(ss, lpr);
+            const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
+            const int64_t b = rr / a.rows_per_batch;
+            const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+            const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+            if (has) finish_chunk<T>(a, f, mean, rinv, sub, sc, sh, reinterpret_cast<T*>(a.y) + rr * a.ldy, active);
         }
-        Chunk16 o; f32_to_chunk<T>(f, o);
-        if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+    } else {
+        const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
+        const bool active = row < a.rows;
+        const int64_t rr = active ? row : a.rows - 1;
+        const T* x = reinterpret_cast<const T*>(a.x) + rr * a.ldx;
+        T* y = reinterpret_cast<T*>(a.y) + rr * a.ldy;
+        const int64_t b = rr / a.rows_per_batch;
+        const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+        const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+        if constexpr (MODE == 0) {
+            Chunk16 v[NSLOT];
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                int c = sub + i * lpr;
+                v[i].u = (u32x4){0u, 0u, 0u, 0u};
+                if (c < nch) v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
+            }
+            float mean = 0.f;
+            if (a.kind == 1) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSLOT; ++i) { float f[CH]; chunk_to_f32<T>(v[i], f);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) s += f[j]; }
+                mean = group_sum(s, lpr) * invD;
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                if (sub + i * lpr < nch) {
+                    float f[CH]; chunk_to_f32<T>(v[i], f);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { float d = f[j] - mean; ss += d * d; }
+                }
+            }
+            ss = group_sum(ss, lpr);
+            const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                int c = sub + i * lpr;
+                if (c < nch) { float f[CH]; chunk_to_f32<T>(v[i], f); finish_chunk<T>(a, f, mean, rinv, c, sc, sh, y, active); }
+            }
+        } else {
+            float mean = 0.f;
+            if (a.kind == 1) {
+                float s = 0.f;
+                for (int c = sub; c < nch; c += lpr) {
+                    Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+                    float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) s += f[i];
+                }
+                mean = group_sum(s, lpr) * invD;
+            }
+            float ss = 0.f;
+            for (int c = sub; c < nch; c += lpr) {
+                Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+                float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { float d = f[i] - mean; ss += d * d; }
+            }
+            ss = group_sum(ss, lpr);
+            const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
+            for (int c = sub; c < nch; c += lpr) {
+                Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+                float f[CH]; chunk_to_f32<T>(v, f);
+                finish_chunk<T>(a, f, mean, rinv, c, sc, sh, y, active);
+            }
+        }
     }
 }
 
-template <typename T>
+// CACHED: the (<= NSLOT chunks per lane) segment stays in registers between the two passes
+template <typename T, bool CACHED>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,38 +187,65 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
     const bool active = row < a.rows;
     const int64_t rr = active ? row : a.rows - 1;
     const int nch = a.D / CH;
+    const float* cs = a.cos ? a.cos + rr * (a.D / 2) : nullptr;
+    const float* sn = a.sin ? a.sin + rr * (a.D / 2) : nullptr;
+    auto finish = [&](Chunk16 v, int c, float rinv, const T* w, T* x) {
+        float f[CH]; chunk_to_f32<T>(v, f);
+        Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
+        float wv[CH]; chunk_to_f32<T>(wc, wv);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) f[i] = f[i] * rinv * wv[i];
+        if (cs) {
+            float co[CH / 2], si[CH / 2];
+            if constexpr (CH == 8) {
+                f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + c * 4), s4 = *reinterpret_cast<const f32x4*>(sn + c * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { co[p] = c4[p]; si[p] = s4[p]; }
+            } else {
+#pragma unroll
+                for (int p = 0; p < CH / 2; ++p) { co[p] = cs[c * (CH / 2) + p]; si[p] = sn[c * (CH / 2) + p]; }
+            }
+#pragma unroll
+            for (int p = 0; p < CH / 2; ++p) {
+                float re = f[2 * p], im = f[2 * p + 1];
+                f[2 * p] = re * co[p] - im * si[p];          // x*cos + (-x_imag)*sin
+                f[2 * p + 1] = im * co[p] + re * si[p];      // x*cos + ( x_real)*sin
+            }
+        }
+        Chunk16 o; f32_to_chunk<T>(f, o);
+        if (active) *reinterpret_cast<u32x4*>(x + c * CH) = o.u;
+    };
     for (int seg = 0; seg < a.nseg; ++seg) {
         T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * a.D;
         const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
-        float ss = 0.f;
-        for (int c = sub; c < nch; c += lpr) {
-            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
-            float f[CH]; chunk_to_f32<T>(v, f);
+        if constexpr (CACHED) {
+            Chunk16 v[NSLOT];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) ss += f[i] * f[i];
-        }
-        ss = group_sum(ss, lpr);
-        const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
-        const float* cs = a.cos ? a.cos + rr * (a.D / 2) : nullptr;
-        const float* sn = a.sin ? a.sin + rr * (a.D / 2) : nullptr;
-        for (int c = sub; c < nch; c += lpr) {
-            Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
-            float f[CH]; chunk_to_f32<T>(v, f);
-            Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
-            float wv[CH]; chunk_to_f32<T>(wc, wv);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) f[i] = f[i] * rinv * wv[i];
-            if (cs) {
-#pragma unroll
-                for (int p = 0; p < CH / 2; ++p) {
-                    float co = cs[c * (CH / 2) + p], si = sn[c * (CH / 2) + p];
-                    float re = f[2 * p], im = f[2 * p + 1];
-                    f[2 * p] = re * co - im * si;          // x*cos + (-x_imag)*sin
-                    f[2 * p + 1] = im * co + re * si;      // x*cos + ( x_real)*sin
-                }
+            for (int i = 0; i < NSLOT; ++i) {
+                int c = sub + i * lpr;
+                v[i].u = (u32x4){0u, 0u, 0u, 0u};
+                if (c < nch) v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
             }
-            Chunk16 o; f32_to_chunk<T>(f, o);
-            if (active) *reinterpret_cast<u32x4*>(x + c * CH) = o.u;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) { float f[CH]; chunk_to_f32<T>(v[i], f);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) ss += f[j] * f[j]; }
+            ss = group_sum(ss, lpr);
+            const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) { int c = sub + i * lpr; if (c < nch) finish(v[i], c, rinv, w, x); }
+        } else {
+            float ss = 0.f;
+            for (int c = sub; c < nch; c += lpr) {
+                Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH);
+                float f[CH]; chunk_to_f32<T>(v, f);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) ss += f[i] * f[i];
+            }
+            ss = group_sum(ss, lpr);
+            const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+            for (int c = sub; c < nch; c += lpr) { Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH); finish(v, c, rinv, w, x); }
         }
     }
 }
@@ -158,6 +285,20 @@ int pick_lpr(int nch) {
     return lpr;
 }
 
+template <typename T>
+void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
+    const int rpw = 64 / lpr;
+    if (nch <= lpr && a.rows >= (int64_t)rpw * NSLOT * 4 * 64) {       // narrow rows, enough of them: NSLOT rows per lane group
+        const int64_t rows_per_block = (int64_t)4 * rpw * NSLOT;
+        hipLaunchKernelGGL((rownorm_kernel<T, 1>), dim3((unsigned)cdiv64(a.rows, rows_per_block)), dim3(256), 0, s, a, lpr);
+    } else {
+        const int64_t rows_per_block = 4 * rpw;
+        dim3 grid((unsigned)cdiv64(a.rows, rows_per_block));
+        if (nch <= NSLOT * lpr) hipLaunchKernelGGL((rownorm_kernel<T, 0>), grid, dim3(256), 0, s, a, lpr);
+        else hipLaunchKernelGGL((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
+    }
+}
+
 }  // namespace
 
 int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
@@ -165,13 +306,11 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     if (a.rows <= 0) return LTX_OK;
     if (a.D % ch != 0 || a.ldx % ch != 0 || a.ldy % ch != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: D/ld must be multiples of the 16-byte chunk");
     if ((a.scale == nullptr) != (a.shift == nullptr)) LTX_FAIL(LTX_ERR_ARG, "rownorm: scale and shift go together");
-    const int lpr = pick_lpr(a.D / ch);
-    const int64_t rows_per_block = 4 * (64 / lpr);
-    dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
+    const int nch = a.D / ch, lpr = pick_lpr(nch);
     void* tok = nullptr;
     ltx_prof_begin(LTX_PROF_ROWNORM, 2.0 * (double)a.rows * a.D * (dtype == LTX_DT_BF16 ? 2 : 4), s, &tok);
-    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(rownorm_kernel<bf16_t>, grid, block, 0, s, a, lpr);
-    else hipLaunchKernelGGL(rownorm_kernel<float>, grid, block, 0, s, a, lpr);
+    if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
+    else launch_rownorm_t<float>(a, lpr, nch, s);
     ltx_prof_end(tok, s);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
@@ -182,11 +321,17 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     if (a.rows <= 0) return LTX_OK;
     if (a.D % ch != 0 || a.ld % ch != 0) LTX_FAIL(LTX_ERR_ARG, "qknorm: D/ld must be multiples of the 16-byte chunk");
     if (a.nseg < 1 || a.nseg > 2 || !a.w0 || (a.nseg == 2 && !a.w1)) LTX_FAIL(LTX_ERR_ARG, "qknorm: bad segments/weights");
-    const int lpr = pick_lpr(a.D / ch);
+    const int nch = a.D / ch, lpr = pick_lpr(nch);
     const int64_t rows_per_block = 4 * (64 / lpr);
     dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
-    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(qknorm_rope_kernel<bf16_t>, grid, block, 0, s, a, lpr);
-    else hipLaunchKernelGGL(qknorm_rope_kernel<float>, grid, block, 0, s, a, lpr);
+    const bool cached = nch <= NSLOT * lpr;
+    if (dtype == LTX_DT_BF16) {
+        if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
+        else hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, false>), grid, block, 0, s, a, lpr);
+    } else {
+        if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<float, true>), grid, block, 0, s, a, lpr);
+        else hipLaunchKernelGGL((qknorm_rope_kernel<float, false>), grid, block, 0, s, a, lpr);
+    }
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

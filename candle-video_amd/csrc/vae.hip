@@ -11,6 +11,7 @@
 //     accumulator values a lane owns are contiguous in the destination).
 // The packed token layout the denoise loop carries ([B, F*H*W, 128]) IS channels-last, so
 // unpack_latents is free on this path.
+#include <deque>
 #include "model_util.h"
 
 struct ConvW {
@@ -35,7 +36,7 @@ struct ltx_vae {
     int mid_ch = 0, last_ch = 0;
     std::vector<void*> owned;
     DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats;
-    std::vector<DevBuf> tilebufs;
+    std::deque<DevBuf> tilebufs;   // deque: growing it must not move DevBufs that Tile.buf points at
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
@@ -294,7 +295,7 @@ struct Tile { DevBuf* buf; int t, h, w; };   // decoded f32 NCTHW tile [B*3, t, 
 
 // tiled_decode (vae.rs:2225-2290) of a channels-last latent window; result into `out` (dims oT,oH,oW given)
 int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, const ltx_tiling& tl,
-                 float* out, std::vector<DevBuf>& pool, size_t& pool_used, hipStream_t s) {
+                 float* out, std::deque<DevBuf>& pool, size_t& pool_used, hipStream_t s) {
     const ltx_vae_config& c = v->cfg;
     const int r = c.spatial_compression_ratio, tr = c.temporal_compression_ratio;
     const size_t esz = ltx_dt_size(v->dtype);

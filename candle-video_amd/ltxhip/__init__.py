@@ -108,6 +108,7 @@ _SIGS = {
     "ltx_op_conv3d": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_upsample3d": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
 for _name, _sig in _SIGS.items():
@@ -573,6 +574,15 @@ class ops:
         _check(lib.ltx_op_upsample3d(_ptr(x_cl.contiguous()), _ptr(w.contiguous()), _ptr(bias.to(w.dtype).contiguous()), _dt(w.dtype), _ptr(y),
                                      B, T, H, W, Cin, Cout, int(causal), int(residual), _dt(x_cl.dtype), _stream()))
         return y
+
+    @staticmethod
+    def blend(a, b, dim, blend_extent):
+        """in place on a copy of b; a, b f32 [B,C,t,h,w]."""
+        a = a.contiguous(); b = b.clone().contiguous()
+        BC = a.shape[0] * a.shape[1]
+        _check(lib.ltx_op_blend(_ptr(a), _ptr(b), BC, a.shape[2], a.shape[3], a.shape[4], b.shape[2], b.shape[3], b.shape[4],
+                                dim, blend_extent, _stream()))
+        return b
 
     @staticmethod
     def conv_out_unpatchify(x_cl, w, bias, causal=False, postprocess=False):

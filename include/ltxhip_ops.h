@@ -52,6 +52,10 @@ int ltx_op_upsample3d(const void* x, const void* w, const void* bias, int wdtype
 int ltx_op_conv_out_unpatchify(const void* x, const void* w, const void* bias, int wdtype, float* y,
                                int B, int T, int H, int W, int Cin, int Cout, int causal, int postprocess, int dtype, ltx_stream stream);
 
+/* blend_h / blend_v / blend_t of the tiled decode (vae.rs:1927-2006), in place on b:
+ * b[..., x] = a[..., -blend + x]*(1 - x/blend) + b[..., x]*(x/blend) along dim (2=T, 3=H, 4=W); a,b f32 [BC,t,h,w]. */
+int ltx_op_blend(const float* a, float* b, int BC, int at, int ah, int aw, int bt, int bh, int bw, int dim, int blend_extent, ltx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,9 +229,46 @@ def test_guidance_and_scheduler_step_reference_vectors(hip, golden):
     assert (out - ref).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("dim", [2, 3, 4])
+@pytest.mark.parametrize("ashape,bshape,extent", [((9, 64, 64), (9, 64, 64), 32), ((9, 96, 96), (9, 32, 96), 32), ((9, 96, 96), (9, 96, 32), 32),
+                                                  ((16, 8, 8), (8, 8, 8), 8), ((3, 5, 7), (3, 5, 7), 50)])
+def test_tile_blend(hip, dim, ashape, bshape, extent):
+    # blend_h / blend_v / blend_t (vae.rs:1927-2006) vs the oracle's restatement; dims other than `dim` must agree
+    a = torch.randn(1, 3, *ashape); b = torch.randn(1, 3, *bshape)
+    for d in (2, 3, 4):
+        if d != dim and a.shape[d] != b.shape[d]:
+            pytest.skip("blend needs equal extents off-axis")
+    ref = O._blend(a, b, extent, dim)
+    out = hip.ops.blend(a.cuda(), b.cuda(), dim, extent).cpu()
+    assert (out - ref).abs().max() < 1e-6
+
+
 def test_errors_are_reported_not_crashed(hip):
     x = torch.randn(8, 30, device="cuda")           # K=30 is not a multiple of the 16-byte chunk
     with pytest.raises(hip.LtxError, match="multiple"):
         hip.ops.linear(x, torch.randn(16, 30, device="cuda"))
     with pytest.raises(hip.LtxError, match="head_dim"):
         hip.ops.attention(torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), 2, 1.0)
+
+
+@pytest.mark.parametrize("tile", ["256x256", "192x256", "128x256", "256x128", "192x128", "128x128"])
+def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
+    """gemm_big.hip (LDS-DMA staged, 8 waves): every tile shape, ragged M/N/K tails, every epilogue."""
+    monkeypatch.setenv("LTX_GEMM_TILE", tile)
+    dt = torch.bfloat16
+    M, N, K, S = 1300, 328, 200, 650
+    x, w, b = rnd(dt, M, K), rnd(dt, N, K, scale=K ** -0.5), rnd(dt, N, scale=0.1)
+    r = rnd(dt, M, N, seed=3); gate = rnd(torch.float32, M // S, N, seed=4)
+    lin = O.linear(x.float(), w.float(), b.float())
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda()), lin, dt)
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=1), O.gelu_approximate(lin), dt)
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=2, resid=r.cuda(), gate=gate.cuda(), rows_per_batch=S), r.float() + gate.repeat_interleave(S, 0) * lin, dt)
+    check(hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=3, resid=r.cuda()), r.float() + lin, dt)
+    # conv modes with M >= 1024 voxels
+    xc, wc, bc = rnd(dt, 1, 24, 3, 20, 19), rnd(dt, 40, 24, 3, 3, 3, scale=0.04), rnd(dt, 40, scale=0.1)
+    check(ncthw(hip.ops.conv3d(cl(xc).cuda(), wc.cuda(), bc.cuda())), O.causal_conv3d(xc.float(), wc.float(), bc.float(), False), dt)
+    xu, wu, bu = rnd(dt, 1, 32, 3, 20, 19), rnd(dt, 64, 32, 3, 3, 3, scale=0.04), rnd(dt, 64, scale=0.1)   # residual repeats = 64/32 = 2
+    pu = {"conv.conv.weight": wu.float(), "conv.conv.bias": bu.float()}
+    check(ncthw(hip.ops.upsample3d(cl(xu).cuda(), wu.cuda(), bu.cuda())), O.upsampler(pu, "", xu.float(), 8, False), dt)
+    wo, bo = rnd(dt, 48, 24, 3, 3, 3, scale=0.04), rnd(dt, 48, scale=0.1)
+    check(hip.ops.conv_out_unpatchify(cl(xc).cuda(), wo.cuda(), bo.cuda()), O.unpatchify(O.causal_conv3d(xc.float(), wo.float(), bo.float(), False), 4, 1), dt)
