@@ -130,7 +130,7 @@ __global__ void blend_kernel(BlendArgs a) {
         const int off = a.a_len - a.blend;
         const int x = a.dim == 2 ? t : (a.dim == 3 ? h : w);
         const int ta = t + (a.dim == 2 ? off : 0), ha = h + (a.dim == 3 ? off : 0), wa = w + (a.dim == 4 ? off : 0);
-        float wgt = (float)x * (1.0f / (float)a.blend);
+        float wgt = (float)x * a.inv_blend;
         int64_t ib = (((int64_t)bc * a.bt + t) * a.bh + h) * a.bw + w;
         int64_t ia = (((int64_t)bc * a.at + ta) * a.ah + ha) * a.aw + wa;
         int64_t id = (((int64_t)bc * a.dt + a.ot + t) * a.dh + a.oh + h) * a.dw + a.ow + w;
@@ -205,7 +205,9 @@ int ltx_launch_ncthw_to_cl(const void* x, int xdt, void* y, int ydt, int B, int 
 }
 int ltx_launch_blend(const BlendArgs& a, hipStream_t s) {
     if (a.blend <= 0 || a.et <= 0 || a.eh <= 0 || a.ew <= 0) return LTX_OK;
-    hipLaunchKernelGGL(blend_kernel, grid_for((int64_t)a.BC * a.et * a.eh * a.ew), dim3(256), 0, s, a);
+    BlendArgs b = a;
+    b.inv_blend = 1.0f / (float)a.blend;
+    hipLaunchKernelGGL(blend_kernel, grid_for((int64_t)a.BC * a.et * a.eh * a.ew), dim3(256), 0, s, b);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }
 int ltx_launch_copy_window(const float* src, int t, int h, int w, float* dst, int T, int H, int W, int BC,

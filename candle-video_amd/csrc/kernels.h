@@ -120,6 +120,7 @@ struct BlendArgs {
     int ot = 0, oh = 0, ow = 0;       // where b's origin sits inside dst
     int et = 1, eh = 1, ew = 1;       // extent of b to process (along `dim`: <= blend)
     int dim = 3, blend = 0;
+    float inv_blend = 0.f;            // 1/blend, filled by ltx_launch_blend
 };
 int ltx_launch_blend(const BlendArgs& a, hipStream_t s);
 // copy a [BC, st, sh, sw] window of src (dims [BC, t,h,w]) into dst at offset (ot,oh,ow) of dims [BC, T,H,W]
