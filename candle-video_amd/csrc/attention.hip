@@ -17,6 +17,7 @@
 //     of one read on distinct banks;
 //   * K tile rows are chunk-XOR-swizzled so the 32-row ds_read_b128 operand reads are conflict-free.
 // f32 kernel: exact-f32 VALU flash kernel (one query per lane), used only by the f32 parity mode.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -35,7 +36,7 @@ template <int CPR> __device__ __forceinline__ int vswz(int row, int c) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bf16_kernel(const AttnArgs a) {
     constexpr int HDP = HD < 32 ? 32 : HD;          // padded head dim for the PV d-blocks
     constexpr int KROW = HD * 2, VROW = HDP * 2;    // bytes per LDS row
     constexpr int KCPR = KROW / 16, VCPR = VROW / 16, VCV = (HD * 2) / 16;  // chunks per row; valid V chunks
@@ -122,7 +123,17 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a) {
     // tr-read lane geometry (see header): 16-lane group g = lane>>4 -> (h = g>>1, d-half = g&1)
     const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
 
-    for (int t = 0; t < nt; ++t) {
+    // Softmax bookkeeping.  Fast path (no key bias): the running max m_run is kept in RAW score units and
+    // the scale is folded into the exponent, p = exp2(fma(s, c, -m*c)) with c = scale*log2(e): one FMA + one
+    // v_exp per element, no separate scaling pass.  With a key bias the scores are first moved to the log2
+    // domain (x = s*c + bias*log2e) and c becomes 1.  The O/l rescale is LAZY: it is skipped while the tile
+    // max exceeds the running max by less than 2^RESCALE_THR for every query of the wave (P then stays <= 32,
+    // exact in bf16's floating format; sums are f32).  Tail-key masking runs only on the last, partial tile.
+    const bool has_bias = bias != nullptr;
+    const float c = has_bias ? 1.0f : sc2;
+    constexpr float RESCALE_THR = 5.0f;
+    auto tile_body = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int buf = t & 1;
         if (t + 1 < nt) gload(t + 1);
         const unsigned char* Ks = smem + buf * TILE_BYTES;
@@ -142,38 +153,49 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a) {
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax (per query column = lane&31; keys split over the two lane halves)
-        float mt = -INFINITY;
+        if (has_bias || MASKED) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float x = sacc[kb][i] * sc2;
-                if (bias) x += bias[key < a.Sk ? key : a.Sk - 1] * LOG2E;
-                if (key >= a.Sk) x = -INFINITY;
-                sacc[kb][i] = x;
-                mt = fmaxf(mt, x);
-            }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    float x = sacc[kb][i];
+                    if (has_bias) x = fmaf(x, sc2, bias[key < a.Sk ? key : a.Sk - 1] * LOG2E);
+                    if (MASKED && key >= a.Sk) x = -INFINITY;
+                    sacc[kb][i] = x;
+                }
+        }
+        // ---- tile max per query column (in-register over 32 scores, then across the two lane halves)
+        float mt = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, sacc[0][i]), sacc[1][i]);
+        {
+            unsigned mu = __float_as_uint(mt);
+            auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (!__all((mt - m_run) * c <= RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+        }
+        const float mc = -m_run * c;
         float ls = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float p = __builtin_amdgcn_exp2f(sacc[kb][i] - m_new);
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c, mc));
                 ls += p;
                 pf[kb][i >> 3][i & 7] = (bf16_t)p;
             }
-        l_run = l_run * alpha + ls;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+        l_run += ls;
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
@@ -194,7 +216,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a) {
         }
         if (t + 1 < nt) swrite(buf ^ 1);
         __syncthreads();
-    }
+    };
+    const bool ragged = (a.Sk % BKV) != 0;
+    for (int t = 0; t < nt - 1; ++t) tile_body(t, std::false_type{});
+    if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;

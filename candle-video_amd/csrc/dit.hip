@@ -4,11 +4,18 @@
 //   per block: rms+AdaLN | fused QKV GEMM | qk-RMSNorm+RoPE | flash attention | to_out GEMM (+gate*x+h)
 //              | q GEMM | q-norm | (k,v GEMM | k-norm) | cross attention (key bias) | to_out GEMM (+h)
 //              | rms+AdaLN | FF1 GEMM (+GELU-tanh) | FF2 GEMM (+gate*x+h)
+#include <deque>
 #include "model_util.h"
 
 struct DitBlock {
     LinearW qkv1, o1, q2, kv2, o2, ff1, ff2;
     void *nq1 = nullptr, *nk1 = nullptr, *nq2 = nullptr, *nk2 = nullptr;
+};
+
+struct DitCtx {                      // cached text context (see ltx_dit_forward)
+    const void* enc = nullptr; const float* mask = nullptr;
+    int B = 0, K = 0, iodt = 0; bool valid = false;
+    DevBuf kv, bias;                 // [L][B*K][2D] (k already RMS-normed), [B*K]
 };
 
 struct ltx_dit {
@@ -23,6 +30,8 @@ struct ltx_dit {
     float* rope_freqs = nullptr;     // [D/6]
     float* inv_freq = nullptr;       // [128]
     std::vector<int> skip_blocks;
+    std::deque<DitCtx> ctxs;         // deque: entries must not move while `ctx` points at one
+    bool ctx_mode = false;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
     DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT;
@@ -31,6 +40,8 @@ struct ltx_dit {
         owned.clear();
         DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT};
         for (DevBuf* b : bs) b->release();
+        for (auto& e : ctxs) { e.kv.release(); e.bias.release(); }
+        ctxs.clear();
     }
 };
 
@@ -209,7 +220,6 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
 
     // inputs -> model dtype (:1045-1047)
     LTX_TRY(ltx_launch_cast(hidden, iodt, m->xin.p, dt, M * c.in_channels, s));
-    LTX_TRY(ltx_launch_cast(enc, iodt, m->encin.p, dt, MK * c.caption_channels, s));
     LTX_TRY(ltx_linear(m->proj_in, m->xin.p, c.in_channels, m->h.p, D, (int)M, dt, EPI_BIAS, s));
 
     // AdaLayerNormSingle (:262-267): sinusoid(256) -> Linear -> SiLU -> Linear = embedded_timestep ; SiLU -> Linear(6D) = temb
@@ -223,11 +233,30 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
     LTX_TRY(ltx_launch_ada(m->ada.as<float>(), m->sst_blocks, m->temb.p, L, B, 6 * D, dt, s));
     LTX_TRY(ltx_launch_ada(m->adaf.as<float>(), m->sst_final, m->emb.p, 2, B, D, dt, s));
 
-    // caption projection (:186-190)
-    LTX_TRY(ltx_linear(m->cap1, m->encin.p, c.caption_channels, m->c1.p, D, (int)MK, dt, EPI_GELU, s));
-    LTX_TRY(ltx_linear(m->cap2, m->c1.p, D, m->encp.p, D, (int)MK, dt, EPI_BIAS, s));
-    const float* bias = nullptr;
-    if (enc_mask) { LTX_TRY(ltx_launch_mask_bias(m->bias.as<float>(), enc_mask, MK, s)); bias = m->bias.as<float>(); }
+    // Text context: caption projection (:186-190), mask bias (:1059-1070) and, for every layer, the cross-attention
+    // K/V projections + k-RMSNorm (:667-672).  None of it depends on the timestep or the latents, so inside a
+    // caching scope (ltx_dit_context_cache) it is computed once per (enc, mask) pair instead of once per forward.
+    DitCtx* ctx = nullptr;
+    for (auto& e : m->ctxs) if (e.valid && e.enc == enc && e.mask == enc_mask && e.B == B && e.K == K && e.iodt == iodt) ctx = &e;
+    if (!ctx) {
+        if (m->ctxs.size() >= 4 || !m->ctx_mode) { for (auto& e : m->ctxs) e.valid = false; }
+        for (auto& e : m->ctxs) if (!e.valid) { ctx = &e; break; }
+        if (!ctx) { m->ctxs.emplace_back(); ctx = &m->ctxs.back(); }
+        ctx->enc = enc; ctx->mask = enc_mask; ctx->B = B; ctx->K = K; ctx->iodt = iodt;
+        LTX_TRY(ctx->kv.ensure((size_t)L * MK * 2 * D * esz)); LTX_TRY(ctx->bias.ensure(MK * sizeof(float)));
+        LTX_TRY(ltx_launch_cast(enc, iodt, m->encin.p, dt, MK * c.caption_channels, s));
+        LTX_TRY(ltx_linear(m->cap1, m->encin.p, c.caption_channels, m->c1.p, D, (int)MK, dt, EPI_GELU, s));
+        LTX_TRY(ltx_linear(m->cap2, m->c1.p, D, m->encp.p, D, (int)MK, dt, EPI_BIAS, s));
+        if (enc_mask) LTX_TRY(ltx_launch_mask_bias(ctx->bias.as<float>(), enc_mask, MK, s));
+        for (int l = 0; l < L; ++l) {
+            void* kvl = (char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
+            LTX_TRY(ltx_linear(m->blocks[l].kv2, m->encp.p, D, kvl, 2 * D, (int)MK, dt, EPI_BIAS, s));
+            QkNormRopeArgs k2; k2.x = kvl; k2.rows = MK; k2.D = D; k2.ld = 2 * D; k2.nseg = 1; k2.w0 = m->blocks[l].nk2; k2.eps = 1e-5f;
+            LTX_TRY(ltx_launch_qknorm_rope(k2, dt, s));
+        }
+        ctx->valid = true;     // outside a caching scope the entry is invalidated again at the end of this forward
+    }
+    const float* bias = enc_mask ? ctx->bias.as<float>() : nullptr;
 
     // RoPE tables (:436-524)
     {
@@ -281,10 +310,8 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         LTX_TRY(ltx_linear(b.q2, m->h.p, D, m->qkv.p, D, (int)M, dt, EPI_BIAS, s));
         QkNormRopeArgs q2; q2.x = m->qkv.p; q2.rows = M; q2.D = D; q2.ld = D; q2.nseg = 1; q2.w0 = b.nq2; q2.eps = 1e-5f;
         LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
-        LTX_TRY(ltx_linear(b.kv2, m->encp.p, D, m->kv2.p, 2 * D, (int)MK, dt, EPI_BIAS, s));
-        QkNormRopeArgs k2; k2.x = m->kv2.p; k2.rows = MK; k2.D = D; k2.ld = 2 * D; k2.nseg = 1; k2.w0 = b.nk2; k2.eps = 1e-5f;
-        LTX_TRY(ltx_launch_qknorm_rope(k2, dt, s));
-        AttnArgs ax; ax.q = m->qkv.p; ax.k = m->kv2.p; ax.v = (char*)m->kv2.p + (size_t)D * esz; ax.o = m->attn.p;
+        const char* kvl = (const char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
+        AttnArgs ax; ax.q = m->qkv.p; ax.k = kvl; ax.v = kvl + (size_t)D * esz; ax.o = m->attn.p;
         ax.ldq = D; ax.ldk = ax.ldv = 2 * D; ax.ldo = D; ax.B = B; ax.Sq = S; ax.Sk = K; ax.heads = H; ax.hd = hd; ax.scale = attn_scale; ax.bias = bias;
         LTX_TRY(ltx_launch_attention(ax, dt, s));
         LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
@@ -306,5 +333,13 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         LTX_TRY(ltx_linear(m->proj_out, m->n.p, D, dst, c.out_channels, (int)M, dt, EPI_BIAS, s));
         if (iodt != dt) LTX_TRY(ltx_launch_cast(m->outT.p, dt, out, iodt, M * c.out_channels, s));
     }
+    if (!m->ctx_mode) ctx->valid = false;
+    return LTX_OK;
+}
+
+extern "C" int ltx_dit_context_cache(ltx_dit* m, int enable) {
+    if (!m) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_context_cache: null handle");
+    for (auto& e : m->ctxs) e.valid = false;
+    m->ctx_mode = enable != 0;
     return LTX_OK;
 }

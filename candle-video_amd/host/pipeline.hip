@@ -190,6 +190,8 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
         for (int i = 0; i < p->n_skip_blocks; ++i) { int li = p->skip_block_list[i]; if (li >= 0 && li < L) for (int b = 0; b < B; ++b) stg_mask[(size_t)li * B + b] = 1.0f; }
     }
     const float* coords = reinterpret_cast<const float*>(sc.coords);
+    struct CtxScope { ltx_dit* d; ~CtxScope() { (void)ltx_dit_context_cache(d, 0); } } ctx_scope{dit};
+    LTX_TRY(ltx_dit_context_cache(dit, 1));     // embeddings/masks are step-invariant inside one call
     // denoising loop (:860-994)
     for (int i = 0; i < N; ++i) {
         float tvals[8]; for (int b = 0; b < 8; ++b) tvals[b] = (float)ts[i];       // Tensor::full(t as f32, (b,))

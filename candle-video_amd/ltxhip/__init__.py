@@ -85,7 +85,7 @@ _fp = C.POINTER(C.c_float)
 _SIGS = {
     "ltx_dit_config_default": [_vp], "ltx_vae_config_default": [_vp], "ltx_tiling_default": [_vp],
     "ltx_dit_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_dit_destroy": [_vp],
-    "ltx_dit_set_skip_blocks": [_vp, _vp, _i], "ltx_dit_get_config": [_vp, _vp],
+    "ltx_dit_set_skip_blocks": [_vp, _vp, _i], "ltx_dit_context_cache": [_vp, _i], "ltx_dit_get_config": [_vp, _vp],
     "ltx_dit_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ltx_vae_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_vae_destroy": [_vp], "ltx_vae_get_config": [_vp, _vp],
     "ltx_vae_latents_mean": [_vp], "ltx_vae_latents_std": [_vp],

@@ -102,6 +102,12 @@ int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float
                     const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
                     ltx_dtype io_dtype, void* out, ltx_stream stream);
 
+/* Extension (no reference counterpart; results are identical): between enable=1 and enable=0 the caller promises
+ * that an (enc pointer, enc_mask pointer, B, K) tuple identifies unchanged contents, so the caption projection
+ * and the per-layer cross-attention K/V (which do not depend on timestep or latents, ltx_transformer.rs:1056,
+ * 667-672) are computed once per tuple instead of once per forward.  ltx_pipeline_call uses it around its loop. */
+int ltx_dit_context_cache(ltx_dit* m, int enable);
+
 /* ---- VaeLtxVideo (AutoencoderKLLtxVideo::new decoder side, vae.rs:1765-1869) ---- */
 /* weight names are the `decoder.*`, `latents_mean`, `latents_std` keys (vae.rs:1521-1608, 1827-1838) */
 int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t n_weights,
