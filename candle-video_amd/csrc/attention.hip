@@ -314,6 +314,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     struct End { void* t; hipStream_t s; ~End() { ltx_prof_end(t, s); } } end_{tok, s};
     if (dtype == LTX_DT_BF16) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
+        if (ltx_attention_pipe_eligible(a, dtype)) return ltx_launch_attention_pipe(a, s);   // long-Sk software-pipelined variant
         dim3 grid((unsigned)cdiv(a.Sq, BQ), (unsigned)a.heads, (unsigned)a.B), block(256);
         switch (a.hd) {
             case 16: hipLaunchKernelGGL(attn_bf16_kernel<16>, grid, block, 0, s, a); break;

@@ -12,11 +12,11 @@
 //   * conv mode gathers the A rows per tap from the channels-last activation: replicate padding
 //     on T is a clamp, zero padding on H/W (and K tails) redirect the lane to a zero page;
 //   * D = Wfrag x Afrag so a lane owns 4 consecutive output columns (shared fused epilogues).
+#include <cstring>
 #include "gemm_common.h"
 
 namespace {
 
-constexpr int BIG_THREADS = 512;
 constexpr int ROWB = 128;          // bytes per LDS row (64 bf16)
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];   // all zeros (static init)
@@ -30,15 +30,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 
 extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 
-template <int BM, int BN, int EPI, bool CONV>
-__global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 4, FM = WM / 16, FN = WN / 16;
-    constexpr int AI = BM / 64, BI = BN / 64;          // glds instructions per wave per K-step (A, B)
+template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV, bool PIN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs g) {
+    constexpr int NW = WGM * WGN;                       // waves per block, laid out WGM (M) x WGN (N)
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // glds instructions per wave per K-step (A, B)
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
     constexpr int STAGE = (BM + BN) * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int ntn = (g.N + BN - 1) / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    // XCD-aware tile order (speed only, bijective for any grid): blocks b and b+8 share an XCD/L2, so XCD x is
+    // given a CONTIGUOUS run of tiles -> neighbouring tiles (shared A rows / conv halos / W columns) hit one L2.
+    int bid = blockIdx.x;
+    if (g.xcd_remap) {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int mt = bid / ntn, nt = bid - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
@@ -52,25 +61,27 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const GemmArgs g)
     // lane -> (row in group = lane>>3, physical chunk = lane&7), logical chunk = pc ^ ((row>>1)&7)
     const int lr = lane >> 3, pc = lane & 7;
     int a_chunk[AI], b_chunk[BI];
-    int64_t a_off[AI];                 // linear mode: element offset of the row
-    int cb[AI], ct[AI], chh[AI], cw[AI];
+    int64_t a_off[AI];                 // element offset of the row (conv: of the centre voxel)
+    int ct[AI], vmask[AI];             // conv: frame index; 6 validity bits (h-1,h,h+1 | w-1,w,w+1 inside the image)
     int64_t b_off[BI];
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-        const int row = 8 * (j * 8 + wave) + lr;
+        const int row = 8 * (j * NW + wave) + lr;
         a_chunk[j] = pc ^ ((row >> 1) & 7);
         int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
         if constexpr (CONV) {
-            int w = m % g.Wd; int t1 = m / g.Wd;
-            int h = t1 % g.H; int t2 = t1 / g.H;
-            ct[j] = t2 % g.T; cb[j] = t2 / g.T; chh[j] = h; cw[j] = w;
+            const int w = m % g.Wd; const int t1 = m / g.Wd;
+            const int h = t1 % g.H; const int t2 = t1 / g.H;
+            ct[j] = t2 % g.T;
+            vmask[j] = (h > 0 ? 1 : 0) | 2 | (h < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0);
+            a_off[j] = (int64_t)m * g.Cin;
         } else {
             a_off[j] = (int64_t)m * g.lda;
         }
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int row = 8 * (j * 8 + wave) + lr;
+        const int row = 8 * (j * NW + wave) + lr;
         b_chunk[j] = pc ^ ((row >> 1) & 7);
         int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
         b_off[j] = (int64_t)n * Kdim;
@@ -81,33 +92,35 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const GemmArgs g)
         unsigned char* Bs = As + BM * ROWB;
         int tap = 0, kk = kt;
         if constexpr (CONV) { tap = kt / ktiles; kk = kt - tap * ktiles; }
-        int dt = 0, dh = 0, dw = 0;
+        int dt = 0, vbit = 0; int64_t hw_delta = 0;       // all wave-uniform (scalar) per tap
         if constexpr (CONV) {
             const int khw = g.kh * g.kw;
             const int it = tap / khw; const int rem = tap - it * khw;
             const int ih = rem / g.kw; const int iw = rem - ih * g.kw;
-            dt = it - g.pad_t; dh = ih - g.kh / 2; dw = iw - g.kw / 2;
+            const int dh = ih - g.kh / 2, dw = iw - g.kw / 2;
+            dt = it - g.pad_t;
+            vbit = (1 << (dh + 1)) | (8 << (dw + 1));
+            hw_delta = ((int64_t)dh * g.Wd + dw) * g.Cin;
         }
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             const int k = kk * 64 + a_chunk[j] * 8;
             const unsigned char* src = zero;
             if constexpr (CONV) {
-                int tt = ct[j] + dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);      // replicate pad (vae.rs:374-413)
-                const int hh = chh[j] + dh, ww = cw[j] + dw;
-                if (k < Kdim && hh >= 0 && hh < g.H && ww >= 0 && ww < g.Wd)                 // zero pad (vae.rs:337-349)
-                    src = reinterpret_cast<const unsigned char*>(A + ((((int64_t)cb[j] * g.T + tt) * g.H + hh) * g.Wd + ww) * (int64_t)g.Cin + k);
+                int tt = ct[j] + dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);      // replicate pad on T (vae.rs:374-413)
+                if (k < Kdim && (vmask[j] & vbit) == vbit)                                   // zero pad on H/W (vae.rs:337-349)
+                    src = reinterpret_cast<const unsigned char*>(A + a_off[j] + (int64_t)(tt - ct[j]) * g.H * g.Wd * g.Cin + hw_delta + k);
             } else {
                 if (k < Kdim) src = reinterpret_cast<const unsigned char*>(A + a_off[j] + k);
             }
-            glds16(src, As + (j * 8 + wave) * 1024);
+            glds16(src, As + (j * NW + wave) * 1024);
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const int k = kk * 64 + b_chunk[j] * 8;
             const unsigned char* src = zero;
             if (k < Kdim) src = reinterpret_cast<const unsigned char*>(W + (int64_t)tap * g.N * Kdim + b_off[j] + k);
-            glds16(src, Bs + (j * 8 + wave) * 1024);
+            glds16(src, Bs + (j * NW + wave) * 1024);
         }
     };
 
@@ -126,17 +139,32 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const GemmArgs g)
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const unsigned char* As = big_smem + buf * STAGE;
         const unsigned char* Bs = As + BM * ROWB;
+        // Fragment stream: W fragments of the k-block stay in registers, A fragments are read ONE AHEAD of the
+        // MFMAs that consume them (the pinned order below keeps hipcc from collapsing it back into
+        // "read 2, drain lgkmcnt(0), 4 MFMAs", which exposed the LDS latency 6 times per K-step).
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             Chunk16 af[FM], wf[FN];
 #pragma unroll
-            for (int f = 0; f < FM; ++f) af[f].u = *reinterpret_cast<const u32x4*>(As + swz_big(wm * WM + f * 16 + frow, kb * 4 + fq));
-#pragma unroll
             for (int f = 0; f < FN; ++f) wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_big(wn * WN + f * 16 + frow, kb * 4 + fq));
+            af[0].u = *reinterpret_cast<const u32x4*>(As + swz_big(wm * WM + frow, kb * 4 + fq));
 #pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
+            for (int fm = 0; fm < FM; ++fm) {
+                if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + swz_big(wm * WM + (fm + 1) * 16 + frow, kb * 4 + fq));
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
+            }
+        }
+        if constexpr (PIN) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                __builtin_amdgcn_sched_group_barrier(0x100, FN + 1, 0);            // DS read: W frags + first A frag
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    if (fm + 1 < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // next A frag
+                    __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);            // MFMAs of the current A frag
+                }
+            }
         }
         __syncthreads();
     }
@@ -155,76 +183,96 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const GemmArgs g)
     }
 }
 
-template <int BM, int BN, int EPI, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;
-    auto kern = gemm_big_kernel<BM, BN, EPI, CONV>;
+    auto kern = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, true>;
+    auto kern_nopin = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, false>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_nopin), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN))), block(BIG_THREADS);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, g);
+    dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN))), block(64 * WGM * WGN);
+    const char* pe = getenv("LTX_GEMM_PIN");
+    if (pe && pe[0] == '0') hipLaunchKernelGGL(kern_nopin, grid, block, smem, s, g);
+    else hipLaunchKernelGGL(kern, grid, block, smem, s, g);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int WGM, int WGN, bool CONV>
 int launch_epi(const GemmArgs& g, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_BIAS: return launch_one<BM, BN, EPI_BIAS, CONV>(g, s);
-        case EPI_GELU: return launch_one<BM, BN, EPI_GELU, CONV>(g, s);
-        case EPI_GATE_RESID: return launch_one<BM, BN, EPI_GATE_RESID, CONV>(g, s);
-        case EPI_RESID: return launch_one<BM, BN, EPI_RESID, CONV>(g, s);
-        case EPI_D2S: if constexpr (CONV) return launch_one<BM, BN, EPI_D2S, CONV>(g, s); break;
-        case EPI_UNPATCH: if constexpr (CONV) return launch_one<BM, BN, EPI_UNPATCH, CONV>(g, s); break;
+        case EPI_BIAS: return launch_one<BM, BN, WGM, WGN, EPI_BIAS, CONV>(g, s);
+        case EPI_GELU: return launch_one<BM, BN, WGM, WGN, EPI_GELU, CONV>(g, s);
+        case EPI_GATE_RESID: return launch_one<BM, BN, WGM, WGN, EPI_GATE_RESID, CONV>(g, s);
+        case EPI_RESID: return launch_one<BM, BN, WGM, WGN, EPI_RESID, CONV>(g, s);
+        case EPI_D2S: if constexpr (CONV) return launch_one<BM, BN, WGM, WGN, EPI_D2S, CONV>(g, s); break;
+        case EPI_UNPATCH: if constexpr (CONV) return launch_one<BM, BN, WGM, WGN, EPI_UNPATCH, CONV>(g, s); break;
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: bad epilogue");
 }
 
+// tile ids: see kTiles below
 template <bool CONV>
-int launch_tile(const GemmArgs& g, int epi, int bm, int bn, hipStream_t s) {
-    if (bm == 256 && bn == 256) return launch_epi<256, 256, CONV>(g, epi, s);
-    if (bm == 192 && bn == 256) return launch_epi<192, 256, CONV>(g, epi, s);
-    if (bm == 128 && bn == 256) return launch_epi<128, 256, CONV>(g, epi, s);
-    if (bm == 256 && bn == 128) return launch_epi<256, 128, CONV>(g, epi, s);
-    if (bm == 192 && bn == 128) return launch_epi<192, 128, CONV>(g, epi, s);
-    if (bm == 128 && bn == 128) return launch_epi<128, 128, CONV>(g, epi, s);
+int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
+    switch (tile) {
+        case 0: return launch_epi<256, 256, 2, 4, CONV>(g, epi, s);
+        case 1: return launch_epi<192, 256, 2, 4, CONV>(g, epi, s);
+        case 2: return launch_epi<128, 256, 2, 4, CONV>(g, epi, s);
+        case 3: return launch_epi<256, 128, 2, 4, CONV>(g, epi, s);
+        case 4: return launch_epi<192, 128, 2, 4, CONV>(g, epi, s);
+        case 5: return launch_epi<128, 128, 2, 4, CONV>(g, epi, s);
+        case 6: return launch_epi<192, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 96x64 per wave
+        case 7: return launch_epi<128, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 64x64 per wave
+        case 8: return launch_epi<256, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 128x64 per wave
+    }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
 
+struct TileInfo { int bm, bn, threads; double rate; int per_cu; const char* name; };
+// rate: per-CU sustained TFLOP/s of the tile at full occupancy (tools/microbench.py tiles, MI355X, random data);
+// per_cu: blocks that fit one CU (LDS 2*(BM+BN)*128 B of 160 KiB, <= 2048 threads)
+const TileInfo kTiles[] = {
+    {256, 256, 512, 1160, 1, "256x256"}, {192, 256, 512, 1190, 1, "192x256"}, {128, 256, 512, 1023, 1, "128x256"},
+    {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
+    {192, 128, 256, 0, 2, "192x128w4"},  {128, 128, 256, 0, 2, "128x128w4"},  {256, 128, 256, 0, 1, "256x128w4"},
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
 }  // namespace
 
-// Tile choice: minimise (rounds over 256 CUs) x (tile area); ties go to the larger tile (less operand re-reading).
-void ltx_gemm_big_pick_tile(int M, int N, int* bm_out, int* bn_out) {
-    static const int cand[6][2] = {{256, 256}, {192, 256}, {128, 256}, {256, 128}, {192, 128}, {128, 128}};
-    const char* force = getenv("LTX_GEMM_TILE");       // e.g. "256x128" (tuning aid)
-    if (force) { int a = 0, b = 0; if (sscanf(force, "%dx%d", &a, &b) == 2) { *bm_out = a; *bn_out = b; return; } }
-    // per-CU sustained rate of each tile at full occupancy (TFLOP/s, measured with tools/microbench.py tiles on
-    // MI355X, random data) and how many 512-thread blocks of it fit one CU (LDS: 2*(BM+BN)*128 B of 160 KiB)
-    static const double rate[6] = {1160, 1190, 1023, 989, 1400, 1032};
-    static const int per_cu[6] = {1, 1, 1, 1, 2, 2};
-    double best = 1e30; int bi = 0;
-    for (int i = 0; i < 6; ++i) {
-        const int bm = cand[i][0], bn = cand[i][1];
-        if (bn > 128 && N <= 128) continue;
-        const int64_t tiles = (int64_t)cdiv(M, bm) * cdiv(N, bn);
-        const double cost = (double)cdiv64(tiles, 256 * per_cu[i]) * (double)(bm * bn * per_cu[i]) / rate[i];
+// Tile choice: minimise (rounds over the CUs) x (tile time); ties go to the larger tile (less operand re-reading).
+int ltx_gemm_big_pick_tile(int M, int N) {
+    const char* force = getenv("LTX_GEMM_TILE");       // e.g. "256x128" or "192x128w4" (tuning aid)
+    if (force) for (int i = 0; i < kNumTiles; ++i) if (!strcmp(force, kTiles[i].name)) return i;
+    double best = 1e30; int bi = 4;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileInfo& t = kTiles[i];
+        if (t.rate <= 0) continue;
+        if (t.bn > 128 && N <= 128) continue;
+        const int64_t tiles = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
+        const double cost = (double)cdiv64(tiles, 256 * t.per_cu) * (double)(t.bm * t.bn * t.per_cu) / t.rate;
         if (cost < best * 0.999) { best = cost; bi = i; }
     }
-    *bm_out = cand[bi][0]; *bn_out = cand[bi][1];
+    return bi;
 }
 
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     if (dtype != LTX_DT_BF16) return false;
     const char* off = getenv("LTX_GEMM_BIG");
     if (off && off[0] == '0') return false;
+    if (g.conv && (g.kh > 3 || g.kw > 3)) return false;   // the validity mask covers 3x3 (and 1x1) spatial taps
     return g.M >= 1024 && g.N >= 64;
 }
 
-int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s) {
-    int bm, bn;
-    ltx_gemm_big_pick_tile(g.M, g.N, &bm, &bn);
-    return g.conv ? launch_tile<true>(g, epi, bm, bn, s) : launch_tile<false>(g, epi, bm, bn, s);
+int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
+    GemmArgs g = g_in;
+    const int tile = ltx_gemm_big_pick_tile(g.M, g.N);
+    // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
+    const char* xr = getenv("LTX_XCD_REMAP");
+    g.xcd_remap = xr ? (xr[0] == '1') : 1;
+    return g.conv ? launch_tile<true>(g, epi, tile, s) : launch_tile<false>(g, epi, tile, s);
 }

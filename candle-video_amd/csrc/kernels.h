@@ -31,12 +31,13 @@ struct GemmArgs {
     int ntaps = 1, kh = 1, kw = 1, pad_t = 0;   // pad_t: frames of left temporal replicate padding
     // D2S / UNPATCH
     int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
+    int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
 };
 int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
 // large-tile LDS-DMA bf16 variant (gemm_big.hip); ltx_launch_gemm dispatches to it when eligible
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype);
 int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
-void ltx_gemm_big_pick_tile(int M, int N, int* bm_out, int* bn_out);
+int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table
 
 // ---------------- row norms (rownorm.hip) ----------------
 struct RowNormArgs {
@@ -80,6 +81,9 @@ struct AttnArgs {
     const float* bias = nullptr;                  // f32 [B, Sk] additive key bias or null
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+// software-pipelined bf16 variant for long key sequences (attention_pipe.hip); ltx_launch_attention dispatches to it
+bool ltx_attention_pipe_eligible(const AttnArgs& a, int dtype);
+int ltx_launch_attention_pipe(const AttnArgs& a, hipStream_t s);
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
 struct TimeVec { float t[8]; int n; };
