@@ -217,7 +217,8 @@ def main():
             # separate, untimed pass with hipEvents around every launch of the heavy kernel classes (on their stream)
             ltxhip.prof_enable(True)
             step()
-            kinds = {"gemm_kernel<bf16> (Linear)": 0, "gemm_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_bf16_kernel<64> (self)": 2,
+            kinds = {"gemm_big_kernel/gemm_p8_kernel<bf16> (Linear GEMMs, tile per shape)": 0,
+                     "gemm_big_kernel/gemm_p8_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_bf16_kernel<64> (self)": 2,
                      "attn_bf16_kernel<64> (cross)": 3, "rownorm_kernel<bf16>": 4}
             per = {}
             for name, k in kinds.items():
@@ -231,6 +232,10 @@ def main():
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": per[dom]["avg_ms"],
                                "launches_per_video": per[dom]["launches"]}
             out["kernels"] = per
+            Fh, Hh, Wh = F, H, W
+            out["gemm_plans"] = {"qkv": ltxhip.ops.gemm_plan(S, 6144, 2048), "attn_out/q2/out2": ltxhip.ops.gemm_plan(S, 2048, 2048),
+                                 "ff1": ltxhip.ops.gemm_plan(S, 8192, 2048), "ff2": ltxhip.ops.gemm_plan(S, 2048, 8192),
+                                 "vae_mid_1024": ltxhip.ops.gemm_plan(Fh * Hh * Wh, 1024, 1024, 1, 27, Fh, Hh, Wh)}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -117,3 +117,11 @@ extern "C" int ltx_op_blend(const float* a, float* b, int BC, int at, int ah, in
     if (dim == 2) ba.et = ba.blend; else if (dim == 3) ba.eh = ba.blend; else ba.ew = ba.blend;
     return ltx_launch_blend(ba, (hipStream_t)stream);
 }
+
+const char* ltx_gemm_plan_name(int M, int N, int K, int conv, int ntaps, int T, int H, int W);
+extern "C" int ltx_op_gemm_plan(int M, int N, int K, int conv, int ntaps, int T, int H, int W, char* name, int cap) {
+    if (!name || cap < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_op_gemm_plan: bad argument");
+    const char* n = ltx_gemm_plan_name(M, N, K, conv, ntaps, T, H, W);
+    snprintf(name, (size_t)cap, "%s", n);
+    return LTX_OK;
+}

@@ -13,6 +13,8 @@
 //     on T is a clamp, zero padding on H/W (and K tails) redirect the lane to a zero page;
 //   * D = Wfrag x Afrag so a lane owns 4 consecutive output columns (shared fused epilogues).
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "gemm_common.h"
 
 namespace {
@@ -34,8 +36,9 @@ template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV, bool PIN>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN;                       // waves per block, laid out WGM (M) x WGN (N)
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
-    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // glds instructions per wave per K-step (A, B)
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
+    constexpr int AI = (BM + 8 * NW - 1) / (8 * NW), BI = BN / (8 * NW);   // glds instructions per wave per K-step (A, B)
+    constexpr bool A_RAGGED = BM % (8 * NW) != 0;       // e.g. BM = 160: 20 eight-row pieces over 8 waves, the last round half empty
+    static_assert(BM % 8 == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
     constexpr int STAGE = (BM + BN) * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             } else {
                 if (k < Kdim) src = reinterpret_cast<const unsigned char*>(A + a_off[j] + k);
             }
-            glds16(src, As + (j * NW + wave) * 1024);
+            if (!A_RAGGED || (j * NW + wave) * 8 < BM) glds16(src, As + (j * NW + wave) * 1024);
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
@@ -228,6 +231,7 @@ int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         case 6: return launch_epi<192, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 96x64 per wave
         case 7: return launch_epi<128, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 64x64 per wave
         case 8: return launch_epi<256, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 128x64 per wave
+        case 9: return launch_epi<160, 128, 2, 4, CONV>(g, epi, s);     // M = 4992 = 31.2 x 160: 32 x (N/128) tiles = whole rounds of 512
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
@@ -239,6 +243,7 @@ const TileInfo kTiles[] = {
     {256, 256, 512, 1160, 1, "256x256"}, {192, 256, 512, 1190, 1, "192x256"}, {128, 256, 512, 1023, 1, "128x256"},
     {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
     {192, 128, 256, 0, 2, "192x128w4"},  {128, 128, 256, 0, 2, "128x128w4"},  {256, 128, 256, 0, 1, "256x128w4"},
+    {160, 128, 512, 1330, 2, "160x128"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -268,11 +273,102 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     return g.M >= 1024 && g.N >= 64;
 }
 
+// ---- plan selection --------------------------------------------------------------------------------------------
+// A plan is a gemm_big tile id (0 .. kNumTiles-1) or kPlanP8 + {0: BN=256, 1: BN=128} (gemm_p8.hip).  Every plan
+// accumulates K in the same order with the same MFMA, so the choice changes speed only, never a bit of the result.
+// Default: measure once per problem shape (first call: each candidate runs into a scratch output, best of the timed
+// launches wins, cached for the life of the process).  LTX_GEMM_TUNE=0 falls back to the static cost model;
+// LTX_GEMM_TILE / LTX_GEMM_P8 force a plan (tests, A/B runs).
+namespace {
+constexpr int kPlanP8 = 100;
+struct PlanKey {
+    int M, N, K, conv, ntaps, T, H, W;
+    bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
+};
+std::map<PlanKey, int> g_plans;
+std::mutex g_plan_mu;
+
+int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
+    if (plan >= kPlanP8) return ltx_launch_gemm_p8(g, epi, plan == kPlanP8 ? 256 : 128, s);
+    return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
+}
+
+int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) {
+    *plan_out = fallback;
+    GemmArgs g = g_in;                                   // plain bias epilogue into a scratch [M, N] output
+    void* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)g.M * g.N * sizeof(bf16_t)) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
+    g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
+    float best = 1e30f;
+    const char* p8e = getenv("LTX_GEMM_P8");
+    const bool p8_off = p8e && p8e[0] == '0';
+    for (int plan = 0; plan < kPlanP8 + 2; ++plan) {
+        if (plan < kPlanP8) {
+            if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
+            if (kTiles[plan].rate <= 0 || (kTiles[plan].bn > 128 && g.N <= 128)) continue;
+        } else if (p8_off || nk < 2 || (plan == kPlanP8 && g.N <= 128)) continue;
+        // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
+        // 3..16 of them, best of two rounds
+        HIP_TRY(hipEventRecord(e0, s));
+        int rc = run_plan(g, EPI_BIAS, plan, s);
+        if (rc != LTX_OK) continue;
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        int n = ms > 0.f ? (int)(1.5f / ms) : 16;
+        n = n < 3 ? 3 : (n > 16 ? 16 : n);
+        for (int round = 0; round < 2; ++round) {
+            HIP_TRY(hipEventRecord(e0, s));
+            for (int i = 0; i < n; ++i) run_plan(g, EPI_BIAS, plan, s);
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            ms /= (float)n;
+            if (ms < best) { best = ms; *plan_out = plan; }
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipFree(scratch));
+    return LTX_OK;
+}
+}  // namespace
+
 int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     GemmArgs g = g_in;
-    const int tile = ltx_gemm_big_pick_tile(g.M, g.N);
     // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
     const char* xr = getenv("LTX_XCD_REMAP");
     g.xcd_remap = xr ? (xr[0] == '1') : 1;
-    return g.conv ? launch_tile<true>(g, epi, tile, s) : launch_tile<false>(g, epi, tile, s);
+    const int p8 = ltx_gemm_p8_choice(g);
+    if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
+    int plan = ltx_gemm_big_pick_tile(g.M, g.N);
+    const char* tune = getenv("LTX_GEMM_TUNE");
+    if (!getenv("LTX_GEMM_TILE") && !(tune && tune[0] == '0')) {
+        PlanKey key; memset(&key, 0, sizeof(key));
+        key.M = g.M; key.N = g.N; key.K = g.K; key.conv = g.conv;
+        if (g.conv) { key.ntaps = g.ntaps; key.T = g.T; key.H = g.H; key.W = g.Wd; }
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) {
+            int tuned = plan;
+            const int rc = tune_plan(g, s, plan, &tuned);
+            if (rc != LTX_OK) return rc;
+            it = g_plans.emplace(key, tuned).first;
+        }
+        plan = it->second;
+    }
+    return run_plan(g, epi, plan, s);
+}
+
+// tuning/diagnostic aid: name of the plan cached for a shape ("" if none)
+const char* ltx_gemm_plan_name(int M, int N, int K, int conv, int ntaps, int T, int H, int W) {
+    PlanKey key; memset(&key, 0, sizeof(key));
+    key.M = M; key.N = N; key.K = K; key.conv = conv;
+    if (conv) { key.ntaps = ntaps; key.T = T; key.H = H; key.W = W; }
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) return "";
+    return it->second >= kPlanP8 ? (it->second == kPlanP8 ? "p8:256" : "p8:128") : kTiles[it->second].name;
 }

@@ -109,6 +109,7 @@ _SIGS = {
     "ltx_op_upsample3d": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_gemm_plan": [_i, _i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
 for _name, _sig in _SIGS.items():
@@ -574,6 +575,13 @@ class ops:
         _check(lib.ltx_op_upsample3d(_ptr(x_cl.contiguous()), _ptr(w.contiguous()), _ptr(bias.to(w.dtype).contiguous()), _dt(w.dtype), _ptr(y),
                                      B, T, H, W, Cin, Cout, int(causal), int(residual), _dt(x_cl.dtype), _stream()))
         return y
+
+    @staticmethod
+    def gemm_plan(M, N, K, conv=0, ntaps=1, T=1, H=1, W=1) -> str:
+        """name of the GEMM plan the dispatcher cached for this bf16 shape ("" before its first run)."""
+        buf = C.create_string_buffer(32)
+        _check(lib.ltx_op_gemm_plan(M, N, K, conv, ntaps, T, H, W, buf, 32))
+        return buf.value.decode()
 
     @staticmethod
     def blend(a, b, dim, blend_extent):

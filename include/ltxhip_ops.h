@@ -56,6 +56,11 @@ int ltx_op_conv_out_unpatchify(const void* x, const void* w, const void* bias, i
  * b[..., x] = a[..., -blend + x]*(1 - x/blend) + b[..., x]*(x/blend) along dim (2=T, 3=H, 4=W); a,b f32 [BC,t,h,w]. */
 int ltx_op_blend(const float* a, float* b, int BC, int at, int ah, int aw, int bt, int bh, int bw, int dim, int blend_extent, ltx_stream stream);
 
+/* Diagnostic: which GEMM plan (tile shape / kernel) the dispatcher measured best and cached for a bf16 problem shape
+ * (conv = 0: [M,K] x [N,K]^T; conv = 1: K = Cin, ntaps/T/H/W = conv geometry).  Writes a NUL-terminated name
+ * ("192x128", "p8:256", ... or "" if the shape has not run yet) into name[cap]. */
+int ltx_op_gemm_plan(int M, int N, int K, int conv, int ntaps, int T, int H, int W, char* name, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,10 +251,14 @@ def test_errors_are_reported_not_crashed(hip):
         hip.ops.attention(torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), torch.randn(1, 8, 48, device="cuda"), 2, 1.0)
 
 
-@pytest.mark.parametrize("tile", ["256x256", "192x256", "128x256", "256x128", "192x128", "128x128", "192x128w4", "128x128w4", "256x128w4"])
+@pytest.mark.parametrize("tile", ["256x256", "192x256", "128x256", "256x128", "192x128", "128x128", "192x128w4", "128x128w4", "256x128w4",
+                                  "160x128", "p8:256", "p8:128"])
 def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
-    """gemm_big.hip (LDS-DMA staged, 8 waves): every tile shape, ragged M/N/K tails, every epilogue."""
-    monkeypatch.setenv("LTX_GEMM_TILE", tile)
+    """gemm_big.hip (LDS-DMA staged, 8 waves) and gemm_p8.hip (phase-interleaved): every tile shape, ragged M/N/K tails, every epilogue."""
+    if tile.startswith("p8:"):
+        monkeypatch.setenv("LTX_GEMM_P8", tile[3:])
+    else:
+        monkeypatch.setenv("LTX_GEMM_TILE", tile)
     dt = torch.bfloat16
     M, N, K, S = 1300, 328, 200, 650
     x, w, b = rnd(dt, M, K), rnd(dt, N, K, scale=K ** -0.5), rnd(dt, N, scale=0.1)

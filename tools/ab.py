@@ -15,6 +15,15 @@ if "gemm" in which:
         x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
         r = torch.randn(M, N, device=dev).bfloat16(); g = torch.randn(1, N, device=dev)
         cases.append((name, 2 * M * N * K, (lambda x=x, w=w, b=b, r=r, g=g, epi=epi, M=M: ltxhip.ops.linear(x, w, b, epi=epi, resid=r if epi >= 2 else None, gate=g if epi == 2 else None, rows_per_batch=M))))
+if "square" in which:      # the guide's reference shapes (one 256x256 tile per CU at 4096)
+    for n in (4096, 8192):
+        x = torch.randn(n, n, device=dev).bfloat16(); w = (torch.randn(n, n, device=dev) / math.sqrt(n)).bfloat16()
+        cases.append((f"sq{n}", 2 * n ** 3, (lambda x=x, w=w: ltxhip.ops.linear(x, w, None))))
+        if n == 4096:   # data dependence of the clock (DVFS): uniform [-1,1) and all-zero operands
+            xu = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16(); wu = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16()
+            cases.append((f"sq{n}_uniform", 2 * n ** 3, (lambda x=xu, w=wu: ltxhip.ops.linear(x, w, None))))
+            xz = torch.zeros(n, n, device=dev).bfloat16(); wz = torch.zeros(n, n, device=dev).bfloat16()
+            cases.append((f"sq{n}_zero", 2 * n ** 3, (lambda x=xz, w=wz: ltxhip.ops.linear(x, w, None))))
 if "conv" in which:
     for name, C, T, H, W in [("mid1024", 1024, 13, 16, 24), ("up0_512", 512, 25, 32, 48), ("up1_256", 256, 49, 64, 96), ("up2_128", 128, 97, 128, 192)]:
         x = torch.randn(1, T, H, W, C, device=dev).bfloat16(); w = (torch.randn(C, C, 3, 3, 3, device=dev) / math.sqrt(27 * C)).bfloat16(); b = torch.randn(C, device=dev).bfloat16()
@@ -32,3 +41,9 @@ for rnd in range(3):
 os.environ.pop(var, None)
 for name in res:
     print(json.dumps({"case": name, var: {v: round(sorted(res[name][v])[1], 1) for v in vals}}))
+plans = {}
+for name, M, N, K in [("qkv", S, 6144, 2048), ("to_out", S, 2048, 2048), ("ff1", S, 8192, 2048), ("ff2", S, 2048, 8192), ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192)]:
+    plans[name] = ltxhip.ops.gemm_plan(M, N, K)
+for name, C, T, H, W in [("mid1024", 1024, 13, 16, 24), ("up0_512", 512, 25, 32, 48), ("up1_256", 256, 49, 64, 96), ("up2_128", 128, 97, 128, 192)]:
+    plans[name] = ltxhip.ops.gemm_plan(T * H * W, C, C, 1, 27, T, H, W)
+print(json.dumps({"tuned_plans": {k: v for k, v in plans.items() if v}}))
