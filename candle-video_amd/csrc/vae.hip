@@ -499,3 +499,15 @@ extern "C" int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const floa
     TimeVec tv; tv.n = B; for (int i = 0; i < 8; ++i) tv.t[i] = (timestep && i < B) ? timestep[i] : 0.f;
     return decode_cl(v, v->zin.p, B, F, H, W, timestep ? &tv : nullptr, tiling, postprocess, out, s);
 }
+
+extern "C" int ltx_vae_prepare_latents(ltx_vae* v, const float* tokens, const float* noise, const float* noise_scale,
+                                       int B, int F, int H, int W, float* out_tokens, ltx_stream stream) {
+    LTX_TRY(check_decode_args(v, B, F, H, W));
+    if (!tokens || !out_tokens) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_prepare_latents: null tensor");
+    if (noise && !noise_scale) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_prepare_latents: noise needs noise_scale");
+    HIP_TRY(hipSetDevice(v->device));
+    const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
+    TimeVec ns; ns.n = B; for (int i = 0; i < 8; ++i) ns.t[i] = (noise && i < B) ? noise_scale[i] : 0.f;
+    return ltx_launch_denorm_mix(tokens, v->mean, v->std_, 1.0f / v->cfg.scaling_factor, noise, ns, out_tokens, LTX_DT_F32, B, S, C,
+                                 (hipStream_t)stream);
+}

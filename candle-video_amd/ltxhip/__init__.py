@@ -91,6 +91,7 @@ _SIGS = {
     "ltx_vae_latents_mean": [_vp], "ltx_vae_latents_std": [_vp],
     "ltx_vae_decode": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "ltx_vae_decode_tokens": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    "ltx_vae_prepare_latents": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ltx_guidance_step": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp, _vp],
     "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
     "ltx_calculate_shift": [_i, _i, _i, _f, _f],
@@ -205,6 +206,11 @@ class LtxVideoTransformer3DModel:
         if h:
             lib.ltx_dit_destroy(h)
             self._h = None
+
+    def context_cache(self, enable: bool):
+        """keep the text-side projections (caption projection, cross-attention K/V) of repeated forwards with the same
+        embeddings/mask pointers; LtxPipeline::call scopes it to one denoise loop."""
+        _check(lib.ltx_dit_context_cache(self._h, int(enable)))
 
     def set_skip_block_list(self, blocks: Sequence[int]):
         arr = (C.c_int * max(len(blocks), 1))(*blocks)
@@ -335,6 +341,17 @@ class AutoencoderKLLtxVideo:
         _check(lib.ltx_vae_decode_tokens(self._h, _ptr(x), _ptr(nz), ns, t, B, F, H, W, C.byref(tl) if tl else None,
                                          int(postprocess), _ptr(out), _stream()))
         return out
+
+    def prepare_latents(self, tokens: torch.Tensor, F: int, H: int, W: int, noise: Optional[torch.Tensor] = None,
+                        noise_scale=None) -> torch.Tensor:
+        """denormalize (+ decode-noise mix) of packed tokens [B,S,C] -> [B,C,F,H,W] f32 (t2v_pipeline.rs:1002-1053)."""
+        x = _dev(tokens, torch.float32)
+        B = x.shape[0]
+        ns = _floats(list(noise_scale)) if noise_scale is not None else None
+        nz = _dev(noise, torch.float32) if noise is not None else None
+        out = torch.empty_like(x)
+        _check(lib.ltx_vae_prepare_latents(self._h, _ptr(x), _ptr(nz), ns, B, F, H, W, _ptr(out), _stream()))
+        return out.reshape(B, F, H, W, -1).permute(0, 4, 1, 2, 3).contiguous()
 
     def latents_mean(self) -> torch.Tensor:
         lib.ltx_vae_latents_mean.restype = C.c_void_p

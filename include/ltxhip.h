@@ -129,6 +129,11 @@ int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtype, const fl
 int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const float* noise, const float* noise_scale,
                           const float* timestep, int B, int F, int H, int W, const ltx_tiling* tiling,
                           int postprocess, float* out, ltx_stream stream);
+/* Only the latent preparation of the call above (unpack is a view; denormalize with latents_mean/std and
+ * scaling_factor, then (1-s)*z + s*noise, t2v_pipeline.rs:1002-1053), for callers that tile the decode themselves
+ * (tile-sharded multi-GPU decode): out_tokens [B, F*H*W, C] f32, same token layout as the input. */
+int ltx_vae_prepare_latents(ltx_vae* v, const float* tokens, const float* noise, const float* noise_scale,
+                            int B, int F, int H, int W, float* out_tokens, ltx_stream stream);
 
 /* ---- pipeline pieces that touch tensors ---- */
 /* noise_pred = guidance(text, uncond?, perturbed?) ; latents += dt * noise_pred   (all f32 math)

@@ -166,6 +166,32 @@ def test_pipeline_trajectory_and_video_fixture(hip, golden):
     assert none is None and torch.equal(lat_only, lat)
 
 
+def test_sharded_pipeline_team_of_one_equals_cabi_pipeline(hip, golden):
+    """ltxhip.sharded (guidance-branch split + VAE tile split) with a single-rank team runs the same kernels
+    in the same order as ltx_pipeline_call: latents bit-identical, tiled video equal up to the postprocess rounding."""
+    from ltxhip import sharded as S
+    g = golden("oracle_pipeline.safetensors")
+    dcfg, vcfg = O.DitConfig(**PIPE_DIT_CFG), O.VaeConfig(**VAE_CFG)
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=12)
+    vwd = {"decoder." + k: v.to(DEV) for k, v in vw.items()}
+    vwd["latents_mean"] = g["latents_mean"].to(DEV); vwd["latents_std"] = g["latents_std"].to(DEV)
+    for mdt in (torch.float32, torch.bfloat16):
+        dit = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**PIPE_DIT_CFG), {k: v.to(DEV) for k, v in dw.items()}, mdt)
+        vae = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**VAE_CFG), vwd, mdt)
+        vae.use_tiling = vae.use_framewise_decoding = True
+        vae.tile_sample_min_height = vae.tile_sample_min_width = 64
+        vae.tile_sample_stride_height = vae.tile_sample_stride_width = 32
+        base = dict(height=64, width=96, num_frames=9, guidance_scale=3.0, guidance_rescale=0.7, stg_scale=1.0, skip_block_list=[1], num_inference_steps=3)
+        inputs = (g["latents"].to(DEV), g["prompt_embeds"].to(DEV), g["prompt_mask"].to(DEV), g["neg_embeds"].to(DEV), g["neg_mask"].to(DEV))
+        lat0, vid0 = hip.LtxPipeline(dit, vae).call(hip.PipelineCall(**base), *inputs, decode_noise=g["decode_noise"].to(DEV))
+        lat1, vid1 = S.ShardedLtxPipeline(dit, vae).call(hip.PipelineCall(**base), *inputs, decode_noise=g["decode_noise"].to(DEV))
+        assert torch.equal(lat0, lat1)
+        assert vid1.shape == vid0.shape and (vid1 - vid0).abs().max() <= 1e-3, (vid1 - vid0).abs().max()
+        lat2, none = S.ShardedLtxPipeline(dit, vae).call(hip.PipelineCall(output_latent=True, **base), *inputs)
+        assert none is None and torch.equal(lat2, lat0)
+
+
 def test_pipeline_rejects_bad_inputs(hip):
     dcfg = O.DitConfig(**PIPE_DIT_CFG)
     dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)

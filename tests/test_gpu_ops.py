@@ -276,3 +276,33 @@ def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
     check(ncthw(hip.ops.upsample3d(cl(xu).cuda(), wu.cuda(), bu.cuda())), O.upsampler(pu, "", xu.float(), 8, False), dt)
     wo, bo = rnd(dt, 48, 24, 3, 3, 3, scale=0.04), rnd(dt, 48, scale=0.1)
     check(hip.ops.conv_out_unpatchify(cl(xc).cuda(), wo.cuda(), bo.cuda()), O.unpatchify(O.causal_conv3d(xc.float(), wo.float(), bo.float(), False), 4, 1), dt)
+
+
+@pytest.mark.gpu
+def test_gemm_plans_are_bit_identical_and_tuner_caches(hip, monkeypatch):
+    """Every GEMM plan (gemm_big tiles, gemm_p8) accumulates K in the same order with the same MFMA, so the plan the
+    dispatcher measures best may change speed only: outputs must be bit-identical across forced plans and the tuned path."""
+    dt = torch.bfloat16
+    M, N, K = 2048, 384, 320
+    x, w, b = rnd(dt, M, K).cuda(), rnd(dt, N, K, scale=K ** -0.5).cuda(), rnd(dt, N, scale=0.1).cuda()
+    xc, wc, bc = cl(rnd(dt, 1, 64, 3, 24, 20)).cuda(), rnd(dt, 128, 64, 3, 3, 3, scale=0.03).cuda(), rnd(dt, 128, scale=0.1).cuda()
+    monkeypatch.setenv("LTX_GEMM_TUNE", "0")
+    base_lin, base_conv = hip.ops.linear(x, w, b, epi=1), hip.ops.conv3d(xc, wc, bc)
+    for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128"]:
+        monkeypatch.setenv("LTX_GEMM_TILE", tile)
+        assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), tile
+        assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), tile
+    monkeypatch.delenv("LTX_GEMM_TILE")
+    for p8 in ["256", "128"]:
+        monkeypatch.setenv("LTX_GEMM_P8", p8)
+        assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), p8
+        assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), p8
+    monkeypatch.delenv("LTX_GEMM_P8")
+    monkeypatch.setenv("LTX_GEMM_TUNE", "1")
+    assert hip.ops.gemm_plan(M, N, K) == ""
+    assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin)
+    plan = hip.ops.gemm_plan(M, N, K)
+    assert plan != ""
+    assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin) and hip.ops.gemm_plan(M, N, K) == plan
+    assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv)
+    assert hip.ops.gemm_plan(3 * 24 * 20, 128, 64, 1, 27, 3, 24, 20) != ""
