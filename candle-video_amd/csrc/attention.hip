@@ -35,8 +35,12 @@ template <int CPR> __device__ __forceinline__ int vswz(int row, int c) {
     else return c;
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bf16_kernel(const AttnArgs a) {
+// PRE: q already carries scale*log2(e) (folded into the q RMSNorm+RoPE kernel, one bf16 rounding of the product), no key bias.
+// The running max (log2 units) then enters the S^T MFMA chain as its INITIAL ACCUMULATOR (a persistent 16-register
+// tuple holding -m, rewritten only when the max moves), so the accumulator comes out as S - m and p = exp2(acc):
+// no per-score multiply/subtract and no per-tile accumulator zeroing.
+template <int HD, bool PRE>
+__global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void attn_bf16_kernel(const AttnArgs a) {
     constexpr int HDP = HD < 32 ? 32 : HD;          // padded head dim for the PV d-blocks
     constexpr int KROW = HD * 2, VROW = HDP * 2;    // bytes per LDS row
     constexpr int KCPR = KROW / 16, VCPR = VROW / 16, VCV = (HD * 2) / 16;  // chunks per row; valid V chunks
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bf16_kernel(con
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o[d][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
+    f32x16 minit;                                   // initial accumulator of the S^T chains: 0, or -m_run (PRE)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) minit[i] = 0.f;
 
     const int nt = (a.Sk + BKV - 1) / BKV;
     gload(0); swrite(0);
@@ -140,27 +147,25 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bf16_kernel(con
         const unsigned char* Vs = Ks + BKV * KROW;
         const int kv0 = t * BKV;
 
-        // ---- S^T = K . Q^T  (two 32-key blocks)
+        // ---- S^T = K . Q^T  (two 32-key blocks); PRE: accumulators start at -m_run
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
             const int row = kb * 32 + r;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * KROW + kswz<KCPR>(row, 2 * ks + h) * 16);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? minit : sacc[kb], 0, 0, 0);
             }
         }
-        if (has_bias || MASKED) {
+        if ((!PRE && has_bias) || MASKED) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     float x = sacc[kb][i];
-                    if (has_bias) x = fmaf(x, sc2, bias[key < a.Sk ? key : a.Sk - 1] * LOG2E);
+                    if (!PRE && has_bias) x = fmaf(x, sc2, bias[key < a.Sk ? key : a.Sk - 1] * LOG2E);
                     if (MASKED && key >= a.Sk) x = -INFINITY;
                     sacc[kb][i] = x;
                 }
@@ -174,27 +179,51 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bf16_kernel(con
             auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
             mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        if (!__all((mt - m_run) * c <= RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
-        }
-        const float mc = -m_run * c;
         float ls = 0.f;
         bf16x8 pf[2][2];
+        if constexpr (PRE) {
+            // mt is the tile max RELATIVE to m_run.  First tile: adopt it unconditionally (m_run was a placeholder 0).
+            if (t == 0 || !__all(mt <= RESCALE_THR)) {
+                const float delta = t == 0 ? mt : fmaxf(mt, 0.f);
+                const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c, mc));
-                ls += p;
-                pf[kb][i >> 3][i & 7] = (bf16_t)p;
+                    for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { minit[i] = -m_run; sacc[0][i] -= delta; sacc[1][i] -= delta; }
             }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(sacc[kb][i]);
+                    ls += p;
+                    pf[kb][i >> 3][i & 7] = (bf16_t)p;
+                }
+        } else {
+            if (!__all((mt - m_run) * c <= RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+            }
+            const float mc = -m_run * c;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c, mc));
+                    ls += p;
+                    pf[kb][i >> 3][i & 7] = (bf16_t)p;
+                }
+        }
         l_run += ls;
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -307,6 +336,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 }  // namespace
 
+bool ltx_attention_prescale_ok(int hd) {
+    const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
+    return hd == 64 && !(e && e[0] == '0');
+}
+
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.Sq <= 0 || a.Sk <= 0 || a.heads <= 0) LTX_FAIL(LTX_ERR_ARG, "attention: empty problem");
     void* tok = nullptr;
@@ -316,11 +350,14 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         if (ltx_attention_pipe_eligible(a, dtype)) return ltx_launch_attention_pipe(a, s);   // long-Sk software-pipelined variant
         dim3 grid((unsigned)cdiv(a.Sq, BQ), (unsigned)a.heads, (unsigned)a.B), block(256);
+        if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 and no key bias");
         switch (a.hd) {
-            case 16: hipLaunchKernelGGL(attn_bf16_kernel<16>, grid, block, 0, s, a); break;
-            case 32: hipLaunchKernelGGL(attn_bf16_kernel<32>, grid, block, 0, s, a); break;
-            case 64: hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, block, 0, s, a); break;
-            case 128: hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, a); break;
+            case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, a); break;
+            case 64: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, a);
+                     else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, a);
+                     break;
+            case 128: hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, a); break;
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
         }
     } else {

@@ -65,6 +65,14 @@ extern "C" int ltx_op_attention(const void* q, const void* k, const void* v, voi
     return ltx_launch_attention(a, dtc(dtype), (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                                          int ldq, int ldk, int ldv, int ldo, ltx_stream stream) {
+    if (!q || !k || !v || !o) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention_prescaled: null tensor");
+    AttnArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.heads = heads; a.hd = hd; a.scale = 1.0f; a.q_prescaled = 1;
+    return ltx_launch_attention(a, LTX_DT_BF16, (hipStream_t)stream);
+}
+
 namespace {
 int conv_common(const void* x, const void* w, const void* bias, int wdtype, void* y, const void* resid,
                 int B, int T, int H, int W, int Cin, int Cout, int causal, int dtype, int epi, int mode, int post, hipStream_t s) {

@@ -300,9 +300,14 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         LTX_TRY(ltx_linear(b.qkv1, m->n.p, D, m->qkv.p, 3 * D, (int)M, dt, EPI_BIAS, s));
         QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = 3 * D; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
         qa.eps = 1e-5f; qa.cos = m->cosb.as<float>(); qa.sin = m->sinb.as<float>();
+        // bf16: q leaves the norm already multiplied by scale*log2(e) (ONE bf16 rounding, of the product), so the
+        // attention kernel's exponent is exp2(S - m) with no per-score multiply
+        const bool fold_q = dt == LTX_DT_BF16 && ltx_attention_prescale_ok(hd);
+        if (fold_q) qa.out_scale0 = attn_scale * 1.4426950408889634f;
         LTX_TRY(ltx_launch_qknorm_rope(qa, dt, s));
         AttnArgs at; at.q = m->qkv.p; at.k = (char*)m->qkv.p + (size_t)D * esz; at.v = (char*)m->qkv.p + (size_t)2 * D * esz; at.o = m->attn.p;
         at.ldq = at.ldk = at.ldv = 3 * D; at.ldo = D; at.B = B; at.Sq = S; at.Sk = S; at.heads = H; at.hd = hd; at.scale = attn_scale;
+        at.q_prescaled = fold_q ? 1 : 0;
         LTX_TRY(ltx_launch_attention(at, dt, s));
         // h = h + gate_msa * to_out(attn)     (gate_msa = row 2)
         LTX_TRY(ltx_linear(b.o1, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 2 * D, 6 * D, S));

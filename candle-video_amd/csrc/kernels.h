@@ -61,6 +61,7 @@ struct QkNormRopeArgs {
     const void* w0 = nullptr; const void* w1 = nullptr;   // T [D]
     float eps = 1e-5f;
     const float* cos = nullptr; const float* sin = nullptr;  // f32 [rows, D/2] or null (no RoPE)
+    float out_scale0 = 1.f;       // extra factor on segment 0's output (q): lets attention fold scale*log2(e) into Q
 };
 int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s);
 
@@ -81,8 +82,10 @@ struct AttnArgs {
     int B = 1, Sq = 0, Sk = 0, heads = 0, hd = 0;
     float scale = 1.f;
     const float* bias = nullptr;                  // f32 [B, Sk] additive key bias or null
+    int q_prescaled = 0;                          // bf16, no bias: q already carries scale*log2(e) (qknorm_rope out_scale0)
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 // software-pipelined bf16 variant for long key sequences (attention_pipe.hip); ltx_launch_attention dispatches to it
 bool ltx_attention_pipe_eligible(const AttnArgs& a, int dtype);
 int ltx_launch_attention_pipe(const AttnArgs& a, hipStream_t s);

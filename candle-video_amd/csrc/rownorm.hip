@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
     for (int seg = 0; seg < a.nseg; ++seg) {
         T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * a.D;
         const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+        const float oscale = seg == 0 ? a.out_scale0 : 1.0f;
         if constexpr (CACHED) {
             Chunk16 v[NSLOT];
 #pragma unroll
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
 #pragma unroll
                 for (int j = 0; j < CH; ++j) ss += f[j] * f[j]; }
             ss = group_sum(ss, lpr);
-            const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+            const float rinv = oscale / sqrtf(ss / (float)a.D + a.eps);
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) { int c = sub + i * lpr; if (c < nch) finish(v[i], c, rinv, w, x); }
         } else {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
                 for (int i = 0; i < CH; ++i) ss += f[i] * f[i];
             }
             ss = group_sum(ss, lpr);
-            const float rinv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+            const float rinv = oscale / sqrtf(ss / (float)a.D + a.eps);
             for (int c = sub; c < nch; c += lpr) { Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH); finish(v, c, rinv, w, x); }
         }
     }

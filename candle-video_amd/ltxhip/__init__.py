@@ -106,6 +106,7 @@ _SIGS = {
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
     "ltx_op_rope_table": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ltx_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "ltx_op_attention_prescaled": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_conv3d": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_upsample3d": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -573,6 +574,15 @@ class ops:
         o = torch.empty_like(q)
         _check(lib.ltx_op_attention(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, Sk, heads, D // heads,
                                     D, D, D, D, C.c_float(scale), _ptr(key_bias), _dt(q.dtype), _stream()))
+        return o
+
+    @staticmethod
+    def attention_prescaled(q, k, v, heads):
+        """bf16, head_dim 64: q already multiplied by scale*log2(e); softmax in base 2 (DiT self-attention fast path)."""
+        B, Sq, D = q.shape
+        o = torch.empty_like(q)
+        _check(lib.ltx_op_attention_prescaled(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, k.shape[1],
+                                              heads, D // heads, D, D, D, D, _stream()))
         return o
 
     @staticmethod

@@ -30,7 +30,9 @@ if "conv" in which:
         cases.append((name, 54 * C * C * T * H * W, (lambda x=x, w=w, b=b: ltxhip.ops.conv3d(x, w, b))))
 if "attn" in which:
     q, k, v = [torch.randn(1, S, 2048, device=dev).bfloat16() for _ in range(3)]
-    cases.append(("attn_self", 4 * 32 * S * S * 64, (lambda: ltxhip.ops.attention(q, k, v, 32, 0.125))))
+    cases.append(("attn_self", 4 * 32 * S * S * 64, (lambda q=q, k=k, v=v: ltxhip.ops.attention(q, k, v, 32, 0.125))))
+    qp = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
+    cases.append(("attn_self_prescaled", 4 * 32 * S * S * 64, (lambda qp=qp, k=k, v=v: ltxhip.ops.attention_prescaled(qp, k, v, 32))))
 res = {c[0]: {v: [] for v in vals} for c in cases}
 for rnd in range(3):
     for name, fl, fn in cases:
