@@ -52,8 +52,18 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * BQ + wave * 32;
+    // 1-D grid.  Blocks L and L+8 share an XCD (one L2): with heads % 8 == 0 every XCD is given WHOLE heads
+    // (head = xcd + 8*(j / nqb)), so the K/V of a head (2 x Sk x hd bf16, 1.3 MB at 4992 x 64) is re-read by its
+    // query blocks from that XCD's L2 instead of from the Infinity Cache by all eight.
+    int head, b, qb;
+    {
+        const int nqb = (a.Sq + BQ - 1) / BQ, per_b = nqb * a.heads;
+        int L = blockIdx.x;
+        b = L / per_b; L -= b * per_b;
+        if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / nqb); qb = j % nqb; }
+        else { head = L / nqb; qb = L - head * nqb; }
+    }
+    const int q0 = qb * BQ + wave * 32;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
@@ -349,15 +359,18 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     if (dtype == LTX_DT_BF16) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         if (ltx_attention_pipe_eligible(a, dtype)) return ltx_launch_attention_pipe(a, s);   // long-Sk software-pipelined variant
-        dim3 grid((unsigned)cdiv(a.Sq, BQ), (unsigned)a.heads, (unsigned)a.B), block(256);
+        dim3 grid((unsigned)(cdiv(a.Sq, BQ) * a.heads * a.B)), block(256);
+        AttnArgs ax = a;
+        const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)
+        ax.xcd_heads = (a.heads % 8 == 0 && !(xe && xe[0] == '0')) ? 1 : 0;
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 and no key bias");
         switch (a.hd) {
-            case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, a); break;
-            case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, a); break;
-            case 64: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, a);
-                     else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, a);
+            case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
+            case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;
+            case 64: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
+                     else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);
                      break;
-            case 128: hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, ax); break;
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
         }
     } else {

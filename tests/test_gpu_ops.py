@@ -131,7 +131,8 @@ def ref_attention(q, k, v, heads, scale, bias):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("hd,heads,Sq,Sk,B,biased", [(64, 2, 384, 384, 1, False), (64, 3, 200, 128, 2, True), (16, 4, 256, 10, 1, False),
-                                                     (32, 2, 130, 70, 1, True), (128, 2, 160, 192, 1, False), (16, 2, 2048, 2048, 1, False)])
+                                                     (32, 2, 130, 70, 1, True), (128, 2, 160, 192, 1, False), (16, 2, 2048, 2048, 1, False),
+                                                     (64, 8, 300, 300, 2, False), (16, 16, 130, 200, 1, True)])
 def test_attention(hip, dt, hd, heads, Sq, Sk, B, biased):
     D = hd * heads
     q, k, v = rnd(dt, B, Sq, D), rnd(dt, B, Sk, D, seed=1), rnd(dt, B, Sk, D, seed=2)
