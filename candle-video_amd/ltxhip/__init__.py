@@ -112,16 +112,31 @@ _SIGS = {
     "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_gemm_plan": [_i, _i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
+    # include/ltxhip_weights.h
+    "ltx_weights_detect_format": [C.c_char_p], "ltx_weights_remap_key": [C.c_char_p, C.c_char_p, _sz],
+    "ltx_weights_is_transformer_key": [C.c_char_p], "ltx_weights_is_vae_key": [C.c_char_p],
+    "ltx_name_mapper_create": [], "ltx_name_mapper_destroy": [_vp], "ltx_name_mapper_add": [_vp, _i, C.c_char_p, C.c_char_p],
+    "ltx_name_mapper_has_mapping": [_vp, C.c_char_p], "ltx_name_mapper_map": [_vp, C.c_char_p, C.c_char_p, _sz],
+    "ltx_weights_validate_names": [_vp, _sz, _vp, _sz, _vp, _vp],
+    "ltx_safetensors_open": [C.c_char_p, _vp], "ltx_safetensors_close": [_vp], "ltx_safetensors_count": [_vp],
+    "ltx_safetensors_tensor": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ltx_weights_resolve": [C.c_char_p, C.c_char_p, _sz, _vp],
+    "ltx_dit_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp], "ltx_vae_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
 for _name, _sig in _SIGS.items():
     _fn = getattr(lib, _name)          # raises AttributeError if the library lacks a declared symbol
     _fn.argtypes = _sig
-    if _name not in ("ltx_calculate_shift", "ltx_vae_latents_mean", "ltx_vae_latents_std"):
+    if _name not in ("ltx_calculate_shift", "ltx_vae_latents_mean", "ltx_vae_latents_std", "ltx_name_mapper_create",
+                     "ltx_name_mapper_destroy", "ltx_safetensors_close", "ltx_safetensors_count"):
         _fn.restype = C.c_int
 lib.ltx_calculate_shift.restype = C.c_float
 lib.ltx_vae_latents_mean.restype = C.c_void_p
 lib.ltx_vae_latents_std.restype = C.c_void_p
+lib.ltx_name_mapper_create.restype = C.c_void_p
+lib.ltx_name_mapper_destroy.restype = None
+lib.ltx_safetensors_close.restype = None
+lib.ltx_safetensors_count.restype = C.c_size_t
 
 
 def _dt(t: torch.dtype) -> int:
@@ -208,6 +223,20 @@ class LtxVideoTransformer3DModel:
             lib.ltx_dit_destroy(h)
             self._h = None
 
+    @classmethod
+    def from_files(cls, config: "LtxVideoTransformer3DModelConfig", path: str, unified: bool = False,
+                   dtype: torch.dtype = torch.bfloat16, device: int = 0) -> "LtxVideoTransformer3DModel":
+        """Build from a checkpoint on disk (ltx_dit_create_from_files): `unified` = Official single-file checkpoint
+        (keys remapped/split as examples/ltx-video/main.rs:461-499), else the transformer's own file or directory."""
+        self = cls.__new__(cls)
+        self.config, self.dtype = config, dtype
+        c = DitConfigC(config.in_channels, config.out_channels, config.patch_size, config.patch_size_t,
+                       config.num_attention_heads, config.attention_head_dim, config.cross_attention_dim,
+                       config.num_layers, config.norm_eps, config.caption_channels)
+        self._h = C.c_void_p()
+        _check(lib.ltx_dit_create_from_files(C.byref(c), path.encode(), int(unified), _dt(dtype), device, C.byref(self._h)))
+        return self
+
     def context_cache(self, enable: bool):
         """keep the text-side projections (caption projection, cross-attention K/V) of repeated forwards with the same
         embeddings/mask pointers; LtxPipeline::call scopes it to one denoise loop."""
@@ -264,10 +293,8 @@ class AutoencoderKLLtxVideoConfig:               # vae.rs:32-103 (decoder side)
 class AutoencoderKLLtxVideo:
     """impl VaeLtxVideo (t2v_pipeline.rs:91-103) over ltx_vae_*; tiling fields as vae.rs:1744-1758."""
 
-    def __init__(self, config: AutoencoderKLLtxVideoConfig, weights: Dict[str, torch.Tensor],
-                 dtype: torch.dtype = torch.bfloat16, device: int = 0):
-        self.config = config
-        self.dtype = dtype
+    @staticmethod
+    def _config_c(config: "AutoencoderKLLtxVideoConfig") -> "VaeConfigC":
         c = VaeConfigC()
         c.latent_channels, c.out_channels = config.latent_channels, config.out_channels
         nb = len(config.decoder_block_out_channels)
@@ -283,10 +310,9 @@ class AutoencoderKLLtxVideo:
         c.scaling_factor = config.scaling_factor
         c.spatial_compression_ratio = config.spatial_compression_ratio
         c.temporal_compression_ratio = config.temporal_compression_ratio
-        arr, keep = _make_weights(weights)
-        self._h = C.c_void_p()
-        _check(lib.ltx_vae_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
-        del keep
+        return c
+
+    def _tiling_defaults(self):
         # defaults of examples/ltx-video/main.rs:514-516 (tiling off unless asked)
         self.use_tiling = False
         self.use_framewise_decoding = False
@@ -296,6 +322,29 @@ class AutoencoderKLLtxVideo:
         self.tile_sample_stride_height = 384
         self.tile_sample_stride_width = 384
         self.tile_sample_stride_num_frames = 8
+
+    def __init__(self, config: AutoencoderKLLtxVideoConfig, weights: Dict[str, torch.Tensor],
+                 dtype: torch.dtype = torch.bfloat16, device: int = 0):
+        self.config = config
+        self.dtype = dtype
+        c = self._config_c(config)
+        arr, keep = _make_weights(weights)
+        self._h = C.c_void_p()
+        _check(lib.ltx_vae_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
+        del keep
+        self._tiling_defaults()
+
+    @classmethod
+    def from_files(cls, config: "AutoencoderKLLtxVideoConfig", path: str, unified: bool = False,
+                   dtype: torch.dtype = torch.bfloat16, device: int = 0) -> "AutoencoderKLLtxVideo":
+        """Build from a checkpoint on disk (ltx_vae_create_from_files); see LtxVideoTransformer3DModel.from_files."""
+        self = cls.__new__(cls)
+        self.config, self.dtype = config, dtype
+        c = cls._config_c(config)
+        self._h = C.c_void_p()
+        _check(lib.ltx_vae_create_from_files(C.byref(c), path.encode(), int(unified), _dt(dtype), device, C.byref(self._h)))
+        self._tiling_defaults()
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -1,0 +1,72 @@
+/* ltxhip_weights.h — weight ingestion for the LTX-Video path: everything between a checkpoint on
+ * disk and `ltx_dit_create` / `ltx_vae_create`.  Host-side string/IO logic restating
+ *     src/models/ltx_video/weight_format.rs   (format detection, Official -> Diffusers key remapping)
+ *     src/models/ltx_video/loader.rs          (name-mapping rules, safetensors index, directory resolution)
+ *     examples/ltx-video/main.rs:455-546      (splitting a unified checkpoint into VAE and transformer tensors)
+ * Tensor payloads are never copied on the host: a safetensors file is mmap'ed and `ltx_weight.data` points into the map;
+ * the model constructors upload + cast on the device (bf16 or f32 sources).
+ */
+#ifndef LTXHIP_WEIGHTS_H
+#define LTXHIP_WEIGHTS_H
+#include "ltxhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* WeightFormat / detect_format (weight_format.rs:13-29): a regular file is the Official single-file checkpoint (1);
+ * a directory — or a path that does not exist — is the Diffusers layout (0). */
+int ltx_weights_detect_format(const char* path);
+
+/* KeyRemapper::remap_key (weight_format.rs:55-83, block-index tables :96-141): Official (native) -> Diffusers name.
+ * Writes the NUL-terminated result into out[cap]; fails with LTX_ERR_ARG if it does not fit. */
+int ltx_weights_remap_key(const char* key, char* out, size_t cap);
+/* KeyRemapper::is_transformer_key / is_vae_key (weight_format.rs:144-163): 1 / 0. */
+int ltx_weights_is_transformer_key(const char* key);
+int ltx_weights_is_vae_key(const char* key);
+
+/* WeightLoader name mapping (loader.rs:63-112, 223-317): ordered exact / prefix / suffix rules; every rule that
+ * matches rewrites the name and its result feeds the next rule. */
+typedef struct ltx_name_mapper ltx_name_mapper;
+typedef enum { LTX_MAP_EXACT = 0, LTX_MAP_PREFIX = 1, LTX_MAP_SUFFIX = 2 } ltx_map_kind;
+ltx_name_mapper* ltx_name_mapper_create(void);
+void ltx_name_mapper_destroy(ltx_name_mapper* m);
+int ltx_name_mapper_add(ltx_name_mapper* m, ltx_map_kind kind, const char* from, const char* to);
+int ltx_name_mapper_has_mapping(const ltx_name_mapper* m, const char* name);              /* loader.rs:296-300 */
+int ltx_name_mapper_map(const ltx_name_mapper* m, const char* name, char* out, size_t cap);   /* loader.rs:306-316 */
+
+/* validate_tensor_names (loader.rs:495-505): writes the indices of `expected` names absent from `actual` into
+ * missing_idx[n_expected] (in order) and their count into *n_missing. */
+int ltx_weights_validate_names(const char* const* expected, size_t n_expected, const char* const* actual, size_t n_actual,
+                               size_t* missing_idx, size_t* n_missing);
+
+/* One mmap'ed safetensors file (8-byte LE header length, JSON header, raw little-endian payload). */
+typedef struct ltx_safetensors ltx_safetensors;
+int ltx_safetensors_open(const char* path, ltx_safetensors** out);
+void ltx_safetensors_close(ltx_safetensors* st);
+size_t ltx_safetensors_count(const ltx_safetensors* st);
+/* i-th tensor in file (header) order.  dtype_name is the safetensors dtype string ("F32", "BF16", "F16", ...);
+ * data points into the mapping and stays valid until close. */
+int ltx_safetensors_tensor(const ltx_safetensors* st, size_t i, const char** name, const char** dtype_name,
+                           int* ndim, const int64_t** shape, const void** data, size_t* nbytes);
+
+/* WeightLoader::load_from_directory's file resolution (loader.rs:341-397, 437-456) — or a single file path as is:
+ *   dir/model.safetensors.index.json -> its distinct shard files (all must exist), else dir/model.safetensors,
+ *   else every *.safetensors in dir (sorted).  Writes up to cap NUL-separated absolute-or-relative paths into
+ *   out (double-NUL terminated) and their count into *n_files. */
+int ltx_weights_resolve(const char* path, char* out, size_t cap, size_t* n_files);
+
+/* Build the models straight from checkpoint files.
+ *   unified != 0 : `path` is an Official single-file checkpoint; keys are remapped and split exactly as
+ *                  main.rs:461-499 does ("vae." / "model.diffusion_model." / "transformer." prefixes stripped);
+ *   unified == 0 : `path` is the component's own safetensors file or directory (Diffusers layout), tensor names taken
+ *                  as they are (WeightLoader::load_single / load_from_directory).
+ * F32 and BF16 payloads are accepted (anything else: LTX_ERR_UNSUPPORTED naming the tensor). */
+int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* path, int unified,
+                              ltx_dtype model_dtype, int device, ltx_dit** out);
+int ltx_vae_create_from_files(const ltx_vae_config* cfg, const char* path, int unified,
+                              ltx_dtype model_dtype, int device, ltx_vae** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -192,6 +192,49 @@ def test_sharded_pipeline_team_of_one_equals_cabi_pipeline(hip, golden):
         assert none is None and torch.equal(lat2, lat0)
 
 
+def test_models_built_from_checkpoint_files_equal_dict_built_models(hip, tmp_path):
+    """Weight ingestion (include/ltxhip_weights.h): an Official-layout unified safetensors file (native names, bf16 + f32
+    payloads, one foreign tensor) and a Diffusers-layout directory (sharded with index.json) must build the same models as
+    the in-memory weight dicts: forwards are bit-identical."""
+    import json
+    from safetensors.torch import save_file
+    from tools_cfg import to_official_names
+    dcfg, vcfg = O.DitConfig(**PIPE_DIT_CFG), O.VaeConfig(**VAE_CFG)
+    dw = {k: v.bfloat16() if v.dim() > 1 else v for k, v in O.synth_weights(O.dit_weight_shapes(dcfg), seed=11).items()}
+    vw = {"decoder." + k: (v.bfloat16() if v.dim() > 1 else v) for k, v in O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=12).items()}
+    vw["latents_mean"] = torch.linspace(-0.5, 0.5, vcfg.latent_channels); vw["latents_std"] = torch.linspace(0.5, 1.5, vcfg.latent_channels)
+    off = to_official_names(list(dw), list(vw))
+    unified = {ok: (dw[n] if comp == "dit" else vw[n]).contiguous() for ok, (comp, n) in off.items()}
+    unified["text_encoder.shared.weight"] = torch.zeros(4, 4, dtype=torch.float16)          # ignored: neither component
+    ufile = str(tmp_path / "ltx-video-unified.safetensors")
+    save_file(unified, ufile)
+    ddir = tmp_path / "transformer"; ddir.mkdir()
+    names = sorted(dw)
+    half = len(names) // 2
+    save_file({k: dw[k].contiguous() for k in names[:half]}, str(ddir / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: dw[k].contiguous() for k in names[half:]}, str(ddir / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    (ddir / "model.safetensors.index.json").write_text(json.dumps({"weight_map": {
+        k: ("diffusion_pytorch_model-00001-of-00002.safetensors" if i < half else "diffusion_pytorch_model-00002-of-00002.safetensors") for i, k in enumerate(names)}}))
+    tcfg, acfg = hip.LtxVideoTransformer3DModelConfig(**PIPE_DIT_CFG), hip.AutoencoderKLLtxVideoConfig(**VAE_CFG)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 12, 8, generator=g).to(DEV); pe = torch.randn(1, 6, 32, generator=g).to(DEV); pm = torch.ones(1, 6, device=DEV)
+    z = torch.randn(1, 8, 2, 2, 3, generator=g).to(DEV)
+    for mdt in (torch.bfloat16, torch.float32):
+        ref_dit = hip.LtxVideoTransformer3DModel(tcfg, {k: v.to(DEV) for k, v in dw.items()}, mdt)
+        want = ref_dit.forward(lat, pe, [500.0], pm, 2, 2, 3)
+        for m in (hip.LtxVideoTransformer3DModel.from_files(tcfg, ufile, unified=True, dtype=mdt),
+                  hip.LtxVideoTransformer3DModel.from_files(tcfg, str(ddir), unified=False, dtype=mdt)):
+            assert torch.equal(m.forward(lat, pe, [500.0], pm, 2, 2, 3), want)
+        ref_vae = hip.AutoencoderKLLtxVideo(acfg, {k: v.to(DEV) for k, v in vw.items()}, mdt)
+        v2 = hip.AutoencoderKLLtxVideo.from_files(acfg, ufile, unified=True, dtype=mdt)
+        assert torch.equal(v2.decode(z, [0.05]), ref_vae.decode(z, [0.05]))
+        assert torch.equal(v2.latents_mean().cpu(), vw["latents_mean"])
+    bad = dict(unified); bad.pop("model.diffusion_model.patchify_proj.weight")
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(hip.LtxError, match="missing weight 'proj_in.weight'"):
+        hip.LtxVideoTransformer3DModel.from_files(tcfg, str(tmp_path / "bad.safetensors"), unified=True)
+
+
 def test_pipeline_rejects_bad_inputs(hip):
     dcfg = O.DitConfig(**PIPE_DIT_CFG)
     dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)
