@@ -134,6 +134,23 @@ def job_fps(world, steps, frames, elapsed):
     return world * steps * frames / elapsed
 
 
+def pmc_traffic_bytes(cls):
+    """Per-launch memory-side traffic of a kernel class from the newest committed rocprofv3 --pmc summary under profiles/
+    (separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH doubled on gfx950: MI355X_MICROARCH.md HBM section).
+    bench.py cannot run the profiler on itself; None when no summary is present."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernel_stats.json"))):
+        try:
+            d = json.load(open(f))
+            fe, wr = d["pmc"]["FETCH_SIZE"][cls], d["pmc"]["WRITE_SIZE"][cls]
+            key = "per_launch_MB_raw" if "per_launch_MB_raw" in fe else "per_launch_MB"
+            best = ((2.0 * fe[key] + wr[key]) * 1e6, os.path.basename(f))
+        except Exception:
+            continue
+    return best if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,8 +245,10 @@ def main():
             ltxhip.prof_enable(False)
             dom = max((n for n in per if "rownorm" not in n), key=lambda n: per[n]["ms_total"])
             ach = per[dom]["TFLOP/s"]
+            traffic, tsrc = pmc_traffic_bytes("conv3d implicit GEMM" if "conv" in dom else "linear GEMM")
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": per[dom]["avg_ms"],
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: HBM + Infinity Cache)",
+                               "traffic_source": tsrc, "avg_launch_ms": per[dom]["avg_ms"],
                                "launches_per_video": per[dom]["launches"]}
             out["kernels"] = per
             Fh, Hh, Wh = F, H, W

@@ -1,64 +1,98 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSVs (kernel stats + optional PMC passes) into a small tracked summary under profiles/.
-usage: summarize_prof.py <stats_dir> <out_prefix> [--pmc FETCH_SIZE=<dir> --pmc WRITE_SIZE=<dir>] [--videos N]"""
+"""Condense rocprofv3 CSVs (kernel trace + optional PMC passes) into a small tracked summary under profiles/.
+
+Only the LAST video period of the profiled run is summarised: periods are delimited by the denorm_mix launch that opens a
+VAE decode (decode of video n-1 + denoise loop of video n = one video's worth of launches), so warm-up work (first-call
+GEMM plan measurement, workspace allocation) never enters the numbers.
+
+usage: summarize_prof.py <stats_dir> <out_prefix> [--pmc FETCH_SIZE=<dir> --pmc WRITE_SIZE=<dir>]"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
+
+DELIM = re.compile(r"denorm_mix_kernel")      # launched once per video (start of the VAE decode): one period = one video
 
 
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)([a-z_0-9]+?)I(.*)E+v", n)
-    if n.startswith("_ZN12_GLOBAL__N_1"):
-        m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9A-Z]+?)I(.*?)EEv", n)
-        if m:
-            return f"{m.group(1)}<{m.group(2)}>"
-    return n[:90]
+    n = re.sub(r"^void ", "", n)
+    return n[:100]
+
+
+def targs(n):
+    m = re.search(r"<(.*)>\(", n)
+    return [a.strip() for a in m.group(1).split(",")] if m else []
 
 
 def classify(n):
-    if "gemm_big_kernel" in n or "gemm_kernel" in n:
-        conv = "Lb1" in n or ", true>" in n
-        return "conv3d implicit GEMM" if conv else "linear GEMM"
-    for k in ("attn_bf16", "attn_f32", "rownorm", "qknorm_rope", "cast_kernel", "pack_conv", "guidance", "denorm", "rope_table"):
+    a = targs(n)
+    if "gemm_big_kernel" in n:
+        return "conv3d implicit GEMM" if len(a) > 5 and a[5] == "true" else "linear GEMM"
+    if "gemm_p8_kernel" in n:
+        return "conv3d implicit GEMM" if len(a) > 4 and a[4] == "true" else "linear GEMM"
+    if "gemm_kernel" in n:
+        # rocprofv3 cannot demangle the bf16 template argument of this kernel: "..., ELb1E>" is the CONV=true form
+        return "conv3d implicit GEMM" if "Lb1" in n else "linear GEMM"
+    if "attn_bf16_kernel" in n:
+        return "attention (self, q-prescaled)" if len(a) > 1 and a[1] == "true" else "attention (cross / generic)"
+    for k in ("attn_f32", "rownorm", "qknorm_rope", "cast_kernel", "pack_conv", "guidance", "denorm", "rope_table"):
         if k in n:
             return k
     return "other (torch RNG/fill for synthetic inputs, misc)"
 
 
+def last_video(rows, name_key):
+    idx = [i for i, r in enumerate(rows) if DELIM.search(r[name_key])]
+    if len(idx) >= 2:
+        return rows[idx[-2] + 1: idx[-1] + 1], True
+    return rows, False
+
+
 def main():
     stats_dir, out = sys.argv[1], sys.argv[2]
-    pmc = {}; videos = 3
+    pmc = {}
     a = sys.argv[3:]
     for i, x in enumerate(a):
-        if x == "--pmc": k, d = a[i + 1].split("="); pmc[k] = d
-        if x == "--videos": videos = int(a[i + 1])
-    f = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
-    rows = list(csv.DictReader(open(f)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    cls = defaultdict(lambda: [0.0, 0])
+        if x == "--pmc":
+            k, d = a[i + 1].split("="); pmc[k] = d
+    f = glob.glob(os.path.join(stats_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    win, ok = last_video(rows, "Kernel_Name")
+    per = defaultdict(lambda: [0.0, 0]); cls = defaultdict(lambda: [0.0, 0])
+    for r in win:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        per[r["Kernel_Name"]][0] += d; per[r["Kernel_Name"]][1] += 1
+        c = classify(r["Kernel_Name"]); cls[c][0] += d; cls[c][1] += 1
+    tot = sum(v[0] for v in per.values())
+    span = int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])
     lines = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-    for r in rows[:24]:
-        lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
-    for r in rows:
-        c = classify(r["Name"]); cls[c][0] += float(r["TotalDurationNs"]); cls[c][1] += int(r["Calls"])
-    summary = {"total_gpu_ms": tot / 1e6, "videos": videos, "gpu_ms_per_video": tot / 1e6 / videos,
-               "classes": {k: {"ms_per_video": v[0] / 1e6 / videos, "launches_per_video": v[1] / videos, "avg_us": v[0] / 1e3 / max(v[1], 1)} for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}}
+    for n, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:28]:
+        lines.append(f"| `{short(n)}` | {c} | {t/1e6:.2f} | {t/1e3/c:.1f} | {100*t/tot:.1f} |")
+    summary = {"window": "last video period of the run" if ok else "whole run (no video delimiter found)", "kernel_busy_ms": tot / 1e6, "wall_span_ms": span / 1e6,
+               "launches": len(win),
+               "classes": {k: {"ms_per_video": v[0] / 1e6, "launches_per_video": v[1], "avg_us": v[0] / 1e3 / max(v[1], 1)} for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}}
     for name, d in pmc.items():
         fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not fs:
             continue
+        prow = [r for r in csv.DictReader(open(fs[0])) if r.get("Counter_Name") == name]
+        prow.sort(key=lambda r: int(r["Dispatch_Id"]))
+        pwin, _ = last_video(prow, "Kernel_Name")
         acc = defaultdict(lambda: [0.0, 0])
-        for r in csv.DictReader(open(fs[0])):
-            if r.get("Counter_Name") != name:
-                continue
+        for r in pwin:
             c = classify(r["Kernel_Name"]); acc[c][0] += float(r["Counter_Value"]); acc[c][1] += 1
-        # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B? (derived: *_sum*64/1024) -> bytes = value*1024
-        summary.setdefault("pmc", {})[name] = {k: {"per_launch_MB": v[0] * 1024 / max(v[1], 1) / 1e6, "launches": v[1]} for k, v in acc.items()}
+        # FETCH_SIZE / WRITE_SIZE are reported in KiB (MI355X_MICROARCH.md, HBM/rocprofv3 section); gfx950: double FETCH_SIZE
+        summary.setdefault("pmc", {})[name] = {k: {"per_launch_MB_raw": v[0] * 1024 / max(v[1], 1) / 1e6, "launches": v[1]} for k, v in acc.items()}
     open(out + ".json", "w").write(json.dumps(summary, indent=1))
-    open(out + ".md", "w").write(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(out)})\n\nGPU time {tot/1e6:.1f} ms over {videos} videos "
-                                 f"({tot/1e6/videos:.1f} ms/video)\n\n" + "\n".join(lines) + "\n\n## by class (per video)\n\n" +
-                                 "\n".join(f"- {k}: {v['ms_per_video']:.2f} ms, {v['launches_per_video']:.0f} launches, avg {v['avg_us']:.1f} us" for k, v in summary["classes"].items()) + "\n")
-    print(open(out + ".md").read())
+    md = (f"# rocprofv3 --kernel-trace summary ({os.path.basename(out)}) — {summary['window']}\n\n"
+          f"kernel busy time {tot/1e6:.1f} ms over a wall span of {span/1e6:.1f} ms, {len(win)} launches\n\n" + "\n".join(lines) +
+          "\n\n## by class (per video)\n\n" +
+          "\n".join(f"- {k}: {v['ms_per_video']:.2f} ms, {v['launches_per_video']} launches, avg {v['avg_us']:.1f} us" for k, v in summary["classes"].items()) + "\n")
+    if "pmc" in summary:
+        md += "\n## PMC (raw counter value x 1024 B, per launch; FETCH_SIZE must be doubled on gfx950)\n\n"
+        for name, d in summary["pmc"].items():
+            md += f"### {name}\n\n" + "\n".join(f"- {k}: {v['per_launch_MB_raw']:.1f} MB/launch over {v['launches']} launches" for k, v in sorted(d.items(), key=lambda kv: -kv[1]['per_launch_MB_raw'])) + "\n\n"
+    open(out + ".md", "w").write(md)
+    print(md)
 
 
 if __name__ == "__main__":
