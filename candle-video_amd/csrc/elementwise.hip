@@ -95,7 +95,14 @@ __global__ void guidance_apply_kernel(GuidanceArgs a) {
         }
         if (a.pert) c = c + (t - ldd(a.pert, a.pred_dtype, i)) * a.stg_scale;
         if (a.noise_out) a.noise_out[i] = c;
-        if (a.latents) a.latents[i] = a.latents[i] + c * a.dt;
+        if (a.latents) {
+            if (a.step_noise) {
+                const float x0 = a.latents[i] - a.sigma * c;
+                a.latents[i] = (1.0f - a.sigma_next) * x0 + a.sigma_next * a.step_noise[i];
+            } else {
+                a.latents[i] = a.latents[i] + c * a.dt;
+            }
+        }
     }
 }
 

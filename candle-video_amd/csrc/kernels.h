@@ -111,6 +111,9 @@ struct GuidanceArgs {
     int B = 1; int64_t n_per_batch = 0;
     float guidance_scale = 1.f, guidance_rescale = 0.f, stg_scale = 0.f, dt = 0.f;
     double* stats = nullptr;       // workspace [B][4] doubles (sum_t, sumsq_t, sum_c, sumsq_c)
+    // stochastic sampling (scheduler.rs:557-575): x = (1 - sigma_next) * (x - sigma * v) + sigma_next * noise
+    const float* step_noise = nullptr;   // f32 [B, n_per_batch] or null (= deterministic Euler with dt)
+    float sigma = 0.f, sigma_next = 0.f;
 };
 int ltx_launch_guidance_step(const GuidanceArgs& a, hipStream_t s);
 

@@ -111,6 +111,21 @@ extern "C" int ltx_guidance_step(const void* text, const void* uncond, const voi
     return ltx_launch_guidance_step(a, (hipStream_t)stream);
 }
 
+extern "C" int ltx_guidance_step_stochastic(const void* text, const void* uncond, const void* perturbed, ltx_dtype pred_dtype,
+                                            float* latents, float* noise_pred_out, int B, int64_t n,
+                                            float guidance_scale, float guidance_rescale, float stg_scale,
+                                            float sigma, float sigma_next, const float* step_noise,
+                                            void* stats_ws, ltx_stream stream) {
+    if (!step_noise || !latents) LTX_FAIL(LTX_ERR_ARG, "ltx_guidance_step_stochastic: latents and step_noise are required");
+    GuidanceArgs a;
+    a.text = text; a.uncond = uncond; a.pert = perturbed; a.pred_dtype = pred_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32;
+    a.latents = latents; a.noise_out = noise_pred_out; a.B = B; a.n_per_batch = n;
+    a.guidance_scale = guidance_scale; a.guidance_rescale = guidance_rescale; a.stg_scale = stg_scale;
+    a.sigma = sigma; a.sigma_next = sigma_next; a.step_noise = step_noise;
+    a.stats = reinterpret_cast<double*>(stats_ws);
+    return ltx_launch_guidance_step(a, (hipStream_t)stream);
+}
+
 // ---- LtxPipeline::call ----
 static thread_local float g_timing[4] = {0, 0, 0, 0};
 extern "C" int ltx_pipeline_last_timing(float ms[4]) {
@@ -145,6 +160,7 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     if (p->num_inference_steps < 1) LTX_FAIL(LTX_ERR_ARG, "num_inference_steps must be >= 1");
     const bool do_cfg = p->guidance_scale > 1.0f, do_stg = p->stg_scale > 0.0f;      // :304-310
     if (do_cfg && (!neg_embeds || !neg_mask)) LTX_FAIL(LTX_ERR_ARG, "classifier-free guidance needs negative embeddings and mask");
+    if (p->stochastic_sampling && !p->step_noise) LTX_FAIL(LTX_ERR_ARG, "stochastic_sampling needs step_noise [steps,B,S*C]");
     hipStream_t s = (hipStream_t)stream;
     ltx_dit_config dc; LTX_TRY(ltx_dit_get_config(dit, &dc));
     int ts_ratio = 8, sp_ratio = 32;
@@ -205,8 +221,13 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
         HIP_TRY(hipEventRecord(e1, s));
         // guidance mix (:941-962) + scheduler.step (:987; scheduler.rs:544-581): dt = sigma_next - sigma
         const float dts = sig[i + 1] - sig[i];
-        LTX_TRY(ltx_guidance_step(sc.p_text, do_cfg ? sc.p_uncond : nullptr, do_stg ? sc.p_pert : nullptr, LTX_F32, latents, nullptr, B, n,
-                                  p->guidance_scale, p->guidance_rescale, p->stg_scale, dts, sc.stats, s));
+        if (p->stochastic_sampling)
+            LTX_TRY(ltx_guidance_step_stochastic(sc.p_text, do_cfg ? sc.p_uncond : nullptr, do_stg ? sc.p_pert : nullptr, LTX_F32, latents, nullptr, B, n,
+                                                 p->guidance_scale, p->guidance_rescale, p->stg_scale, sig[i], sig[i + 1],
+                                                 p->step_noise + (size_t)i * B * n, sc.stats, s));
+        else
+            LTX_TRY(ltx_guidance_step(sc.p_text, do_cfg ? sc.p_uncond : nullptr, do_stg ? sc.p_pert : nullptr, LTX_F32, latents, nullptr, B, n,
+                                      p->guidance_scale, p->guidance_rescale, p->stg_scale, dts, sc.stats, s));
         HIP_TRY(hipEventRecord(e2, s));
     }
     HIP_TRY(hipEventRecord(sc.ev[1], s));

@@ -77,7 +77,8 @@ class PipelineParamsC(C.Structure):
                 ("skip_block_list", C.POINTER(C.c_int)), ("n_skip_blocks", C.c_int),
                 ("decode_timestep", C.c_float), ("decode_noise_scale", C.c_float),
                 ("output_latent", C.c_int), ("postprocess", C.c_int), ("tiling", C.POINTER(TilingC)),
-                ("shift_terminal", C.c_float), ("use_shift_terminal", C.c_int)]
+                ("shift_terminal", C.c_float), ("use_shift_terminal", C.c_int),
+                ("stochastic_sampling", C.c_int), ("step_noise", C.POINTER(C.c_float))]
 
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -93,6 +94,7 @@ _SIGS = {
     "ltx_vae_decode_tokens": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "ltx_vae_prepare_latents": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ltx_guidance_step": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp, _vp],
+    "ltx_guidance_step_stochastic": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _vp, _vp, _vp],
     "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
     "ltx_calculate_shift": [_i, _i, _i, _f, _f],
     "ltx_pcg32_randn": [C.c_uint64, C.c_uint64, _sz, _vp],
@@ -438,9 +440,10 @@ def calculate_shift(seq_len: int, base_seq_len: int = 256, max_seq_len: int = 40
 class FlowMatchEulerDiscreteScheduler:
     """Scheduler trait (t2v_pipeline.rs:28-37) as implemented at scheduler.rs:646-668."""
 
-    def __init__(self, shift: float = 1.0, shift_terminal: Optional[float] = 0.1):
+    def __init__(self, shift: float = 1.0, shift_terminal: Optional[float] = 0.1, stochastic_sampling: bool = False):
         self.shift = shift
         self.shift_terminal = shift_terminal
+        self.stochastic_sampling = stochastic_sampling
         self.sigmas: List[float] = []
         self.timesteps: List[int] = []
         self.step_index = 0
@@ -458,12 +461,23 @@ class FlowMatchEulerDiscreteScheduler:
         self.step_index = 0
         return self.timesteps
 
-    def step(self, noise_pred: torch.Tensor, timestep: int, latents: torch.Tensor) -> torch.Tensor:
-        """x + (sigma_next - sigma) * v, f32, in place on a copy (scheduler.rs:544-581)."""
-        dt = C.c_float(self.sigmas[self.step_index + 1]).value - C.c_float(self.sigmas[self.step_index]).value
+    def step(self, noise_pred: torch.Tensor, timestep: int, latents: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x + (sigma_next - sigma) * v, or with stochastic_sampling (1 - sigma_next) * (x - sigma * v) + sigma_next * noise
+        (`noise` = the randn_like(sample) draw, supplied by the caller); f32, on a copy (scheduler.rs:544-581)."""
+        sg, sn = C.c_float(self.sigmas[self.step_index]).value, C.c_float(self.sigmas[self.step_index + 1]).value
+        dt = sn - sg
         x = _dev(latents, torch.float32).clone()
         p = _dev(noise_pred)
         B = x.shape[0]
+        if self.stochastic_sampling:
+            if noise is None:
+                raise LtxError("stochastic_sampling: pass the per-step noise (the reference draws randn_like(sample))")
+            nz = _dev(noise, torch.float32)
+            _check(lib.ltx_guidance_step_stochastic(_ptr(p), None, None, _dt(p.dtype), _ptr(x), None, B, C.c_int64(x[0].numel()),
+                                                    C.c_float(1.0), C.c_float(0.0), C.c_float(0.0), C.c_float(sg), C.c_float(sn),
+                                                    _ptr(nz), None, _stream()))
+            self.step_index += 1
+            return x
         _check(lib.ltx_guidance_step(_ptr(p), None, None, _dt(p.dtype), _ptr(x), None, B, C.c_int64(x[0].numel()),
                                      C.c_float(1.0), C.c_float(0.0), C.c_float(0.0), C.c_float(dt), None, _stream()))
         self.step_index += 1
@@ -524,6 +538,7 @@ class PipelineCall:
     output_latent: bool = False
     postprocess: bool = True
     shift_terminal: Optional[float] = 0.1
+    stochastic_sampling: bool = False           # SchedulerConfig::stochastic_sampling (0.9.6-distilled preset)
 
 
 class LtxPipeline:
@@ -536,8 +551,9 @@ class LtxPipeline:
 
     def call(self, args: PipelineCall, latents: torch.Tensor, prompt_embeds: torch.Tensor, prompt_attention_mask: torch.Tensor,
              negative_prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_attention_mask: Optional[torch.Tensor] = None,
-             decode_noise: Optional[torch.Tensor] = None):
-        """Returns (final_latents [B,S,C] f32, video [B,3,frames,H,W] f32 or None)."""
+             decode_noise: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None):
+        """Returns (final_latents [B,S,C] f32, video [B,3,frames,H,W] f32 or None).
+        step_noise [steps,B,S,C] f32: the per-step draws of the stochastic-sampling scheduler (required iff enabled)."""
         lat = _dev(latents, torch.float32).clone()
         pe = _dev(prompt_embeds, torch.float32)
         pm = _dev(prompt_attention_mask, torch.float32)
@@ -562,6 +578,12 @@ class LtxPipeline:
         p.output_latent, p.postprocess = int(args.output_latent), int(args.postprocess)
         p.shift_terminal = args.shift_terminal if args.shift_terminal is not None else 0.0
         p.use_shift_terminal = int(args.shift_terminal is not None)
+        if args.stochastic_sampling:
+            if step_noise is None:
+                raise LtxError("stochastic_sampling needs step_noise [steps,B,S,C]")
+            sn = _dev(step_noise, torch.float32); keep.append(sn)
+            p.stochastic_sampling = 1
+            p.step_noise = C.cast(C.c_void_p(sn.data_ptr()), C.POINTER(C.c_float))
         tl = self.vae._tiling() if self.vae is not None else None
         if tl is not None:
             keep.append(tl)

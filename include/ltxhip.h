@@ -143,6 +143,15 @@ int ltx_guidance_step(const void* text, const void* uncond, const void* perturbe
                       float* latents, float* noise_pred_out, int B, int64_t n,
                       float guidance_scale, float guidance_rescale, float stg_scale, float dt,
                       void* stats_ws, ltx_stream stream);
+/* Same guidance mix, followed by the scheduler's stochastic-sampling update (SchedulerConfig::stochastic_sampling,
+ * scheduler.rs:557-575; the 0.9.6-distilled preset, configs.rs:210) instead of the Euler step:
+ *   x0 = x - sigma * noise_pred;   x = (1 - sigma_next) * x0 + sigma_next * step_noise
+ * step_noise [B, n] f32 is supplied by the caller (the reference draws it from the device RNG, :567). */
+int ltx_guidance_step_stochastic(const void* text, const void* uncond, const void* perturbed, ltx_dtype pred_dtype,
+                                 float* latents, float* noise_pred_out, int B, int64_t n,
+                                 float guidance_scale, float guidance_rescale, float stg_scale,
+                                 float sigma, float sigma_next, const float* step_noise,
+                                 void* stats_ws, ltx_stream stream);
 
 /* ---- host-side scalar restatements (no device work) ---- */
 /* FlowMatchEulerDiscreteScheduler::set_timesteps via the Scheduler trait (scheduler.rs:274-412, 646-660).
@@ -168,6 +177,9 @@ typedef struct {
     int postprocess;                /* apply postprocess_video */
     const ltx_tiling* tiling;       /* NULL = untiled */
     float shift_terminal; int use_shift_terminal;   /* scheduler config (configs.rs:101-121) */
+    int stochastic_sampling;        /* scheduler config (configs.rs:16; main.rs:550): stochastic step instead of Euler */
+    const float* step_noise;        /* DEVICE f32 [num_inference_steps, B, S*C]: the per-step randn_like(sample) draws;
+                                       required iff stochastic_sampling */
 } ltx_pipeline_params;
 void ltx_pipeline_params_default(ltx_pipeline_params* p);
 /*   latents [B,S,128] f32 packed, updated in place;  prompt_embeds [B,K,4096] f32;  prompt_mask [B,K] f32;

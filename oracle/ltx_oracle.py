@@ -922,7 +922,8 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
                   args: PipelineArgs, latents: Tensor, prompt_embeds: Tensor, prompt_mask: Tensor,
                   neg_embeds: Optional[Tensor] = None, neg_mask: Optional[Tensor] = None,
                   decode_noise: Optional[Tensor] = None, dtype=torch.float32,
-                  sched_cfg: SchedulerCfg = SchedulerCfg(), trajectory: Optional[list] = None) -> Tensor:
+                  sched_cfg: SchedulerCfg = SchedulerCfg(), trajectory: Optional[list] = None,
+                  step_noise: Optional[Tensor] = None) -> Tensor:
     """LtxPipeline::call (t2v_pipeline.rs:627-1073) with embeddings supplied
     (text encoder out of scope) and the decode noise supplied explicitly (the
     reference draws it from the device RNG, :1055)."""
@@ -949,6 +950,7 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
         return dit_forward(dit_p, dit_cfg, lat, emb, torch.full((b,), float(t)), mask, F_, H_, W_,
                            None, coords, slm, skip_perm, dtype)
 
+    trajectory_idx: list = []
     for t in ts:
         if do_cfg or do_stg:
             un = fwd(neg_embeds, neg_mask, t) if do_cfg else None
@@ -963,7 +965,9 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
             noise_pred = guidance_combine(tx, un, pe, args.guidance_scale, args.guidance_rescale, args.stg_scale)
         else:
             noise_pred = fwd(prompt_embeds, prompt_mask, t).float()
-        lat = sched.step(noise_pred, float(t), lat)
+        # stochastic sampling draws randn_like(sample) per step (scheduler.rs:567); supplied explicitly here
+        lat = sched.step(noise_pred, float(t), lat, None if step_noise is None else step_noise[len(trajectory_idx)])
+        trajectory_idx.append(0)
         if trajectory is not None:
             trajectory.append(lat.clone())
     if args.output_latent:

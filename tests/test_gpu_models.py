@@ -235,6 +235,39 @@ def test_models_built_from_checkpoint_files_equal_dict_built_models(hip, tmp_pat
         hip.LtxVideoTransformer3DModel.from_files(tcfg, str(tmp_path / "bad.safetensors"), unified=True)
 
 
+def test_pipeline_stochastic_sampling_matches_oracle(hip):
+    """SchedulerConfig::stochastic_sampling (0.9.6-distilled preset, configs.rs:210): the C-ABI loop with caller-supplied
+    per-step draws against the oracle's scheduler.step stochastic branch, f32, 3 steps with CFG."""
+    dcfg = O.DitConfig(**PIPE_DIT_CFG)
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)
+    g = torch.Generator().manual_seed(21)
+    F, H, W, K, N = 2, 2, 3, 6, 3
+    lat = torch.randn(1, F * H * W, 8, generator=g); pe = torch.randn(1, K, 32, generator=g); ne = torch.randn(1, K, 32, generator=g)
+    pm = torch.ones(1, K); pm[0, 4:] = 0; nm = torch.ones(1, K)
+    step_noise = torch.randn(N, 1, F * H * W, 8, generator=g)
+    args = O.PipelineArgs(height=H * 32, width=W * 32, num_frames=(F - 1) * 8 + 1, num_inference_steps=N, guidance_scale=2.5, output_latent=True)
+    want = O.pipeline_call(dw, dcfg, None, O.VaeConfig(**VAE_CFG), None, None, args, lat, pe, pm, ne, nm,
+                           sched_cfg=O.SchedulerCfg(stochastic_sampling=True), step_noise=step_noise)
+    dit = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**PIPE_DIT_CFG), {k: v.to(DEV) for k, v in dw.items()}, torch.float32)
+    pipe = hip.LtxPipeline(dit, None)
+    call = hip.PipelineCall(height=H * 32, width=W * 32, num_frames=(F - 1) * 8 + 1, num_inference_steps=N, guidance_scale=2.5,
+                            output_latent=True, stochastic_sampling=True)
+    got, _ = pipe.call(call, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV), step_noise=step_noise.to(DEV))
+    assert rel_max(got.cpu(), want) <= 1e-3, rel_max(got.cpu(), want)
+    det, _ = pipe.call(hip.PipelineCall(height=H * 32, width=W * 32, num_frames=(F - 1) * 8 + 1, num_inference_steps=N, guidance_scale=2.5, output_latent=True),
+                       lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV))
+    assert rel_max(got.cpu(), det.cpu()) > 1e-2          # it really is a different update rule
+    with pytest.raises(hip.LtxError, match="step_noise"):
+        pipe.call(call, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV))
+    # scheduler-level op
+    sch = hip.FlowMatchEulerDiscreteScheduler(1.0, 0.1, stochastic_sampling=True)
+    sch.set_timesteps([1.0, 0.6, 0.3], None)
+    x = torch.randn(1, 12, 8, generator=g); v = torch.randn(1, 12, 8, generator=g); nz = torch.randn(1, 12, 8, generator=g)
+    s0, s1 = sch.sigmas[0], sch.sigmas[1]
+    out = sch.step(v.to(DEV), sch.timesteps[0], x.to(DEV), nz.to(DEV)).cpu()
+    assert torch.allclose(out, (1.0 - s1) * (x - s0 * v) + s1 * nz, atol=1e-5)
+
+
 def test_pipeline_rejects_bad_inputs(hip):
     dcfg = O.DitConfig(**PIPE_DIT_CFG)
     dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)

@@ -214,3 +214,19 @@ def test_vae_fixture_reproduces(golden):
     assert torch.allclose(ck, g["weights_checksum"], rtol=1e-9), "torch RNG stream differs from the one the fixture was made with"
     y = O.decoder_forward(w, cfg, g["z"], g["timestep"])
     assert rel_max(y, g["out_f32"]) < 1e-4
+
+
+def test_stochastic_sampling_step_formula():
+    """scheduler.rs:557-575: x0 = x - sigma v; x' = (1 - sigma') x0 + sigma' noise, with the draw supplied."""
+    sched = O.FlowMatchEulerScheduler(O.SchedulerCfg(stochastic_sampling=True))
+    ts = sched.set_timesteps(sigmas=[1.0, 0.75, 0.5], mu=0.0)
+    g = torch.Generator().manual_seed(0)
+    x, v, nz = torch.randn(2, 6, 4, generator=g), torch.randn(2, 6, 4, generator=g), torch.randn(2, 6, 4, generator=g)
+    s0, s1 = float(sched.sigmas[0]), float(sched.sigmas[1])
+    out = sched.step(v, float(ts[0]), x, nz)
+    assert torch.allclose(out, (1.0 - s1) * (x - s0 * v) + s1 * nz, atol=1e-6)
+    # last step: sigma' = 0 -> the result is the clean-sample estimate, noise drops out
+    sched2 = O.FlowMatchEulerScheduler(O.SchedulerCfg(stochastic_sampling=True))
+    sched2.set_timesteps(sigmas=[0.5], mu=0.0)
+    out2 = sched2.step(v, float(sched2.timesteps[0]), x, nz)
+    assert torch.allclose(out2, x - float(sched2.sigmas[0]) * v, atol=1e-6)
