@@ -358,7 +358,6 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     struct End { void* t; hipStream_t s; ~End() { ltx_prof_end(t, s); } } end_{tok, s};
     if (dtype == LTX_DT_BF16) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
-        if (ltx_attention_pipe_eligible(a, dtype)) return ltx_launch_attention_pipe(a, s);   // long-Sk software-pipelined variant
         dim3 grid((unsigned)(cdiv(a.Sq, BQ) * a.heads * a.B)), block(256);
         AttnArgs ax = a;
         const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)

@@ -190,17 +190,14 @@ template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;
+    // PIN = true: the pinned fragment-stream schedule (A/B on MI355X: linear +-1 %, conv +1..4 % over the compiler's order)
     auto kern = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, true>;
-    auto kern_nopin = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, false>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_nopin), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN))), block(64 * WGM * WGN);
-    const char* pe = getenv("LTX_GEMM_PIN");
-    if (pe && pe[0] == '0') hipLaunchKernelGGL(kern_nopin, grid, block, smem, s, g);
-    else hipLaunchKernelGGL(kern, grid, block, smem, s, g);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, g);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
@@ -228,10 +225,7 @@ int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         case 3: return launch_epi<256, 128, 2, 4, CONV>(g, epi, s);
         case 4: return launch_epi<192, 128, 2, 4, CONV>(g, epi, s);
         case 5: return launch_epi<128, 128, 2, 4, CONV>(g, epi, s);
-        case 6: return launch_epi<192, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 96x64 per wave
-        case 7: return launch_epi<128, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 64x64 per wave
-        case 8: return launch_epi<256, 128, 2, 2, CONV>(g, epi, s);     // 4 waves, 128x64 per wave
-        case 9: return launch_epi<160, 128, 2, 4, CONV>(g, epi, s);     // M = 4992 = 31.2 x 160: 32 x (N/128) tiles = whole rounds of 512
+        case 6: return launch_epi<160, 128, 2, 4, CONV>(g, epi, s);     // M = 4992 = 31.2 x 160: 32 x (N/128) tiles = whole rounds of 512
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
@@ -242,7 +236,6 @@ struct TileInfo { int bm, bn, threads; double rate; int per_cu; const char* name
 const TileInfo kTiles[] = {
     {256, 256, 512, 1160, 1, "256x256"}, {192, 256, 512, 1190, 1, "192x256"}, {128, 256, 512, 1023, 1, "128x256"},
     {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
-    {192, 128, 256, 0, 2, "192x128w4"},  {128, 128, 256, 0, 2, "128x128w4"},  {256, 128, 256, 0, 1, "256x128w4"},
     {160, 128, 512, 1330, 2, "160x128"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -251,7 +244,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // Tile choice: minimise (rounds over the CUs) x (tile time); ties go to the larger tile (less operand re-reading).
 int ltx_gemm_big_pick_tile(int M, int N) {
-    const char* force = getenv("LTX_GEMM_TILE");       // e.g. "256x128" or "192x128w4" (tuning aid)
+    const char* force = getenv("LTX_GEMM_TILE");       // e.g. "256x128" (tuning / test aid)
     if (force) for (int i = 0; i < kNumTiles; ++i) if (!strcmp(force, kTiles[i].name)) return i;
     double best = 1e30; int bi = 4;
     for (int i = 0; i < kNumTiles; ++i) {

@@ -87,9 +87,6 @@ struct AttnArgs {
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
-// software-pipelined bf16 variant for long key sequences (attention_pipe.hip); ltx_launch_attention dispatches to it
-bool ltx_attention_pipe_eligible(const AttnArgs& a, int dtype);
-int ltx_launch_attention_pipe(const AttnArgs& a, hipStream_t s);
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
 struct TimeVec { float t[8]; int n; };

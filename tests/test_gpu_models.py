@@ -345,3 +345,22 @@ def test_full_size_dit_layer_stack_determinism_and_sanity(hip):
         outs[dt] = a.float().cpu()
         del m
     assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) <= 3e-2
+
+
+def test_c5_13b_geometry_ops_vs_cpu_slices(hip):
+    """BASELINE config 5 (13B: D=4096, 32 heads x 128, S = 21*22*38 = 17556): the head_dim-128 attention kernel and the
+    FF1 GEMM at full size against CPU f32 on sampled rows (index arithmetic at 17556^2 scores / 16384-wide rows)."""
+    S, H, hd = 17556, 32, 128
+    g = torch.Generator().manual_seed(5)
+    q, k, v = [torch.randn(1, S, H * hd, generator=g).bfloat16() for _ in range(3)]
+    o = hip.ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, hd ** -0.5).float().cpu()
+    rows = torch.tensor([0, 1, 4095, 8777, 17500, 17555])
+    for h in (0, 31):
+        sl = slice(h * hd, (h + 1) * hd)
+        att = torch.softmax(q[0, rows, sl].float() @ k[0, :, sl].float().T * hd ** -0.5, -1)
+        assert rel_l2(o[0, rows, sl], att @ v[0, :, sl].float()) <= 1.5e-2
+    del q, k, v, o
+    x = torch.randn(S, 4096, generator=g).bfloat16(); w = (torch.randn(16384, 4096, generator=g) / 64).bfloat16(); b = torch.randn(16384, generator=g).bfloat16()
+    y = hip.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), epi=1).float().cpu()
+    r2 = torch.tensor([0, 255, 256, 9000, 17555])
+    assert rel_l2(y[r2], O.gelu_approximate(x[r2].float() @ w.float().T + b.float())) <= 1.5e-2

@@ -89,7 +89,7 @@ def tile_sweep():
     for name, M, N, K in [("qkv", S, 6144, 2048), ("to_out", S, 2048, 2048), ("ff1", S, 8192, 2048), ("ff2", S, 2048, 8192), ("sq4096", 4096, 4096, 4096)]:
         x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
         res = {}
-        for tile in ["256x256", "192x256", "256x128", "192x128", "128x128", "192x128w4", "128x128w4", "256x128w4"]:
+        for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128"]:
             if tile == "old":
                 os.environ["LTX_GEMM_BIG"] = "0"
             else:
