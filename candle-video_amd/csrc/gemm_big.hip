@@ -226,6 +226,7 @@ int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         case 4: return launch_epi<192, 128, 2, 4, CONV>(g, epi, s);
         case 5: return launch_epi<128, 128, 2, 4, CONV>(g, epi, s);
         case 6: return launch_epi<160, 128, 2, 4, CONV>(g, epi, s);     // M = 4992 = 31.2 x 160: 32 x (N/128) tiles = whole rounds of 512
+        case 7: return launch_epi<192, 64, 4, 2, CONV>(g, epi, s);      // narrow outputs (conv_out N = 48, proj_out): 4(M) x 2(N) waves of 48x32
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
@@ -236,9 +237,11 @@ struct TileInfo { int bm, bn, threads; double rate; int per_cu; const char* name
 const TileInfo kTiles[] = {
     {256, 256, 512, 1160, 1, "256x256"}, {192, 256, 512, 1190, 1, "192x256"}, {128, 256, 512, 1023, 1, "128x256"},
     {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
-    {160, 128, 512, 1330, 2, "160x128"},
+    {160, 128, 512, 1330, 2, "160x128"}, {192, 64, 512, 900, 2, "192x64"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+// a tile is a candidate for an N-wide output: 64-wide tiles only for narrow outputs, 256-wide only beyond 128 columns
+bool tile_fits(const TileInfo& t, int N) { return t.rate > 0 && !(t.bn > 128 && N <= 128) && !(t.bn == 64 && N > 64) && !(t.bn > 64 && N <= 64); }
 
 }  // namespace
 
@@ -249,8 +252,7 @@ int ltx_gemm_big_pick_tile(int M, int N) {
     double best = 1e30; int bi = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileInfo& t = kTiles[i];
-        if (t.rate <= 0) continue;
-        if (t.bn > 128 && N <= 128) continue;
+        if (!tile_fits(t, N)) continue;
         const int64_t tiles = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
         const double cost = (double)cdiv64(tiles, 256 * t.per_cu) * (double)(t.bm * t.bn * t.per_cu) / t.rate;
         if (cost < best * 0.999) { best = cost; bi = i; }
@@ -263,7 +265,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     const char* off = getenv("LTX_GEMM_BIG");
     if (off && off[0] == '0') return false;
     if (g.conv && (g.kh > 3 || g.kw > 3)) return false;   // the validity mask covers 3x3 (and 1x1) spatial taps
-    return g.M >= 1024 && g.N >= 64;
+    return g.M >= 1024 && g.N >= 32;
 }
 
 // ---- plan selection --------------------------------------------------------------------------------------------
@@ -301,8 +303,8 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     for (int plan = 0; plan < kPlanP8 + 2; ++plan) {
         if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
-            if (kTiles[plan].rate <= 0 || (kTiles[plan].bn > 128 && g.N <= 128)) continue;
-        } else if (p8_off || nk < 2 || (plan == kPlanP8 && g.N <= 128)) continue;
+            if (!tile_fits(kTiles[plan], g.N)) continue;
+        } else if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
         // 3..16 of them, best of two rounds
         HIP_TRY(hipEventRecord(e0, s));

@@ -253,7 +253,7 @@ def test_errors_are_reported_not_crashed(hip):
 
 
 @pytest.mark.parametrize("tile", ["256x256", "192x256", "128x256", "256x128", "192x128", "128x128",
-                                  "160x128", "p8:256", "p8:128"])
+                                  "160x128", "192x64", "p8:256", "p8:128"])
 def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
     """gemm_big.hip (LDS-DMA staged, 8 waves) and gemm_p8.hip (phase-interleaved): every tile shape, ragged M/N/K tails, every epilogue."""
     if tile.startswith("p8:"):
@@ -289,7 +289,7 @@ def test_gemm_plans_are_bit_identical_and_tuner_caches(hip, monkeypatch):
     xc, wc, bc = cl(rnd(dt, 1, 64, 3, 24, 20)).cuda(), rnd(dt, 128, 64, 3, 3, 3, scale=0.03).cuda(), rnd(dt, 128, scale=0.1).cuda()
     monkeypatch.setenv("LTX_GEMM_TUNE", "0")
     base_lin, base_conv = hip.ops.linear(x, w, b, epi=1), hip.ops.conv3d(xc, wc, bc)
-    for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128"]:
+    for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128", "192x64"]:
         monkeypatch.setenv("LTX_GEMM_TILE", tile)
         assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), tile
         assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), tile
