@@ -58,6 +58,42 @@ __device__ __forceinline__ void finish_chunk(const RowNormArgs& a, const float* 
     if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
 }
 
+// Same, with the per-channel operands (weight, scale, shift of ONE chunk) already in registers: the NARROW mapping
+// keeps a lane on the same chunk for all of its rows, so they are loaded once instead of once per row
+// (64 B of modulation per 16 B of data through the L1/TA path otherwise).
+template <typename T>
+__device__ __forceinline__ void finish_chunk_regs(const RowNormArgs& a, const float* f_in, float mean, float rinv, int c, bool has_w, bool has_mod,
+                                                  const float* wv, const float* scv, const float* shv, T* y, bool active) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    float f[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        float n = (f_in[i] - mean) * rinv;
+        if (has_w) n *= wv[i];
+        if (has_mod) n = n * (1.0f + scv[i]) + shv[i];
+        if (a.act == 1) n = silu_f(n);
+        f[i] = n;
+    }
+    Chunk16 o; f32_to_chunk<T>(f, o);
+    if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_chunk_operands(const RowNormArgs& a, int c, int64_t b, float* wv, float* scv, float* shv) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    const T* w = reinterpret_cast<const T*>(a.weight);
+    if (w) { Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH); chunk_to_f32<T>(wc, wv); }
+    if (a.scale) {
+        const float* sc = a.scale + b * a.mod_stride; const float* sh = a.shift + b * a.mod_stride;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(sc + c * CH + 4 * q), b4 = *reinterpret_cast<const f32x4*>(sh + c * CH + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { scv[4 * q + i] = a4[i]; shv[4 * q + i] = b4[i]; }
+        }
+    }
+}
+
 // MODE 0: WIDE (row cached in registers), 1: NARROW (NSLOT rows per lane group), 2: re-read fallback
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int lpr) {
@@ -68,22 +104,28 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int l
     const int nch = a.D / CH;
     const float invD = 1.0f / (float)a.D;
     if constexpr (MODE == 1) {
-        // lane group handles rows base + i*rpw*4*gridDim? -> contiguous block of NSLOT*rpw rows per wave
+        // a wave owns a contiguous block of NSLOT*rpw rows; slot i of a lane group is row0 + i*rpw.  Addresses advance by a
+        // constant stride (no per-row 64-bit multiply), rows past the end are predicated off instead of clamped.
         const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (rpw * NSLOT) + lane / lpr;
-        Chunk16 v[NSLOT];
         const bool has = sub < nch;
+        const T* xp = reinterpret_cast<const T*>(a.x) + row0 * a.ldx + sub * CH;
+        T* yp = reinterpret_cast<T*>(a.y) + row0 * a.ldy;
+        const int64_t xs = (int64_t)rpw * a.ldx, ys = (int64_t)rpw * a.ldy;
+        Chunk16 v[NSLOT];
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            int64_t row = row0 + (int64_t)i * rpw;
-            int64_t rr = row < a.rows ? row : a.rows - 1;
             v[i].u = (u32x4){0u, 0u, 0u, 0u};
-            if (has) v[i].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + rr * a.ldx + sub * CH);
+            if (has && row0 + i * rpw < a.rows) v[i].u = *reinterpret_cast<const u32x4*>(xp + i * xs);
         }
+        // per-channel operands of this lane's chunk, for the batch of its first row (reloaded only if a row crosses a batch)
+        float wv[CH], scv[CH], shv[CH];
+        const int64_t b0 = (row0 < a.rows ? row0 : a.rows - 1) / a.rows_per_batch;      // ONE 64-bit division per lane
+        const int64_t b0_end = (b0 + 1) * a.rows_per_batch;                               // first row of the next batch
+        if (has) load_chunk_operands<T>(a, sub, b0, wv, scv, shv);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            int64_t row = row0 + (int64_t)i * rpw;
+            const int64_t row = row0 + (int64_t)i * rpw;
             const bool active = row < a.rows;
-            int64_t rr = active ? row : a.rows - 1;
             float f[CH]; chunk_to_f32<T>(v[i], f);
             float mean = 0.f;
             if (a.kind == 1) {
@@ -98,11 +140,17 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int l
                 for (int j = 0; j < CH; ++j) { float d = f[j] - mean; ss += d * d; }
             }
             ss = group_sum(ss, lpr);
-            const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
-            const int64_t b = rr / a.rows_per_batch;
-            const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
-            const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
-            if (has) finish_chunk<T>(a, f, mean, rinv, sub, sc, sh, reinterpret_cast<T*>(a.y) + rr * a.ldy, active);
+            const float rinv = __builtin_amdgcn_rsqf(ss * invD + a.eps);
+            if (has) {
+                if (row < b0_end) {
+                    finish_chunk_regs<T>(a, f, mean, rinv, sub, a.weight != nullptr, a.scale != nullptr, wv, scv, shv, yp + i * ys, active);
+                } else if (active) {                                                     // a row of a later batch (rare)
+                    const int64_t b = row / a.rows_per_batch;
+                    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+                    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+                    finish_chunk<T>(a, f, mean, rinv, sub, sc, sh, yp + i * ys, active);
+                }
+            }
         }
     } else {
         const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
@@ -251,6 +299,70 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
     }
 }
 
+// Fast path of the kernel above for rows of <= NS*lpr chunks (the DiT's 2048-wide q/k: 4 chunks per lane): the cos/sin
+// chunks of a lane are loaded ONCE and reused by both segments (q and k share the table), and the loads of every
+// segment are issued before the first reduction (memory-level parallelism; the slow kernel read the tables twice and
+// serialised the segments).
+template <typename T, int NS>
+__global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRopeArgs a, int lpr) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    static_assert(CH == 8, "bf16 rows only");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
+    const int sub = lane % lpr;
+    const bool active = row < a.rows;
+    const int64_t rr = active ? row : a.rows - 1;
+    const int nch = a.D / CH;
+    const bool rope = a.cos != nullptr;
+    const float* cs = rope ? a.cos + rr * (a.D / 2) : nullptr;
+    const float* sn = rope ? a.sin + rr * (a.D / 2) : nullptr;
+    T* x0 = reinterpret_cast<T*>(a.x) + rr * a.ld;
+    Chunk16 v[2][NS];
+    f32x4 co[NS], si[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = sub + i * lpr;
+        const bool in = c < nch;
+        v[0][i].u = (u32x4){0u, 0u, 0u, 0u}; v[1][i].u = (u32x4){0u, 0u, 0u, 0u};
+        if (in) v[0][i].u = *reinterpret_cast<const u32x4*>(x0 + c * CH);
+        if (in && a.nseg == 2) v[1][i].u = *reinterpret_cast<const u32x4*>(x0 + a.D + c * CH);
+        if (in && rope) { co[i] = *reinterpret_cast<const f32x4*>(cs + c * 4); si[i] = *reinterpret_cast<const f32x4*>(sn + c * 4); }
+    }
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        if (seg >= a.nseg) break;
+        const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { float f[CH]; chunk_to_f32<T>(v[seg][i], f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) ss += f[j] * f[j]; }
+        ss = group_sum(ss, lpr);
+        const float rinv = (seg == 0 ? a.out_scale0 : 1.0f) / sqrtf(ss / (float)a.D + a.eps);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = sub + i * lpr;
+            if (c >= nch) continue;
+            float f[CH]; chunk_to_f32<T>(v[seg][i], f);
+            Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
+            float wv[CH]; chunk_to_f32<T>(wc, wv);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) f[j] = f[j] * rinv * wv[j];
+            if (rope) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float re = f[2 * p], im = f[2 * p + 1];
+                    f[2 * p] = re * co[i][p] - im * si[i][p];
+                    f[2 * p + 1] = im * co[i][p] + re * si[i][p];
+                }
+            }
+            Chunk16 o; f32_to_chunk<T>(f, o);
+            if (active) *reinterpret_cast<u32x4*>(x0 + (int64_t)seg * a.D + c * CH) = o.u;
+        }
+    }
+}
+
 __global__ void rope_table_kernel(const RopeTableArgs a) {
     const int half = a.D / 2;
     const int64_t S = (int64_t)a.F * a.H * a.W;
@@ -327,7 +439,8 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
     const bool cached = nch <= NSLOT * lpr;
     if (dtype == LTX_DT_BF16) {
-        if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
+        if (nch <= 4 * lpr) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 4>), grid, block, 0, s, a, lpr);
+        else if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
         else hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, false>), grid, block, 0, s, a, lpr);
     } else {
         if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<float, true>), grid, block, 0, s, a, lpr);
