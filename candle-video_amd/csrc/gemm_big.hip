@@ -304,7 +304,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
             if (!tile_fits(kTiles[plan], g.N)) continue;
-        } else if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128)) continue;
+        } else if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
         // 3..16 of them, best of two rounds
         HIP_TRY(hipEventRecord(e0, s));

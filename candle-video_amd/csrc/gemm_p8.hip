@@ -25,13 +25,6 @@
 
 namespace {
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page8[64];
-
-__device__ __forceinline__ void glds16_8(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 extern __shared__ __attribute__((aligned(16))) unsigned char p8_smem[];
 
 template <int BN, int WGM, int WGN, int EPI, bool CONV>
@@ -63,13 +56,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
     const int ktiles = (Kdim + 63) / 64;
     const int ntaps = CONV ? g.ntaps : 1;
     const int nk = ktiles * ntaps;
-    const uintptr_t zero = reinterpret_cast<uintptr_t>(g_zero_page8);
-
-    // ---- staging lanes: DMA piece j of a half covers rows (j*8+wave)*8 .. +8; lane -> row +(lane>>3), physical chunk lane&7
+    // ---- staging: buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds).  A and W are raw buffers (stride 0); a lane's
+    // address is a loop-invariant 32-bit byte offset (row start + its 16-B chunk) in a VGPR plus a wave-uniform scalar
+    // offset (K position, conv tap) in an SGPR, so a DMA issue costs no 64-bit VALU address arithmetic; padding (K tails,
+    // the zero halo of the conv) is an out-of-range offset, which the buffer unit turns into zeros.
+    constexpr uint32_t OOB = 0x80000000u;                          // >= num_records: launcher guarantees tensors < 2 GiB
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
+    // DMA piece j of a half covers rows (j*8+wave)*8 .. +8; lane -> row +(lane>>3), physical chunk lane&7
     const int srow = wave * 8 + (lane >> 3);                       // + j*64
     const int schunk = (lane & 7) ^ ((srow >> 1) & 7);             // logical chunk this lane fetches (same for every j)
-    int64_t a_off[2][GA]; int a_geo[2][GA];                        // a_geo (conv) = ct << 6 | validity bits
-    int64_t b_off[2][GB];
+    uint32_t a_off[2][GA]; int a_geo[2][GA];                       // byte offsets; a_geo (conv) = ct << 6 | validity bits
+    uint32_t b_off[2][GB];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -80,18 +78,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
                 const int hh = t1 % g.H; const int t2 = t1 / g.H;
                 const int vm = (hh > 0 ? 1 : 0) | 2 | (hh < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0);
                 a_geo[h][j] = ((t2 % g.T) << 6) | vm;
-                a_off[h][j] = (int64_t)m * g.Cin + schunk * 8;
+                a_off[h][j] = ((uint32_t)m * (uint32_t)g.Cin + schunk * 8) * 2u;
             } else {
                 a_geo[h][j] = 0;
-                a_off[h][j] = (int64_t)m * g.lda + schunk * 8;
+                a_off[h][j] = ((uint32_t)m * (uint32_t)g.lda + schunk * 8) * 2u;
             }
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
             int n = n0 + h * HB + j * 64 + srow; if (n > g.N - 1) n = g.N - 1;
-            b_off[h][j] = (int64_t)n * Kdim + schunk * 8;
+            b_off[h][j] = ((uint32_t)n * (uint32_t)Kdim + schunk * 8) * 2u;
         }
     }
+    const uint32_t frame_bytes = CONV ? (uint32_t)g.H * g.Wd * g.Cin * 2u : 0u;
     // stage cursor: K-tile being staged -> (tap, k offset); advanced after the 4th half (A1) of a K-tile
     int c_kk = 0, c_it = 0, c_ih = 0, c_iw = 0, c_tap = 0, c_tile = 0;
     auto cursor_next = [&]() {
@@ -101,45 +100,45 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
             if constexpr (CONV) { if (++c_iw == g.kw) { c_iw = 0; if (++c_ih == g.kh) { c_ih = 0; ++c_it; } } }
         }
     };
+    auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+    };
     // which: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (compile-time after inlining) -- the staging order of a K-tile
     auto stage = [&](int which) {
         unsigned char* buf = p8_smem + (c_tile & 1) * BUF;
         const int kbase = c_kk * 64;
-        const bool kin = kbase + schunk * 8 < Kdim;
+        const bool kin = kbase + schunk * 8 < Kdim;                // only the last K-tile of a ragged K can fail
         if (which == 1 || which == 3) {
             const int h = which == 3 ? 1 : 0;
             unsigned char* dst = buf + h * A_HALF;
-            int dt = 0, vbit = 0; int64_t hw_delta = 0;
+            int dt = 0, vbit = 0; uint32_t soff = (uint32_t)kbase * 2u;
             if constexpr (CONV) {
                 const int dh = c_ih - g.kh / 2, dw = c_iw - g.kw / 2;
                 dt = c_it - g.pad_t;
                 vbit = (1 << (dh + 1)) | (8 << (dw + 1));
-                hw_delta = ((int64_t)dh * g.Wd + dw) * g.Cin;
+                soff += (uint32_t)((dh * g.Wd + dw) * g.Cin * 2);   // may wrap: added modulo 2^32 to the lane offset below
             }
 #pragma unroll
             for (int j = 0; j < GA; ++j) {
-                // branch-free source select: every wave must issue the SAME number of DMA instructions (vmcnt is counted)
-                uintptr_t src;
+                uint32_t voff = a_off[h][j];
+                bool ok = kin;
                 if constexpr (CONV) {
                     const int ct = a_geo[h][j] >> 6;
                     int tt = ct + dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);
-                    src = reinterpret_cast<uintptr_t>(A + a_off[h][j] + (int64_t)(tt - ct) * g.H * g.Wd * g.Cin + hw_delta + kbase);
-                    src = (kin && (a_geo[h][j] & vbit) == vbit) ? src : zero;
+                    // the tap delta is folded into the VGPR offset (it can be negative; the scalar offset is unsigned)
+                    voff += (uint32_t)(tt - ct) * frame_bytes + soff;
+                    ok = ok && (a_geo[h][j] & vbit) == vbit;
+                    dma(ra, ok ? voff : OOB, 0u, dst + (j * 8 + wave) * 1024);
                 } else {
-                    src = reinterpret_cast<uintptr_t>(A + a_off[h][j] + kbase);
-                    src = kin ? src : zero;
+                    dma(ra, ok ? voff : OOB, soff, dst + (j * 8 + wave) * 1024);
                 }
-                glds16_8(reinterpret_cast<const void*>(src), dst + (j * 8 + wave) * 1024);
             }
         } else {
             const int h = which == 2 ? 1 : 0;
             unsigned char* dst = buf + 2 * A_HALF + h * B_HALF;
+            const uint32_t soff = ((uint32_t)c_tap * (uint32_t)g.N * (uint32_t)Kdim + (uint32_t)kbase) * 2u;
 #pragma unroll
-            for (int j = 0; j < GB; ++j) {
-                uintptr_t src = reinterpret_cast<uintptr_t>(W + (int64_t)c_tap * g.N * Kdim + b_off[h][j] + kbase);
-                src = kin ? src : zero;
-                glds16_8(reinterpret_cast<const void*>(src), dst + (j * 8 + wave) * 1024);
-            }
+            for (int j = 0; j < GB; ++j) dma(rw, kin ? b_off[h][j] : OOB, soff, dst + (j * 8 + wave) * 1024);
         }
         if (which == 3) cursor_next();
     };
@@ -295,8 +294,16 @@ int ltx_gemm_p8_choice(const GemmArgs& g) {
     return 0;
 }
 
+// buffer-addressed staging uses 32-bit byte offsets with 0x80000000 as the out-of-range marker
+bool ltx_gemm_p8_fits(const GemmArgs& g) {
+    const double a_bytes = g.conv ? (double)g.M * g.Cin * 2.0 : (double)g.M * g.lda * 2.0;
+    const double w_bytes = (double)(g.conv ? g.ntaps : 1) * g.N * g.K * 2.0;
+    return a_bytes < 2147483648.0 && w_bytes < 2147483648.0;
+}
+
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     if ((g.K + 63) / 64 * (g.conv ? g.ntaps : 1) < 2) LTX_FAIL(LTX_ERR_ARG, "gemm_p8: needs at least two K-tiles");
+    if (!ltx_gemm_p8_fits(g)) LTX_FAIL(LTX_ERR_ARG, "gemm_p8: operands must be smaller than 2 GiB (32-bit buffer offsets)");
     if (bn == 256) return g.conv ? launch_epi8<256, 2, 4, true>(g, epi, s) : launch_epi8<256, 2, 4, false>(g, epi, s);
     return g.conv ? launch_epi8<128, 4, 2, true>(g, epi, s) : launch_epi8<128, 4, 2, false>(g, epi, s);
 }
