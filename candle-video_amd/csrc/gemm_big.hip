@@ -3,14 +3,14 @@
 //
 //   * tile BM x BN (256/192/128 x 256/128), K-step 64 bf16 (128-B LDS rows), 512 threads =
 //     8 waves as 2(M) x 4(N), each wave (BM/2) x (BN/4) with v_mfma_f32_16x16x32_bf16;
-//   * operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip): one wave
+//   * operands go HBM -> LDS with buffer_load_dwordx4 ... lds (no VGPR round trip): one wave
 //     instruction fills 8 rows x 128 B, LDS destination is lane-linear, so the bank swizzle
 //     (16-B chunk ^ ((row>>1)&7)) is applied on the per-lane SOURCE address and again on the
 //     ds_read_b128 fragment reads (same involution on both sides);
 //   * two LDS stages (<= 128 KiB): the loads of K-step t+1 are in flight while step t is
 //     multiplied; one vmcnt(0)+barrier per K-step;
 //   * conv mode gathers the A rows per tap from the channels-last activation: replicate padding
-//     on T is a clamp, zero padding on H/W (and K tails) redirect the lane to a zero page;
+//     on T is a clamp, zero padding on H/W (and K tails) is an out-of-range buffer offset (reads zeros);
 //   * D = Wfrag x Afrag so a lane owns 4 consecutive output columns (shared fused epilogues).
 #include <cstring>
 #include <map>
@@ -21,14 +21,7 @@ namespace {
 
 constexpr int ROWB = 128;          // bytes per LDS row (64 bf16)
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];   // all zeros (static init)
-
 __device__ __forceinline__ int swz_big(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 
@@ -58,15 +51,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     const int ktiles = (Kdim + 63) / 64;
     const int ntaps = CONV ? g.ntaps : 1;
     const int nk = ktiles * ntaps;
-    const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
-
     // per-lane staging geometry: instruction j of this wave fills LDS rows 8*(j*8+wave) .. +7;
-    // lane -> (row in group = lane>>3, physical chunk = lane&7), logical chunk = pc ^ ((row>>1)&7)
+    // lane -> (row in group = lane>>3, physical chunk = lane&7), logical chunk = pc ^ ((row>>1)&7).
+    // Addressing is buffer-style (buffer_load_dwordx4 ... lds): a loop-invariant 32-bit byte offset per lane (row start
+    // + chunk) plus a wave-uniform scalar offset (K position / tap), out-of-range offsets read as zeros (K tails, conv halo).
+    constexpr uint32_t OOB = 0x80000000u;                 // >= num_records; ltx_gemm_big_eligible keeps operands < 2 GiB
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
     const int lr = lane >> 3, pc = lane & 7;
     int a_chunk[AI], b_chunk[BI];
-    int64_t a_off[AI];                 // element offset of the row (conv: of the centre voxel)
+    uint32_t a_off[AI];                // byte offset of the row's chunk (conv: of the centre voxel)
     int ct[AI], vmask[AI];             // conv: frame index; 6 validity bits (h-1,h,h+1 | w-1,w,w+1 inside the image)
-    int64_t b_off[BI];
+    uint32_t b_off[BI];
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int row = 8 * (j * NW + wave) + lr;
@@ -77,9 +73,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             const int h = t1 % g.H; const int t2 = t1 / g.H;
             ct[j] = t2 % g.T;
             vmask[j] = (h > 0 ? 1 : 0) | 2 | (h < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0);
-            a_off[j] = (int64_t)m * g.Cin;
+            a_off[j] = ((uint32_t)m * (uint32_t)g.Cin + a_chunk[j] * 8) * 2u;
         } else {
-            a_off[j] = (int64_t)m * g.lda;
+            a_off[j] = ((uint32_t)m * (uint32_t)g.lda + a_chunk[j] * 8) * 2u;
         }
     }
 #pragma unroll
@@ -87,15 +83,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         const int row = 8 * (j * NW + wave) + lr;
         b_chunk[j] = pc ^ ((row >> 1) & 7);
         int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
-        b_off[j] = (int64_t)n * Kdim;
+        b_off[j] = ((uint32_t)n * (uint32_t)Kdim + b_chunk[j] * 8) * 2u;
     }
+    const uint32_t frame_bytes = CONV ? (uint32_t)g.H * g.Wd * g.Cin * 2u : 0u;
+    auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+    };
 
     auto stage = [&](int kt, int buf) {
         unsigned char* As = big_smem + buf * STAGE;
         unsigned char* Bs = As + BM * ROWB;
         int tap = 0, kk = kt;
         if constexpr (CONV) { tap = kt / ktiles; kk = kt - tap * ktiles; }
-        int dt = 0, vbit = 0; int64_t hw_delta = 0;       // all wave-uniform (scalar) per tap
+        int dt = 0, vbit = 0; uint32_t a_soff = (uint32_t)kk * 128u;      // all wave-uniform (scalar) per tap
         if constexpr (CONV) {
             const int khw = g.kh * g.kw;
             const int it = tap / khw; const int rem = tap - it * khw;
@@ -103,27 +103,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             const int dh = ih - g.kh / 2, dw = iw - g.kw / 2;
             dt = it - g.pad_t;
             vbit = (1 << (dh + 1)) | (8 << (dw + 1));
-            hw_delta = ((int64_t)dh * g.Wd + dw) * g.Cin;
+            a_soff += (uint32_t)((dh * g.Wd + dw) * g.Cin * 2);           // may be "negative": added modulo 2^32 to the lane offset
         }
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
-            const int k = kk * 64 + a_chunk[j] * 8;
-            const unsigned char* src = zero;
+            bool ok = kk * 64 + a_chunk[j] * 8 < Kdim;
+            if (A_RAGGED && (j * NW + wave) * 8 >= BM) continue;
             if constexpr (CONV) {
                 int tt = ct[j] + dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);      // replicate pad on T (vae.rs:374-413)
-                if (k < Kdim && (vmask[j] & vbit) == vbit)                                   // zero pad on H/W (vae.rs:337-349)
-                    src = reinterpret_cast<const unsigned char*>(A + a_off[j] + (int64_t)(tt - ct[j]) * g.H * g.Wd * g.Cin + hw_delta + k);
+                ok = ok && (vmask[j] & vbit) == vbit;                                        // zero pad on H/W (vae.rs:337-349)
+                const uint32_t voff = a_off[j] + (uint32_t)(tt - ct[j]) * frame_bytes + a_soff;
+                dma(ra, ok ? voff : OOB, 0u, As + (j * NW + wave) * 1024);
             } else {
-                if (k < Kdim) src = reinterpret_cast<const unsigned char*>(A + a_off[j] + k);
+                dma(ra, ok ? a_off[j] : OOB, a_soff, As + (j * NW + wave) * 1024);
             }
-            if (!A_RAGGED || (j * NW + wave) * 8 < BM) glds16(src, As + (j * NW + wave) * 1024);
         }
+        const uint32_t b_soff = ((uint32_t)tap * (uint32_t)g.N * (uint32_t)Kdim + (uint32_t)kk * 64u) * 2u;
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const int k = kk * 64 + b_chunk[j] * 8;
-            const unsigned char* src = zero;
-            if (k < Kdim) src = reinterpret_cast<const unsigned char*>(W + (int64_t)tap * g.N * Kdim + b_off[j] + k);
-            glds16(src, Bs + (j * NW + wave) * 1024);
+            const bool ok = kk * 64 + b_chunk[j] * 8 < Kdim;
+            dma(rw, ok ? b_off[j] : OOB, b_soff, Bs + (j * NW + wave) * 1024);
         }
     };
 
@@ -265,6 +264,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     const char* off = getenv("LTX_GEMM_BIG");
     if (off && off[0] == '0') return false;
     if (g.conv && (g.kh > 3 || g.kw > 3)) return false;   // the validity mask covers 3x3 (and 1x1) spatial taps
+    if (!ltx_gemm_p8_fits(g)) return false;               // 32-bit buffer offsets: operands < 2 GiB (else gemm.hip's kernel)
     return g.M >= 1024 && g.N >= 32;
 }
 
