@@ -21,6 +21,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef ATTN_DMA
+#define ATTN_DMA 1
+#endif
 namespace {
 
 constexpr int BQ = 128, BKV = 64;
@@ -48,7 +51,11 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     constexpr int NDB = HDP / 32;                    // 32-row d blocks of O^T
     constexpr int KCH = (BKV * KCPR + 255) / 256, VCH = (BKV * VCV + 255) / 256;
     constexpr int TILE_BYTES = BKV * (KROW + VROW);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    // DMA: K/V tiles go global -> LDS with buffer_load ... lds into a ring of three tiles (the load of tile t+2 is in
+    // flight while t is multiplied; no staging registers, no ds_write pass); otherwise register-staged double buffer.
+    constexpr bool DMA = PRE && HD == 64 && ATTN_DMA;
+    constexpr int NBUF = DMA ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -134,8 +141,45 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     for (int i = 0; i < 16; ++i) minit[i] = 0.f;
 
     const int nt = (a.Sk + BKV - 1) / BKV;
-    gload(0); swrite(0);
-    __syncthreads();
+    // ---- DMA staging geometry (HD = 64: 8 pieces of 8 rows x 128 B per K tile and per V tile; wave w issues pieces 2w, 2w+1)
+    // lane -> row (lane>>3) of the piece, physical 16-B chunk lane&7; the LDS image is lane-linear, so the bank swizzles
+    // of the tile (kswz / vswz, both involutions) are applied to the SOURCE chunk.  Rows past Sk are out of range of the
+    // buffer descriptor and read as zeros (masked again by the tail path).
+    __amdgpu_buffer_rsrc_t rk_rsrc, rv_rsrc;
+    uint32_t k_voff[2], v_voff[2];
+    if constexpr (DMA) {
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
+        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
+        rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
+        rv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + (lane >> 3), pc = lane & 7;
+            k_voff[j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
+            v_voff[j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
+        }
+    }
+    auto dma_tile = [&](int t, int buf) {
+        if constexpr (DMA) {
+            unsigned char* Ks = smem + buf * TILE_BYTES;
+            unsigned char* Vs = Ks + BKV * KROW;
+            const uint32_t ks = (uint32_t)t * BKV * (uint32_t)a.ldk * 2u, vs = (uint32_t)t * BKV * (uint32_t)a.ldv * 2u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_rsrc, (__attribute__((address_space(3))) void*)(Ks + (wave * 2 + j) * 1024), 16, (int)k_voff[j], (int)ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv_rsrc, (__attribute__((address_space(3))) void*)(Vs + (wave * 2 + j) * 1024), 16, (int)v_voff[j], (int)vs, 0, 0);
+            }
+        }
+    };
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+        if (nt > 1) { dma_tile(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        gload(0); swrite(0);
+        __syncthreads();
+    }
 
     // tr-read lane geometry (see header): 16-lane group g = lane>>4 -> (h = g>>1, d-half = g&1)
     const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
@@ -151,8 +195,9 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     constexpr float RESCALE_THR = 5.0f;
     auto tile_body = [&](int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        const int buf = DMA ? t % 3 : (t & 1);
+        if constexpr (DMA) { if (t + 2 < nt) dma_tile(t + 2, (t + 2) % 3); }
+        else if (t + 1 < nt) gload(t + 1);
         const unsigned char* Ks = smem + buf * TILE_BYTES;
         const unsigned char* Vs = Ks + BKV * KROW;
         const int kv0 = t * BKV;
@@ -253,8 +298,14 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
                     acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], acc_o[d], 0, 0, 0);
                 }
         }
-        if (t + 1 < nt) swrite(buf ^ 1);
-        __syncthreads();
+        if constexpr (DMA) {
+            // tile t+1 (issued one tile ago) must have landed for every wave; tile t+2's four pieces may stay in flight
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (t + 1 < nt) swrite(buf ^ 1);
+            __syncthreads();
+        }
     };
     const bool ragged = (a.Sk % BKV) != 0;
     for (int t = 0; t < nt - 1; ++t) tile_body(t, std::false_type{});

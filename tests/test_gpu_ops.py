@@ -323,3 +323,18 @@ def test_attention_prescaled_q(hip, Sq, Sk):
     # and it is the same function as the generic kernel up to the single extra rounding of q
     o2 = hip.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, 0.125)
     assert rel_l2(o.float().cpu(), o2.float().cpu()) <= 2 * BF16_TOL
+
+
+def test_attention_prescaled_dma_ring_screen(hip):
+    """The fast path stages K/V with LDS-DMA into a 3-tile ring synchronised by counted vmcnt + raw barriers: screen it
+    over ragged/odd sizes and repeated launches against the register-staged generic kernel (rare-race detector)."""
+    g = torch.Generator().manual_seed(77)
+    heads, hd = 8, 64
+    for it in range(24):
+        Sq = int(torch.randint(1, 700, (1,), generator=g)); Sk = int(torch.randint(1, 1700, (1,), generator=g))
+        q, k, v = [torch.randn(1, s, heads * hd, generator=g).bfloat16().cuda() for s in (Sq, Sk, Sk)]
+        qp = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
+        ref = hip.ops.attention(q, k, v, heads, 0.125).float()
+        outs = [hip.ops.attention_prescaled(qp, k, v, heads).float() for _ in range(3)]
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), (Sq, Sk)       # deterministic
+        assert rel_l2(outs[0].cpu(), ref.cpu()) <= 2 * BF16_TOL, (Sq, Sk, rel_l2(outs[0].cpu(), ref.cpu()))
