@@ -38,9 +38,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     const int ntn = (g.N + BN - 1) / BN;
     // XCD-aware tile order (speed only, bijective for any grid): blocks b and b+8 share an XCD/L2, so XCD x is
     // given a CONTIGUOUS run of tiles -> neighbouring tiles (shared A rows / conv halos / W columns) hit one L2.
+    // Tail split (g.sk_sf > 1): the first g.sk_full blocks each own a whole tile; the tiles of the last, partly filled
+    // round are cut into sk_sf K-ranges ("parts") so that the round fills the chip; the parts of a tile meet in an
+    // in-launch reduction (below).  The XCD remap covers the whole-tile region only.
     int bid = blockIdx.x;
-    if (g.xcd_remap) {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    int part = 0;
+    const bool split = g.sk_sf > 1 && bid >= g.sk_full;
+    if (split) {
+        const int p = bid - g.sk_full;
+        bid = g.sk_full + p / g.sk_sf; part = p - (p / g.sk_sf) * g.sk_sf;
+    } else if (g.xcd_remap) {
+        const int nblk = g.sk_sf > 1 ? g.sk_full : (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int mt = bid / ntn, nt = bid - mt * ntn;
@@ -132,13 +140,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
+    const int kt0 = split ? (int)((int64_t)part * nk / g.sk_sf) : 0;
+    const int kt1 = split ? (int)((int64_t)(part + 1) * nk / g.sk_sf) : nk;
+    stage(kt0, 0);
     __syncthreads();                                   // emits vmcnt(0) for the outstanding LDS-DMA
 
     const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
         const unsigned char* As = big_smem + buf * STAGE;
         const unsigned char* Bs = As + BM * ROWB;
         // Fragment stream: W fragments of the k-block stay in registers, A fragments are read ONE AHEAD of the
@@ -171,6 +181,57 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         __syncthreads();
     }
 
+    if (split) {
+        // In-launch reduction of a tile's parts: every part stores its f32 accumulators to its slab (fragment-major,
+        // 16 B per lane: fully coalesced), publishes with ONE agent-scope release + a relaxed counter increment; the part
+        // that draws the last ticket acquires once, adds the other slabs to its registers and runs the epilogue.
+        constexpr int SLAB = BM * BN;                                  // floats
+        const int tt = bid - g.sk_full;
+        float* slab = g.sk_ws + ((int64_t)tt * g.sk_sf + part) * SLAB;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) *reinterpret_cast<f32x4*>(slab + ((fm * FN + fn) * (64 * NW) + tid) * 4) = acc[fm][fn];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(big_smem);       // all LDS tile reads are behind the barrier above
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(g.sk_cnt + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)g.sk_sf - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // leave the counter at zero for the next launch on this stream (the workspace is zeroed once, at allocation)
+                __hip_atomic_store(g.sk_cnt + tt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        // canonical order ((s0 + s1) + s2) + ... whichever part happens to be the reducer: results do not depend on timing
+        // (its own slab is re-read from memory when it is not part 0; two parts need no re-read, a + b == b + a)
+        const float* base = g.sk_ws + (int64_t)tt * g.sk_sf * SLAB;
+        const bool reread_own = g.sk_sf > 2 && part != 0;
+        if (reread_own) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = *reinterpret_cast<const f32x4*>(base + ((fm * FN + fn) * (64 * NW) + tid) * 4);
+        }
+        for (int p = (reread_own || part == 0) ? 1 : 0; p < g.sk_sf; ++p) {
+            if (p == part && !reread_own) continue;
+            const float* other = base + (int64_t)p * SLAB;
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(other + ((fm * FN + fn) * (64 * NW) + tid) * 4);
+                    acc[fm][fn] += o;
+                }
+        }
+    }
+
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * WM + fm * 16 + frow;
@@ -185,6 +246,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     }
 }
 
+// ---- tail split-K planning + workspace ---------------------------------------------------------------------------
+// slots = blocks the chip holds at once for this tile (LDS- and thread-limited).  T tiles = `full` whole rounds + a tail of
+// `tail` tiles; when the tail would leave most of the chip idle, each tail tile is cut into sf K-ranges (parts).
+struct SplitWs { void* slabs = nullptr; size_t slab_bytes = 0; void* cnt = nullptr; size_t cnt_bytes = 0; };
+std::map<hipStream_t, SplitWs> g_split_ws;     // one workspace per stream: launches on a stream are ordered
+std::mutex g_split_mu;
+
+int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int smem, hipStream_t s) {
+    g->sk_sf = 1; g->sk_full = tiles;
+    const char* e = getenv("LTX_GEMM_SPLITK");
+    if (e && e[0] == '0') return LTX_OK;
+    int per_cu = (160 * 1024) / smem; const int by_threads = 2048 / threads;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    const int slots = 256 * per_cu;
+    // Measured on MI355X: cutting the partly filled LAST round of a multi-round grid loses (qkv/ff1 -4..-16 %: blocks of a
+    // thin last round already run ~1.6x faster alone on their CU, and the slab/fence/ticket episode costs more than that
+    // leaves); a grid that cannot even half-fill the chip gains (VAE mid-block conv, 256 tiles of 27648-deep K: +11 %).
+    if (tiles * 2 > slots) return LTX_OK;
+    const int full = 0, tail = tiles;
+    const int nk = (g->K + 63) / 64 * (g->conv ? g->ntaps : 1);
+    int sf = slots / tail;
+    if (sf > 8) sf = 8;
+    while (sf > 1 && nk / sf < 8) --sf;                // every part keeps at least 8 K-steps
+    if (sf < 2) return LTX_OK;
+    const size_t slab_bytes = (size_t)tail * sf * bm * bn * sizeof(float), cnt_bytes = (size_t)tail * sizeof(unsigned);
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    SplitWs& w = g_split_ws[s];
+    if (w.slab_bytes < slab_bytes) { if (w.slabs) (void)hipFree(w.slabs); w.slabs = nullptr; HIP_TRY(hipMalloc(&w.slabs, slab_bytes)); w.slab_bytes = slab_bytes; }
+    if (w.cnt_bytes < cnt_bytes) {
+        const size_t nb = cnt_bytes < 4096 ? 4096 : cnt_bytes;
+        if (w.cnt) (void)hipFree(w.cnt);
+        w.cnt = nullptr; HIP_TRY(hipMalloc(&w.cnt, nb)); w.cnt_bytes = nb;
+        HIP_TRY(hipMemsetAsync(w.cnt, 0, nb, s));      // once: every reducer hands its counter back at zero
+    }
+    g->sk_sf = sf; g->sk_full = full; g->sk_ws = reinterpret_cast<float*>(w.slabs); g->sk_cnt = reinterpret_cast<unsigned*>(w.cnt);
+    return LTX_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
@@ -195,8 +295,11 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN))), block(64 * WGM * WGN);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, g);
+    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+    GemmArgs ga = g;
+    LTX_TRY(plan_tail_split(&ga, tiles, BM, BN, 64 * WGM * WGN, smem, s));
+    dim3 grid((unsigned)(ga.sk_sf > 1 ? ga.sk_full + (tiles - ga.sk_full) * ga.sk_sf : tiles)), block(64 * WGM * WGN);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

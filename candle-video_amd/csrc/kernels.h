@@ -32,6 +32,10 @@ struct GemmArgs {
     // D2S / UNPATCH
     int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
+    // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
+    int sk_full = 0, sk_sf = 1;
+    float* sk_ws = nullptr;       // f32 slabs [tail tile][part][BM*BN]
+    unsigned* sk_cnt = nullptr;   // arrival counters [tail tile], zeroed before the launch
 };
 int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
 // large-tile LDS-DMA bf16 variant (gemm_big.hip); ltx_launch_gemm dispatches to it when eligible
