@@ -367,3 +367,20 @@ def test_gemm_tail_split_k(hip, tile, monkeypatch):
     if tile != "192x64" and tile != "256x256":              # N = 64 needs a 128-wide tile here
         y = hip.ops.conv3d(xc, wc, bc)
         check(ncthw(y), O.causal_conv3d(ncthw(xc).float().cpu(), wc.float().cpu(), bc.float().cpu(), False), dt)
+
+
+def test_split_k_reduction_stress_full_size_mid_block(hip):
+    """The VAE mid-block conv at C2 size (M = 4992, N = 1024, K = 27 x 1024) is the production user of the split-K
+    reduction: 150 launches must reproduce the first bit for bit (canonical sum order, slabs published/acquired across
+    XCDs) and match a CPU f32 conv on a halo'd crop."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 1024, 13, 16, 24, generator=g).bfloat16()
+    w = (torch.randn(1024, 1024, 3, 3, 3, generator=g) / 166).bfloat16(); b = torch.randn(1024, generator=g).bfloat16()
+    xc, wc, bc = cl(x).cuda(), w.cuda(), b.cuda()
+    first = hip.ops.conv3d(xc, wc, bc)
+    for _ in range(150):
+        assert torch.equal(hip.ops.conv3d(xc, wc, bc), first)
+    y = ncthw(first).float().cpu()
+    crop = x[:, :, 4:9, 3:10, 5:14].float()
+    ref = O.causal_conv3d(crop, w.float(), b.float(), False)
+    assert rel_l2(y[:, :, 5:8, 4:9, 6:13], ref[:, :, 1:4, 1:6, 1:8]) <= 1.5e-2
