@@ -1,0 +1,226 @@
+// T5 v1.1 encoder on the path's kernels (include/ltxhip_t5.h).  Per layer: T5LayerNorm (rownorm RMS + weight) -> fused
+// q|k|v GEMM -> attention with the shared [H,S,S] relative-position bias (unscaled scores, f32 softmax) -> o GEMM + h ->
+// T5LayerNorm -> fused wi_0|wi_1 GEMM -> NewGelu(a)*b -> wo GEMM + h.  The prompt is <= 512 tokens, so the attention is a
+// small exact-f32 kernel (one query per lane); the GEMMs are the DiT's.
+#include <memory>
+#include <string>
+#include <vector>
+#include "model_util.h"
+#include "../../include/ltxhip_t5.h"
+
+struct ltx_t5 {
+    ltx_t5_config cfg;
+    int dtype = LTX_DT_BF16, device = 0;
+    std::vector<void*> owned;
+    void* embed = nullptr;              // [vocab, d_model]
+    float* rel_table = nullptr;         // f32 [buckets, H]
+    struct Layer { LinearW qkv, o, wi, wo; void *ln0 = nullptr, *ln1 = nullptr; };
+    std::vector<Layer> layers;
+    void* final_ln = nullptr;
+    DevBuf ids, h, n, qkv, att, ff, act, bias;
+    ~ltx_t5() { for (void* p : owned) (void)hipFree(p); ids.release(); h.release(); n.release(); qkv.release(); att.release(); ff.release(); act.release(); bias.release(); }
+};
+
+namespace {
+
+template <typename T>
+__global__ void t5_embed_kernel(const int* ids, const T* table, T* out, int64_t rows, int D, int vocab) {
+    const int64_t n = rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D; int id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        out[i] = table[(int64_t)id * D + (i - r * D)];
+    }
+}
+
+// position_bias[h][i][j] = table[bucket(j - i)][h]   (T5Attention._relative_position_bucket, bidirectional)
+__global__ void t5_bias_kernel(const float* table, float* bias, int H, int S, int num_buckets, int max_distance) {
+    const int64_t n = (int64_t)H * S * S;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % S); const int i = (int)((idx / S) % S); const int h = (int)(idx / ((int64_t)S * S));
+        const int rel = j - i;
+        const int nb = num_buckets / 2, max_exact = nb / 2;
+        int b = rel > 0 ? nb : 0;
+        const int a = rel < 0 ? -rel : rel;
+        if (a < max_exact) b += a;
+        else {
+            int large = max_exact + (int)(logf((float)a / (float)max_exact) / logf((float)max_distance / (float)max_exact) * (float)(nb - max_exact));
+            b += large < nb - 1 ? large : nb - 1;
+        }
+        bias[idx] = table[(int64_t)b * H + h];
+    }
+}
+
+// gated NewGelu: act[m][j] = gelu_tanh(ff[m][j]) * ff[m][d_ff + j]
+template <typename T>
+__global__ void t5_gate_kernel(const T* ff, T* act, int64_t rows, int dff) {
+    const int64_t n = rows * dff;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dff; const int64_t j = i - r * dff;
+        const float a = (float)ff[r * 2 * dff + j], b = (float)ff[r * 2 * dff + dff + j];
+        act[i] = (T)(gelu_tanh_f(a) * b);
+    }
+}
+
+// exact-f32 attention with a per-head [S,S] bias: block = (64 queries, head, batch), one query per lane, K/V tiles in LDS
+template <typename T, int HD>
+__global__ __launch_bounds__(64) void t5_attn_kernel(const T* qkv, const float* bias, T* out, int S, int H) {
+    constexpr int TK = 32;
+    __shared__ float Ks[TK][HD + 1];
+    __shared__ float Vs[TK][HD + 1];
+    const int lane = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int inner = H * HD, ld = 3 * inner;
+    int qi = blockIdx.x * 64 + lane;
+    const bool active = qi < S;
+    if (!active) qi = S - 1;
+    const T* base = qkv + (int64_t)b * S * ld + head * HD;
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = (float)base[(int64_t)qi * ld + d]; o[d] = 0.f; }
+    const float* brow = bias + ((int64_t)head * S + qi) * S;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < S; k0 += TK) {
+        __syncthreads();
+        for (int i = lane; i < TK * HD; i += 64) {
+            const int r = i / HD, d = i - r * HD;
+            int key = k0 + r; if (key > S - 1) key = S - 1;
+            Ks[r][d] = (float)base[(int64_t)key * ld + inner + d];
+            Vs[r][d] = (float)base[(int64_t)key * ld + 2 * inner + d];
+        }
+        __syncthreads();
+        const int jmax = S - k0 < TK ? S - k0 : TK;
+        for (int j = 0; j < jmax; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc += q[d] * Ks[j][d];
+            const float x = acc + brow[k0 + j];                      // no 1/sqrt(d) in T5
+            const float mn = fmaxf(m, x);
+            const float alpha = __expf(m - mn), p = __expf(x - mn);
+            m = mn; l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] = o[d] * alpha + p * Vs[j][d];
+        }
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        T* op = out + ((int64_t)b * S + qi) * inner + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = (T)(o[d] * inv);
+    }
+}
+
+int own_tensor(ltx_t5* m, const WeightMap& wm, const std::string& name, int64_t numel, int dtype, void** out) {
+    LTX_TRY(ltx_load_tensor(wm, name, numel, dtype, out));
+    m->owned.push_back(*out);
+    return LTX_OK;
+}
+int own_fused(ltx_t5* m, const WeightMap& wm, const std::vector<std::string>& names, int in, int out_each, LinearW* l) {
+    const size_t esz = ltx_dt_size(m->dtype);
+    l->in = in; l->out = out_each * (int)names.size(); l->b = nullptr;
+    HIP_TRY(hipMalloc(&l->w, (size_t)l->out * in * esz)); m->owned.push_back(l->w);
+    for (size_t i = 0; i < names.size(); ++i) {
+        const ltx_weight* w = wm.find(names[i]);
+        if (!w) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + names[i] + "'");
+        LTX_TRY(ltx_upload_cast(w, (char*)l->w + i * (size_t)out_each * in * esz, m->dtype, (int64_t)out_each * in, names[i]));
+    }
+    return LTX_OK;
+}
+
+template <typename T>
+int run_attn(const ltx_t5* m, const void* qkv, const float* bias, void* out, int B, int S, hipStream_t s) {
+    dim3 grid((unsigned)cdiv(S, 64), (unsigned)m->cfg.num_heads, (unsigned)B), block(64);
+    switch (m->cfg.d_kv) {
+        case 32: hipLaunchKernelGGL((t5_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
+        case 64: hipLaunchKernelGGL((t5_attn_kernel<T, 64>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
+        case 8: hipLaunchKernelGGL((t5_attn_kernel<T, 8>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
+        case 16: hipLaunchKernelGGL((t5_attn_kernel<T, 16>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
+        default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "t5: d_kv must be 8, 16, 32 or 64");
+    }
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+}  // namespace
+
+extern "C" void ltx_t5_config_default(ltx_t5_config* c) {
+    if (!c) return;
+    c->vocab_size = 32128; c->d_model = 4096; c->d_kv = 64; c->d_ff = 10240; c->num_layers = 24; c->num_heads = 64;
+    c->relative_attention_num_buckets = 32; c->relative_attention_max_distance = 128; c->layer_norm_epsilon = 1e-6f;
+}
+
+extern "C" int ltx_t5_create(const ltx_t5_config* cfg, const ltx_weight* weights, size_t n_weights,
+                             ltx_dtype model_dtype, int device, ltx_t5** out) {
+    if (!cfg || !weights || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create: null argument");
+    *out = nullptr;
+    const int D = cfg->d_model, inner = cfg->num_heads * cfg->d_kv;
+    if (cfg->num_layers < 1 || D % 8 || inner % 8 || cfg->d_ff % 8 || cfg->relative_attention_num_buckets < 4)
+        LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create: d_model, heads*d_kv and d_ff must be multiples of 8");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<ltx_t5> m(new ltx_t5());
+    m->cfg = *cfg; m->device = device; m->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32;
+    WeightMap wm(weights, n_weights);
+    LTX_TRY(own_tensor(m.get(), wm, "shared.weight", (int64_t)cfg->vocab_size * D, m->dtype, &m->embed));
+    void* rt = nullptr;
+    LTX_TRY(own_tensor(m.get(), wm, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+                       (int64_t)cfg->relative_attention_num_buckets * cfg->num_heads, LTX_DT_F32, &rt));
+    m->rel_table = reinterpret_cast<float*>(rt);
+    m->layers.resize(cfg->num_layers);
+    for (int i = 0; i < cfg->num_layers; ++i) {
+        const std::string p = "encoder.block." + std::to_string(i) + ".layer.";
+        ltx_t5::Layer& L = m->layers[i];
+        LTX_TRY(own_fused(m.get(), wm, {p + "0.SelfAttention.q.weight", p + "0.SelfAttention.k.weight", p + "0.SelfAttention.v.weight"}, D, inner, &L.qkv));
+        LTX_TRY(own_fused(m.get(), wm, {p + "0.SelfAttention.o.weight"}, inner, D, &L.o));
+        LTX_TRY(own_tensor(m.get(), wm, p + "0.layer_norm.weight", D, m->dtype, &L.ln0));
+        LTX_TRY(own_fused(m.get(), wm, {p + "1.DenseReluDense.wi_0.weight", p + "1.DenseReluDense.wi_1.weight"}, D, cfg->d_ff, &L.wi));
+        LTX_TRY(own_fused(m.get(), wm, {p + "1.DenseReluDense.wo.weight"}, cfg->d_ff, D, &L.wo));
+        LTX_TRY(own_tensor(m.get(), wm, p + "1.layer_norm.weight", D, m->dtype, &L.ln1));
+    }
+    LTX_TRY(own_tensor(m.get(), wm, "encoder.final_layer_norm.weight", D, m->dtype, &m->final_ln));
+    *out = m.release();
+    return LTX_OK;
+}
+
+extern "C" void ltx_t5_destroy(ltx_t5* m) { delete m; }
+
+extern "C" int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S, ltx_dtype out_dtype, void* out, ltx_stream stream) {
+    if (!m || !input_ids || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_forward: null argument");
+    if (B < 1 || S < 1 || S > 512) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_forward: need B >= 1 and 1 <= S <= 512");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const ltx_t5_config& c = m->cfg;
+    const int D = c.d_model, H = c.num_heads, inner = H * c.d_kv, dt = m->dtype;
+    const int64_t M = (int64_t)B * S; const size_t esz = ltx_dt_size(dt);
+    LTX_TRY(m->ids.ensure(M * sizeof(int))); LTX_TRY(m->h.ensure(M * D * esz)); LTX_TRY(m->n.ensure(M * D * esz));
+    LTX_TRY(m->qkv.ensure(M * 3 * inner * esz)); LTX_TRY(m->att.ensure(M * inner * esz));
+    LTX_TRY(m->ff.ensure(M * 2 * c.d_ff * esz)); LTX_TRY(m->act.ensure(M * c.d_ff * esz));
+    LTX_TRY(m->bias.ensure((size_t)H * S * S * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(m->ids.p, input_ids, M * sizeof(int), hipMemcpyHostToDevice, s));
+    const int blocks = (int)((M * D + 255) / 256 > 4096 ? 4096 : (M * D + 255) / 256);
+    if (dt == LTX_DT_BF16) hipLaunchKernelGGL((t5_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, m->ids.as<int>(), (const bf16_t*)m->embed, m->h.as<bf16_t>(), M, D, c.vocab_size);
+    else hipLaunchKernelGGL((t5_embed_kernel<float>), dim3(blocks), dim3(256), 0, s, m->ids.as<int>(), (const float*)m->embed, m->h.as<float>(), M, D, c.vocab_size);
+    LTX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(t5_bias_kernel, dim3((unsigned)(((int64_t)H * S * S + 255) / 256)), dim3(256), 0, s, m->rel_table, m->bias.as<float>(), H, S,
+                       c.relative_attention_num_buckets, c.relative_attention_max_distance);
+    LTX_CHECK_LAUNCH();
+    RowNormArgs rn; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D; rn.kind = 0; rn.eps = c.layer_norm_epsilon; rn.rows_per_batch = M;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const ltx_t5::Layer& L = m->layers[i];
+        rn.x = m->h.p; rn.y = m->n.p; rn.weight = L.ln0;
+        LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        LTX_TRY(ltx_linear(L.qkv, m->n.p, D, m->qkv.p, 3 * inner, (int)M, dt, EPI_BIAS, s));
+        if (dt == LTX_DT_BF16) LTX_TRY(run_attn<bf16_t>(m, m->qkv.p, m->bias.as<float>(), m->att.p, B, S, s));
+        else LTX_TRY(run_attn<float>(m, m->qkv.p, m->bias.as<float>(), m->att.p, B, S, s));
+        LTX_TRY(ltx_linear(L.o, m->att.p, inner, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
+        rn.x = m->h.p; rn.y = m->n.p; rn.weight = L.ln1;
+        LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        LTX_TRY(ltx_linear(L.wi, m->n.p, D, m->ff.p, 2 * c.d_ff, (int)M, dt, EPI_BIAS, s));
+        const int gb = (int)((M * c.d_ff + 255) / 256 > 8192 ? 8192 : (M * c.d_ff + 255) / 256);
+        if (dt == LTX_DT_BF16) hipLaunchKernelGGL((t5_gate_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, m->ff.as<bf16_t>(), m->act.as<bf16_t>(), M, c.d_ff);
+        else hipLaunchKernelGGL((t5_gate_kernel<float>), dim3(gb), dim3(256), 0, s, m->ff.as<float>(), m->act.as<float>(), M, c.d_ff);
+        LTX_CHECK_LAUNCH();
+        LTX_TRY(ltx_linear(L.wo, m->act.p, c.d_ff, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
+    }
+    rn.x = m->h.p; rn.y = m->n.p; rn.weight = m->final_ln;
+    LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    return ltx_launch_cast(m->n.p, dt, out, out_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32, M * D, s);
+}

@@ -114,6 +114,9 @@ _SIGS = {
     "ltx_op_conv_out_unpatchify": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_gemm_plan": [_i, _i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
+    # include/ltxhip_t5.h
+    "ltx_t5_config_default": [_vp], "ltx_t5_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_t5_destroy": [_vp],
+    "ltx_t5_forward": [_vp, _vp, _i, _i, _i, _vp, _vp],
     # include/ltxhip_weights.h
     "ltx_weights_detect_format": [C.c_char_p], "ltx_weights_remap_key": [C.c_char_p, C.c_char_p, _sz],
     "ltx_weights_is_transformer_key": [C.c_char_p], "ltx_weights_is_vae_key": [C.c_char_p],
@@ -221,7 +224,7 @@ class LtxVideoTransformer3DModel:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib.ltx_dit_destroy(h)
             self._h = None
 
@@ -272,6 +275,55 @@ class LtxVideoTransformer3DModel:
         out = torch.empty(B, S, self.config.out_channels, dtype=io, device=h.device)
         _check(lib.ltx_dit_forward(self._h, _ptr(h), _ptr(e), _floats(t), _ptr(m), B, S, K, num_frames, height, width,
                                    rs, _ptr(vc), slm, _dt(io), _ptr(out), _stream()))
+        return out
+
+
+# ------------------------------------------------------------------ T5 text encoder (include/ltxhip_t5.h)
+class T5ConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("d_model", C.c_int), ("d_kv", C.c_int), ("d_ff", C.c_int), ("num_layers", C.c_int),
+                ("num_heads", C.c_int), ("relative_attention_num_buckets", C.c_int), ("relative_attention_max_distance", C.c_int),
+                ("layer_norm_epsilon", C.c_float)]
+
+
+@dataclass
+class T5EncoderConfig:                           # text_encoder.rs:66-113; defaults = t5_xxl() (:169-184)
+    vocab_size: int = 32128
+    d_model: int = 4096
+    d_kv: int = 64
+    d_ff: int = 10240
+    num_layers: int = 24
+    num_heads: int = 64
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+
+
+class T5TextEncoder:
+    """impl VTextEncoder (text_encoder.rs:597-606) over ltx_t5_*: forward(input_ids) -> [B,S,d_model] in the model dtype."""
+
+    def __init__(self, config: T5EncoderConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16, device: int = 0):
+        self.config, self.dtype = config, dtype
+        c = T5ConfigC(config.vocab_size, config.d_model, config.d_kv, config.d_ff, config.num_layers, config.num_heads,
+                      config.relative_attention_num_buckets, config.relative_attention_max_distance, config.layer_norm_epsilon)
+        arr, keep = _make_weights(weights)
+        self._h = C.c_void_p()
+        _check(lib.ltx_t5_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and lib is not None:                    # `lib` is already None when the interpreter is shutting down
+            lib.ltx_t5_destroy(h)
+            self._h = None
+
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        ids = input_ids.detach().to("cpu", torch.int32).contiguous()
+        if ids.dim() != 2:
+            raise LtxError("input_ids must be [B, S]")
+        B, S = ids.shape
+        out = torch.empty(B, S, self.config.d_model, dtype=self.dtype, device=torch.device("cuda", torch.cuda.current_device()))
+        _check(lib.ltx_t5_forward(self._h, C.c_void_p(ids.data_ptr()), B, S, _dt(self.dtype), _ptr(out), _stream()))
+        torch.cuda.current_stream().synchronize()       # the ids were read from host memory asynchronously
         return out
 
 
@@ -350,7 +402,7 @@ class AutoencoderKLLtxVideo:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib.ltx_vae_destroy(h)
             self._h = None
 

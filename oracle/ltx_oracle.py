@@ -34,6 +34,9 @@ scripts need `diffusers` + real checkpoints (absent).  Therefore:
     library implementation (F.conv3d with replicate/zero padding, F.scaled_dot_
     product_attention, F.rms_norm, F.layer_norm, F.gelu(tanh), F.pixel_shuffle
     style einops rearranges) in `tests/test_oracle.py`;
+  * the T5 encoder restatement (the reference wraps candle-transformers' port of
+    Hugging Face T5) is PINNED against `transformers.T5EncoderModel` on shared
+    random weights (`tests/test_t5_cpu.py`);
   * for the full DiT forward / VAE decode numbers: **parity unpinned** against
     the reference binary (no reference-produced vectors exist anywhere).
 """
@@ -1018,3 +1021,93 @@ def synth_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, dtype=torch
             w = torch.randn(shp, generator=g) / math.sqrt(fan_in)
         out[name] = w.to(dtype)
     return out
+
+
+# --------------------------------------------------------------------------
+# T5 v1.1 encoder (the step before the path)
+# --------------------------------------------------------------------------
+# The reference wraps `candle_transformers::models::t5::T5EncoderModel` (text_encoder.rs:315-345, 597-606; crates.io
+# candle-transformers ^0.9.2, absent from the checkout) configured by `to_candle_t5_config` (:222-249): gated NewGelu
+# feed-forward, bidirectional relative-position bias with 32 buckets / max distance 128, T5LayerNorm, no attention mask
+# (`VTextEncoder::forward(input_ids)` passes ids only, :600-604).  That model is a port of Hugging Face's T5: this
+# restatement follows the published algorithm and is PINNED against `transformers.T5EncoderModel` (installed here) on
+# shared random weights in tests/test_t5_cpu.py.
+
+@dataclass
+class T5Config:                       # text_encoder.rs:66-113, presets :169-203
+    vocab_size: int = 32128
+    d_model: int = 4096
+    d_kv: int = 64
+    d_ff: int = 10240
+    num_layers: int = 24
+    num_heads: int = 64
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+
+
+def t5_weight_shapes(cfg: T5Config) -> Dict[str, Tuple[int, ...]]:
+    inner = cfg.num_heads * cfg.d_kv
+    s: Dict[str, Tuple[int, ...]] = {"shared.weight": (cfg.vocab_size, cfg.d_model)}
+    for i in range(cfg.num_layers):
+        p = f"encoder.block.{i}.layer."
+        for n in "qkv":
+            s[p + f"0.SelfAttention.{n}.weight"] = (inner, cfg.d_model)
+        s[p + "0.SelfAttention.o.weight"] = (cfg.d_model, inner)
+        if i == 0:
+            s[p + "0.SelfAttention.relative_attention_bias.weight"] = (cfg.relative_attention_num_buckets, cfg.num_heads)
+        s[p + "0.layer_norm.weight"] = (cfg.d_model,)
+        s[p + "1.DenseReluDense.wi_0.weight"] = (cfg.d_ff, cfg.d_model)
+        s[p + "1.DenseReluDense.wi_1.weight"] = (cfg.d_ff, cfg.d_model)
+        s[p + "1.DenseReluDense.wo.weight"] = (cfg.d_model, cfg.d_ff)
+        s[p + "1.layer_norm.weight"] = (cfg.d_model,)
+    s["encoder.final_layer_norm.weight"] = (cfg.d_model,)
+    return s
+
+
+def t5_relative_position_bucket(rel: Tensor, num_buckets: int, max_distance: int) -> Tensor:
+    """Bidirectional bucketing (T5Attention._relative_position_bucket): rel = key_pos - query_pos."""
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float().clamp(min=1) / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, nb - 1))
+    return out + torch.where(is_small, n, large)
+
+
+def t5_position_bias(table: Tensor, S: int, num_buckets: int, max_distance: int) -> Tensor:
+    """[H, S, S] additive bias from relative_attention_bias.weight [buckets, H] (computed once, shared by all layers)."""
+    ctx = torch.arange(S)[:, None]; mem = torch.arange(S)[None, :]
+    bucket = t5_relative_position_bucket(mem - ctx, num_buckets, max_distance)
+    return table.float()[bucket].permute(2, 0, 1)
+
+
+def t5_layer_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    """T5LayerNorm: RMS without mean subtraction, variance in f32."""
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return (x.float() * torch.rsqrt(v + eps)).to(x.dtype) * w.to(x.dtype)
+
+
+def t5_encoder_forward(p: Dict[str, Tensor], cfg: T5Config, input_ids: Tensor, dtype=torch.float32) -> Tensor:
+    """T5EncoderModel.forward(input_ids) -> last hidden state [B, S, d_model]; no attention mask (reference behaviour)."""
+    B, S = input_ids.shape
+    H, dk = cfg.num_heads, cfg.d_kv
+    w = lambda k: p[k].to(dtype)
+    h = w("shared.weight")[input_ids]
+    bias = t5_position_bias(p["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], S,
+                            cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance)
+    for i in range(cfg.num_layers):
+        pre = f"encoder.block.{i}.layer."
+        n = t5_layer_norm(h, w(pre + "0.layer_norm.weight"), cfg.layer_norm_epsilon)
+        q = (n @ w(pre + "0.SelfAttention.q.weight").T).reshape(B, S, H, dk).transpose(1, 2)
+        k = (n @ w(pre + "0.SelfAttention.k.weight").T).reshape(B, S, H, dk).transpose(1, 2)
+        v = (n @ w(pre + "0.SelfAttention.v.weight").T).reshape(B, S, H, dk).transpose(1, 2)
+        sc = q.float() @ k.float().transpose(-1, -2) + bias[None]            # T5 does not scale by 1/sqrt(d_kv)
+        a = torch.softmax(sc, -1).to(dtype) @ v
+        h = h + a.transpose(1, 2).reshape(B, S, H * dk) @ w(pre + "0.SelfAttention.o.weight").T
+        n = t5_layer_norm(h, w(pre + "1.layer_norm.weight"), cfg.layer_norm_epsilon)
+        g = gelu_approximate(n @ w(pre + "1.DenseReluDense.wi_0.weight").T) * (n @ w(pre + "1.DenseReluDense.wi_1.weight").T)
+        h = h + g @ w(pre + "1.DenseReluDense.wo.weight").T
+    return t5_layer_norm(h, w("encoder.final_layer_norm.weight"), cfg.layer_norm_epsilon)

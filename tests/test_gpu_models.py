@@ -364,3 +364,37 @@ def test_c5_13b_geometry_ops_vs_cpu_slices(hip):
     y = hip.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), epi=1).float().cpu()
     r2 = torch.tensor([0, 255, 256, 9000, 17555])
     assert rel_l2(y[r2], O.gelu_approximate(x[r2].float() @ w.float().T + b.float())) <= 1.5e-2
+
+
+@pytest.mark.parametrize("mdt", [torch.float32, torch.bfloat16])
+def test_t5_encoder_matches_oracle(hip, mdt):
+    """T5 v1.1 encoder (include/ltxhip_t5.h) vs the oracle restatement that tests/test_t5_cpu.py pins against Hugging Face
+    transformers: f32 mode within 1e-3 of max; bf16 mode (bf16 storage, f32 accumulate) no further from the f32 oracle on
+    bf16-rounded weights than max(2 x the oracle's own per-op-bf16 evaluation, 2e-2) in rel-L2."""
+    cfg = O.T5Config(vocab_size=120, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_heads=4)
+    g = torch.Generator().manual_seed(3)
+    p = {}
+    for k, shp in O.t5_weight_shapes(cfg).items():
+        if "relative_attention_bias" in k:
+            p[k] = torch.randn(shp, generator=g)
+        elif len(shp) == 2:
+            p[k] = torch.randn(shp, generator=g) / shp[1] ** 0.5 * (4.0 if "SelfAttention.q" in k else 1.0)
+        else:
+            p[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+    if mdt == torch.bfloat16:
+        p = {k: v.bfloat16().float() for k, v in p.items()}
+    enc = hip.T5TextEncoder(hip.T5EncoderConfig(vocab_size=120, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_heads=4),
+                            {k: v.to(DEV) for k, v in p.items()}, mdt)
+    for S in (1, 7, 70, 300):
+        ids = torch.randint(0, 120, (2, S), generator=g)
+        want = O.t5_encoder_forward(p, cfg, ids)
+        got = enc.forward(ids).float().cpu()
+        assert got.shape == want.shape
+        if mdt == torch.float32:
+            assert rel_max(got, want) <= 1e-3, (S, rel_max(got, want))
+        else:
+            # same bar as the DiT: no further from the f32 oracle than twice the reference's own per-op-bf16 path is
+            d_ref = rel_l2(O.t5_encoder_forward(p, cfg, ids, torch.bfloat16).float(), want)
+            assert rel_l2(got, want) <= max(2.0 * d_ref, 2e-2), (S, rel_l2(got, want), d_ref)
+    with pytest.raises(hip.LtxError, match="S <= 512"):
+        enc.forward(torch.zeros(1, 600, dtype=torch.long))
