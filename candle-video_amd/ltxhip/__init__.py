@@ -117,6 +117,9 @@ _SIGS = {
     # include/ltxhip_t5.h
     "ltx_t5_config_default": [_vp], "ltx_t5_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_t5_destroy": [_vp],
     "ltx_t5_forward": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    # include/ltxhip_frames.h
+    "ltx_video_to_rgb8": [_vp, _i, _i, _i, _i, _vp, _vp], "ltx_write_png": [C.c_char_p, _vp, _i, _i],
+    "ltx_save_frames_png": [_vp, _i, _i, _i, _i, C.c_char_p, _vp, _vp],
     # include/ltxhip_weights.h
     "ltx_weights_detect_format": [C.c_char_p], "ltx_weights_remap_key": [C.c_char_p, C.c_char_p, _sz],
     "ltx_weights_is_transformer_key": [C.c_char_p], "ltx_weights_is_vae_key": [C.c_char_p],
@@ -652,6 +655,31 @@ class LtxPipeline:
         _check(lib.ltx_pipeline_last_timing(ms))
         self.last_timing_ms = tuple(ms)
         return lat, video
+
+
+# ------------------------------------------------------------------ frame output (include/ltxhip_frames.h)
+def video_to_rgb8(video: torch.Tensor) -> torch.Tensor:
+    """[B,3,F,H,W] f32 (0..255) -> [B,F,H,W,3] u8 on the device (main.rs:659-664: permute, clamp, truncating cast)."""
+    v = _dev(video, torch.float32)
+    B, _, F, H, W = v.shape
+    out = torch.empty(B, F, H, W, 3, dtype=torch.uint8, device=v.device)
+    _check(lib.ltx_video_to_rgb8(_ptr(v), B, F, H, W, _ptr(out), _stream()))
+    return out
+
+
+def write_png(path: str, rgb: torch.Tensor):
+    """HOST u8 [H,W,3] -> PNG file."""
+    t = rgb.detach().to("cpu", torch.uint8).contiguous()
+    _check(lib.ltx_write_png(path.encode(), C.c_void_p(t.data_ptr()), t.shape[1], t.shape[0]))
+
+
+def save_frames_png(video: torch.Tensor, out_dir: str) -> int:
+    """`--frames` output of examples/ltx-video/main.rs:653-675: out_dir/frame_%04d.png; returns the number written."""
+    v = _dev(video, torch.float32)
+    B, _, F, H, W = v.shape
+    n = C.c_int(0)
+    _check(lib.ltx_save_frames_png(_ptr(v), B, F, H, W, out_dir.encode(), C.byref(n), _stream()))
+    return n.value
 
 
 # ------------------------------------------------------------------ kernel-level ops (include/ltxhip_ops.h)

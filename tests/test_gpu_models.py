@@ -398,3 +398,17 @@ def test_t5_encoder_matches_oracle(hip, mdt):
             assert rel_l2(got, want) <= max(2.0 * d_ref, 2e-2), (S, rel_l2(got, want), d_ref)
     with pytest.raises(hip.LtxError, match="S <= 512"):
         enc.forward(torch.zeros(1, 600, dtype=torch.long))
+
+
+def test_frame_output_rgb8_and_png_files(hip, tmp_path):
+    """main.rs:653-675: [B,3,F,H,W] f32 -> per-frame HWC u8 (clamp, truncating cast) on the device, frame_%04d.png on disk."""
+    from test_frames_cpu import read_png
+    g = torch.Generator().manual_seed(4)
+    v = torch.rand(2, 3, 3, 10, 14, generator=g) * 300.0 - 20.0              # out-of-range values exercise the clamp
+    want = v.permute(0, 2, 3, 4, 1).clamp(0.0, 255.0).to(torch.uint8)
+    got = hip.video_to_rgb8(v.to(DEV))
+    assert torch.equal(got.cpu(), want)
+    n = hip.save_frames_png(v.to(DEV), str(tmp_path / "out"))
+    assert n == 6
+    for j in range(6):
+        assert torch.equal(read_png(str(tmp_path / "out" / f"frame_{j:04d}.png")), want.reshape(6, 10, 14, 3)[j])
