@@ -43,7 +43,7 @@ template <int CPR> __device__ __forceinline__ int vswz(int row, int c) {
 // tuple holding -m, rewritten only when the max moves), so the accumulator comes out as S - m and p = exp2(acc):
 // no per-score multiply/subtract and no per-tile accumulator zeroing.
 template <int HD, bool PRE>
-__global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void attn_bf16_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2))) void attn_bf16_kernel(const AttnArgs a) {
     constexpr int HDP = HD < 32 ? 32 : HD;          // padded head dim for the PV d-blocks
     constexpr int KROW = HD * 2, VROW = HDP * 2;    // bytes per LDS row
     constexpr int KCPR = KROW / 16, VCPR = VROW / 16, VCV = (HD * 2) / 16;  // chunks per row; valid V chunks
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     constexpr int TILE_BYTES = BKV * (KROW + VROW);
     // DMA: K/V tiles go global -> LDS with buffer_load ... lds into a ring of three tiles (the load of tile t+2 is in
     // flight while t is multiplied; no staging registers, no ds_write pass); otherwise register-staged double buffer.
-    constexpr bool DMA = PRE && HD == 64 && ATTN_DMA;
-    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr bool DMA = PRE && (HD == 64 || HD == 128) && ATTN_DMA;
+    constexpr int NBUF = (DMA && HD == 64) ? 3 : 2;            // head_dim 128: 32 KiB tiles, two of them (two blocks per CU)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,16 +145,19 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     // lane -> row (lane>>3) of the piece, physical 16-B chunk lane&7; the LDS image is lane-linear, so the bank swizzles
     // of the tile (kswz / vswz, both involutions) are applied to the SOURCE chunk.  Rows past Sk are out of range of the
     // buffer descriptor and read as zeros (masked again by the tail path).
+    constexpr int RPP = 1024 / KROW;                           // rows per 1-KiB DMA piece (8 at head_dim 64, 4 at 128)
+    constexpr int PW = DMA ? (BKV / RPP) / 4 : 1;              // pieces per wave per K tile (and per V tile)
+    constexpr int INFLIGHT = NBUF == 3 ? 2 * PW : 0;           // DMA instructions of the tile that may stay in flight
     __amdgpu_buffer_rsrc_t rk_rsrc, rv_rsrc;
-    uint32_t k_voff[2], v_voff[2];
+    uint32_t k_voff[PW], v_voff[PW];
     if constexpr (DMA) {
         const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
         const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
         rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
         rv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 8 + (lane >> 3), pc = lane & 7;
+        for (int j = 0; j < PW; ++j) {
+            const int row = (wave * PW + j) * RPP + lane / KCPR, pc = lane % KCPR;
             k_voff[j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
             v_voff[j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
         }
@@ -165,15 +168,15 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
             unsigned char* Vs = Ks + BKV * KROW;
             const uint32_t ks = (uint32_t)t * BKV * (uint32_t)a.ldk * 2u, vs = (uint32_t)t * BKV * (uint32_t)a.ldv * 2u;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_rsrc, (__attribute__((address_space(3))) void*)(Ks + (wave * 2 + j) * 1024), 16, (int)k_voff[j], (int)ks, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv_rsrc, (__attribute__((address_space(3))) void*)(Vs + (wave * 2 + j) * 1024), 16, (int)v_voff[j], (int)vs, 0, 0);
+            for (int j = 0; j < PW; ++j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_rsrc, (__attribute__((address_space(3))) void*)(Ks + (wave * PW + j) * 1024), 16, (int)k_voff[j], (int)ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv_rsrc, (__attribute__((address_space(3))) void*)(Vs + (wave * PW + j) * 1024), 16, (int)v_voff[j], (int)vs, 0, 0);
             }
         }
     };
     if constexpr (DMA) {
         dma_tile(0, 0);
-        if (nt > 1) { dma_tile(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        if (NBUF == 3 && nt > 1) { dma_tile(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     } else {
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
     constexpr float RESCALE_THR = 5.0f;
     auto tile_body = [&](int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int buf = DMA ? t % 3 : (t & 1);
-        if constexpr (DMA) { if (t + 2 < nt) dma_tile(t + 2, (t + 2) % 3); }
+        const int buf = NBUF == 3 ? t % 3 : (t & 1);
+        if constexpr (DMA) { if (t + NBUF - 1 < nt) dma_tile(t + NBUF - 1, (t + NBUF - 1) % NBUF); }
         else if (t + 1 < nt) gload(t + 1);
         const unsigned char* Ks = smem + buf * TILE_BYTES;
         const unsigned char* Vs = Ks + BKV * KROW;
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : (HD == 64 ? 3 : 2))) void att
                 }
         }
         if constexpr (DMA) {
-            // tile t+1 (issued one tile ago) must have landed for every wave; tile t+2's four pieces may stay in flight
-            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile t+1 must have landed for every wave; with the 3-tile ring tile t+2's pieces may stay in flight
+            if (NBUF == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
             if (t + 1 < nt) swrite(buf ^ 1);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 bool ltx_attention_prescale_ok(int hd) {
     const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
-    return hd == 64 && !(e && e[0] == '0');
+    return (hd == 64 || hd == 128) && !(e && e[0] == '0');
 }
 
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
@@ -413,14 +416,16 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         AttnArgs ax = a;
         const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)
         ax.xcd_heads = (a.heads % 8 == 0 && !(xe && xe[0] == '0')) ? 1 : 0;
-        if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 and no key bias");
+        if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
         switch (a.hd) {
             case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
             case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;
             case 64: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
                      else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);
                      break;
-            case 128: hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, ax); break;
+            case 128: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<128, true>), grid, block, 0, s, ax);
+                      else hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, ax);
+                      break;
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
         }
     } else {

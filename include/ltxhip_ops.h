@@ -37,7 +37,7 @@ int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F,
 /* LtxAttention core (ltx_transformer.rs:699-741): o = softmax(scale q k^T + bias) v, q [B,Sq,heads*hd] etc. */
 int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                      int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias, int dtype, ltx_stream stream);
-/* Same core for bf16, head_dim 64, no key bias, with q ALREADY multiplied by scale*log2(e) (the DiT self-attention
+/* Same core for bf16, head_dim 64 or 128, no key bias, with q ALREADY multiplied by scale*log2(e) (the DiT self-attention
  * path folds that factor into the q RMSNorm+RoPE kernel): o = softmax_base2(q' k^T) v. */
 int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                                int ldq, int ldk, int ldv, int ldo, ltx_stream stream);

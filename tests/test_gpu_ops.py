@@ -312,19 +312,21 @@ def test_gemm_plans_are_bit_identical_and_tuner_caches(hip, monkeypatch):
     assert hip.ops.gemm_plan(3 * 24 * 20, 128, 64, 1, 27, 3, 24, 20) != ""
 
 
+@pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("Sq,Sk", [(384, 384), (200, 333), (4992, 704)])
-def test_attention_prescaled_q(hip, Sq, Sk):
+def test_attention_prescaled_q(hip, Sq, Sk, hd):
     """DiT self-attention fast path: q' = bf16(q * scale*log2e) produced by the q-norm kernel, softmax in base 2 with the
     running max fed to the S^T MFMA chain as its initial accumulator.  Reference: f32 softmax of ln2 * (q' k^T)."""
-    heads, hd = 2, 64
+    heads = 2
+    sc = hd ** -0.5
     q, k, v = rnd(torch.bfloat16, 1, Sq, heads * hd), rnd(torch.bfloat16, 1, Sk, heads * hd, seed=1), rnd(torch.bfloat16, 1, Sk, heads * hd, seed=2)
     k[0, Sk - 3] = q[0, 5] * 6.0                        # late dominant key: forces the rescale branch on the last tile
-    qp = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
+    qp = (q.float() * (sc * 1.4426950408889634)).bfloat16()
     o = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
     ref = ref_attention(qp, k, v, heads, math.log(2.0), None)
     assert rel_l2(o.float().cpu(), ref) <= BF16_TOL, rel_l2(o.float().cpu(), ref)
     # and it is the same function as the generic kernel up to the single extra rounding of q
-    o2 = hip.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, 0.125)
+    o2 = hip.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, sc)
     assert rel_l2(o.float().cpu(), o2.float().cpu()) <= 2 * BF16_TOL
 
 
