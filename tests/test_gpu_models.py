@@ -412,3 +412,28 @@ def test_frame_output_rgb8_and_png_files(hip, tmp_path):
     assert n == 6
     for j in range(6):
         assert torch.equal(read_png(str(tmp_path / "out" / f"frame_{j:04d}.png")), want.reshape(6, 10, 14, 3)[j])
+
+
+def test_13b_width_dit_layer_bf16_vs_f32_mode(hip):
+    """One layer of the 13B geometry (D=4096, 32 heads x 128: the head_dim-128 prescaled/DMA attention path inside the
+    DiT, cross_attention_dim 4096) at S = 4*8*12: bf16 mode against the f32 mode of the same weights, and against the
+    oracle in f32."""
+    cfgd = dict(in_channels=128, out_channels=128, num_attention_heads=32, attention_head_dim=128, cross_attention_dim=4096,
+                num_layers=1, caption_channels=4096)
+    ocfg = O.DitConfig(**cfgd)
+    w = O.synth_weights(O.dit_weight_shapes(ocfg), seed=23)
+    wd = {k: v.to(DEV) for k, v in w.items()}
+    Fr, H, W = 4, 8, 12
+    S = Fr * H * W
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, S, 128, generator=g); enc = torch.randn(1, 16, 4096, generator=g)
+    mask = torch.zeros(1, 16); mask[:, :9] = 1
+    coords = O.build_video_coords(1, Fr, H, W)
+    want = O.dit_forward(w, ocfg, x, enc, torch.tensor([500.0]), mask, Fr, H, W, None, coords)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), wd, dt)
+        outs[dt] = m.forward(x.to(DEV), enc.to(DEV), [500.0], mask.to(DEV), Fr, H, W, None, coords.to(DEV)).float().cpu()
+        del m
+    assert rel_max(outs[torch.float32], want) <= 1e-3, rel_max(outs[torch.float32], want)
+    assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) <= 3e-2, rel_l2(outs[torch.bfloat16], outs[torch.float32])
