@@ -135,13 +135,21 @@ extern "C" int ltx_pipeline_last_timing(float ms[4]) {
 }
 
 namespace {
+// Device scratch of the denoise loop, kept per (thread, device) across calls: per-call hipMalloc/hipFree (an implicit
+// device sync each) and the coords rebuild + blocking upload cost ~1 ms per video for nothing.
+struct PipeCache {
+    DevBuf p_text, p_uncond, p_pert, stats, coords;
+    int coords_key[6] = {-1, -1, -1, -1, -1, -1};      // B, F, H, W, frame_rate, ratios packed
+};
+PipeCache& pipe_cache(int device) {
+    thread_local std::map<int, PipeCache> caches;
+    return caches[device];
+}
 struct PipeScratch {
-    void *p_text = nullptr, *p_uncond = nullptr, *p_pert = nullptr, *coords = nullptr, *stats = nullptr;
+    void *p_text = nullptr, *p_uncond = nullptr, *p_pert = nullptr, *coords = nullptr, *stats = nullptr;   // borrowed from PipeCache
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dit_ev, gs_ev;
     ~PipeScratch() {
-        void* ps[] = {p_text, p_uncond, p_pert, coords, stats};
-        for (void* p : ps) if (p) (void)hipFree(p);
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& pr : dit_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto& pr : gs_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -184,19 +192,26 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     LTX_TRY(ltx_sched_set_timesteps(sig_in.data(), N, mu, 1, 1.0f, p->shift_terminal, p->use_shift_terminal, sig.data(), ts.data()));
 
     PipeScratch sc;
+    int cur_dev = 0; HIP_TRY(hipGetDevice(&cur_dev));
+    PipeCache& pc = pipe_cache(cur_dev);
     const size_t pred_bytes = (size_t)B * n * sizeof(float);
-    HIP_TRY(hipMalloc(&sc.p_text, pred_bytes));
-    if (do_cfg) HIP_TRY(hipMalloc(&sc.p_uncond, pred_bytes));
-    if (do_stg) HIP_TRY(hipMalloc(&sc.p_pert, pred_bytes));
-    HIP_TRY(hipMalloc(&sc.stats, 64 * B));
-    // video_coords [B,S,3] (:798-847)
+    LTX_TRY(pc.p_text.ensure(pred_bytes)); sc.p_text = pc.p_text.p;
+    if (do_cfg) { LTX_TRY(pc.p_uncond.ensure(pred_bytes)); sc.p_uncond = pc.p_uncond.p; }
+    if (do_stg) { LTX_TRY(pc.p_pert.ensure(pred_bytes)); sc.p_pert = pc.p_pert.p; }
+    LTX_TRY(pc.stats.ensure(64 * B)); sc.stats = pc.stats.p;
+    // video_coords [B,S,3] (:798-847): rebuilt only when the geometry changes
     {
-        std::vector<float> vc((size_t)S * 3), all((size_t)B * S * 3);
-        LTX_TRY(ltx_build_video_coords(F, H, W, p->frame_rate, ts_ratio, sp_ratio, vc.data()));
-        for (int b = 0; b < B; ++b) std::memcpy(all.data() + (size_t)b * S * 3, vc.data(), sizeof(float) * S * 3);
-        HIP_TRY(hipMalloc(&sc.coords, all.size() * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(sc.coords, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        const int key[6] = {B, F, H, W, p->frame_rate, ts_ratio * 1000 + sp_ratio};
+        LTX_TRY(pc.coords.ensure((size_t)B * S * 3 * sizeof(float)));
+        if (std::memcmp(key, pc.coords_key, sizeof(key)) != 0) {
+            std::vector<float> vc((size_t)S * 3), all((size_t)B * S * 3);
+            LTX_TRY(ltx_build_video_coords(F, H, W, p->frame_rate, ts_ratio, sp_ratio, vc.data()));
+            for (int b = 0; b < B; ++b) std::memcpy(all.data() + (size_t)b * S * 3, vc.data(), sizeof(float) * S * 3);
+            HIP_TRY(hipMemcpyAsync(pc.coords.p, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            std::memcpy(pc.coords_key, key, sizeof(key));
+        }
+        sc.coords = pc.coords.p;
     }
     for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(sc.ev[0], s));
