@@ -386,3 +386,29 @@ def test_split_k_reduction_stress_full_size_mid_block(hip):
     crop = x[:, :, 4:9, 3:10, 5:14].float()
     ref = O.causal_conv3d(crop, w.float(), b.float(), False)
     assert rel_l2(y[:, :, 5:8, 4:9, 6:13], ref[:, :, 1:4, 1:6, 1:8]) <= 1.5e-2
+
+
+def test_fuzz_linear_and_conv_shapes(hip):
+    """Randomised shapes through the GEMM dispatcher (all tiles, split-K, buffer-addressed staging, ragged M/N/K, small and
+    odd conv geometries) against CPU f32: 40 linear + 16 conv cases, bf16."""
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for it in range(40):
+        M, N, K = ri(1, 2600), 4 * ri(1, 160), 8 * ri(1, 140)
+        epi = ri(0, 3)
+        x = torch.randn(M, K, generator=g).bfloat16(); w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16(); b = (torch.randn(N, generator=g) * 0.1).bfloat16()
+        r = torch.randn(M, N, generator=g).bfloat16(); gate = torch.randn(1, N, generator=g)
+        lin = x.float() @ w.float().T + b.float()
+        want = [lin, O.gelu_approximate(lin), r.float() + gate * lin, r.float() + lin][epi]
+        got = hip.ops.linear(x.cuda(), w.cuda(), b.cuda(), epi=epi, resid=r.cuda() if epi >= 2 else None,
+                             gate=gate.cuda() if epi == 2 else None, rows_per_batch=M)
+        assert rel_l2(got.float().cpu(), want) <= BF16_TOL, (it, M, N, K, epi, rel_l2(got.float().cpu(), want))
+    for it in range(16):
+        Cin, Cout = 8 * ri(1, 24), 8 * ri(1, 24)
+        T, H, W = ri(1, 5), ri(1, 33), ri(1, 33)
+        causal = bool(ri(0, 1))
+        x = torch.randn(1, Cin, T, H, W, generator=g).bfloat16(); w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5).bfloat16()
+        b = (torch.randn(Cout, generator=g) * 0.1).bfloat16()
+        got = ncthw(hip.ops.conv3d(cl(x).cuda(), w.cuda(), b.cuda(), causal=causal)).float().cpu()
+        want = O.causal_conv3d(x.float(), w.float(), b.float(), causal)
+        assert rel_l2(got, want) <= BF16_TOL, (it, Cin, Cout, T, H, W, causal, rel_l2(got, want))
