@@ -24,9 +24,32 @@
 #ifndef ATTN_DMA
 #define ATTN_DMA 1
 #endif
+#ifndef ATTN_STATIC_SLOTS
+#define ATTN_STATIC_SLOTS 1
+#endif
+#ifndef ATTN_TR_ASM
+#define ATTN_TR_ASM 1
+#endif
 namespace {
 
 constexpr int BQ = 128, BKV = 64;
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Transpose read issued OUTSIDE the compiler's memory model: for the builtin form the wait-count pass cannot tell the
+// read from the LDS-DMA writes of the other ring slots and drains vmcnt to 0 before the first one, which serialises
+// the K/V prefetch with the softmax.  The asm form is waited for explicitly (lds_wait ties the registers).
+template <int OFF> __device__ __forceinline__ u32x2 ds_tr_read(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait(u32x2& a, u32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 template <int CPR> __device__ __forceinline__ int kswz(int row, int c) {
     if constexpr (CPR >= 4) { constexpr int RPB = 16 / CPR; return c ^ ((row / RPB) % CPR); }
@@ -57,7 +80,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     constexpr int NBUF = (DMA && HD == 64) ? 3 : 2;            // head_dim 128: 32 KiB tiles, two of them (two blocks per CU)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * TILE_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // 1-D grid.  Blocks L and L+8 share an XCD (one L2): with heads % 8 == 0 every XCD is given WHOLE heads
     // (head = xcd + 8*(j / nqb)), so the K/V of a head (2 x Sk x hd bf16, 1.3 MB at 4992 x 64) is re-read by its
@@ -186,6 +209,15 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
 
     // tr-read lane geometry (see header): 16-lane group g = lane>>4 -> (h = g>>1, d-half = g&1)
     const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+    // lane part of the V^T read address per d-block (the swizzles depend only on row bits below 8, so the tile row
+    // offsets kb*32 + 16s (+8) and the ring slot go into the instruction's immediate)
+    uint32_t tr_base[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+        const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+        tr_base[d] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem
+                     + row * VROW + vswz<VCPR>(row, cv) * 16 + (trp & 1) * 8;
+    }
 
     // Softmax bookkeeping.  Fast path (no key bias): the running max m_run is kept in RAW score units and
     // the scale is folded into the exponent, p = exp2(fma(s, c, -m*c)) with c = scale*log2(e): one FMA + one
@@ -196,10 +228,13 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     const bool has_bias = bias != nullptr;
     const float c = has_bias ? 1.0f : sc2;
     constexpr float RESCALE_THR = 5.0f;
-    auto tile_body = [&](int t, auto masked_tag) {
+    // slot_tag >= 0: the ring slot of tile t is a compile-time constant (the steady-state loop is unrolled by NBUF), so
+    // every LDS read is <per-lane base register> + immediate and the DMA target is a scalar constant; -1: computed.
+    auto tile_body = [&](int t, auto masked_tag, auto slot_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int buf = NBUF == 3 ? t % 3 : (t & 1);
-        if constexpr (DMA) { if (t + NBUF - 1 < nt) dma_tile(t + NBUF - 1, (t + NBUF - 1) % NBUF); }
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const int buf = SLOT >= 0 ? SLOT : (NBUF == 3 ? t % 3 : (t & 1));
+        if constexpr (DMA) { if (t + NBUF - 1 < nt) dma_tile(t + NBUF - 1, SLOT >= 0 ? (SLOT + NBUF - 1) % NBUF : (t + NBUF - 1) % NBUF); }
         else if (t + 1 < nt) gload(t + 1);
         const unsigned char* Ks = smem + buf * TILE_BYTES;
         const unsigned char* Vs = Ks + BKV * KROW;
@@ -253,14 +288,17 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { minit[i] = -m_run; sacc[0][i] -= delta; sacc[1][i] -= delta; }
             }
+            f32x2 ls2 = {0.f, 0.f};                                  // two partial sums: v_pk_add_f32
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(sacc[kb][i]);
-                    ls += p;
-                    pf[kb][i >> 3][i & 7] = (bf16_t)p;
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 p = {__builtin_amdgcn_exp2f(sacc[kb][i]), __builtin_amdgcn_exp2f(sacc[kb][i + 1])};
+                    ls2 += p;
+                    pf[kb][i >> 3][i & 7] = (bf16_t)p[0];
+                    pf[kb][i >> 3][(i & 7) + 1] = (bf16_t)p[1];
                 }
+            ls = ls2[0] + ls2[1];
         } else {
             if (!__all((mt - m_run) * c <= RESCALE_THR)) {
                 const float m_new = fmaxf(m_run, mt);
@@ -284,6 +322,30 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
         }
         l_run += ls;
         // ---- O^T += V^T . P^T
+        if constexpr (DMA && ATTN_TR_ASM) {
+            // one MFMA operand = two transpose reads; a rolling window of four operands (16 registers) is in flight:
+            // the reads of step n+4 are issued right after MFMA n has taken its operand
+            constexpr int NSTEP = NDB * 4;                          // step n = d*4 + kb*2 + s
+            u32x2 vr[4][2];
+            auto issue = [&](auto n_tag) {
+                constexpr int n = decltype(n_tag)::value, d = n >> 2, j = n & 3;
+                constexpr int rowc = (j >> 1) * 32 + (j & 1) * 16;
+                constexpr int imm = (SLOT >= 0 ? SLOT : 0) * TILE_BYTES + BKV * KROW + rowc * VROW;
+                const uint32_t vb = tr_base[d] + (SLOT >= 0 ? 0u : (uint32_t)buf * TILE_BYTES);
+                vr[j][0] = ds_tr_read<imm>(vb);
+                vr[j][1] = ds_tr_read<imm + 8 * VROW>(vb);
+            };
+            static_for<0, 4>([&](auto n_tag) { issue(n_tag); });
+            static_for<0, NSTEP>([&](auto n_tag) {
+                constexpr int n = decltype(n_tag)::value, d = n >> 2, j = n & 3;
+                constexpr int after = (NSTEP - 1 - n < 3 ? NSTEP - 1 - n : 3) * 2;
+                lds_wait<after>(vr[j][0], vr[j][1]);
+                union { u32x2 u[2]; bf16x8 v; } cvt;
+                cvt.u[0] = vr[j][0]; cvt.u[1] = vr[j][1];
+                acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf[j >> 1][j & 1], acc_o[d], 0, 0, 0);
+                if constexpr (n + 4 < NSTEP) issue(std::integral_constant<int, n + 4>{});
+            });
+        } else {
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
             const int cv = d * 4 + trdh * 2 + (trp >> 1);
@@ -301,6 +363,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
                     acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], acc_o[d], 0, 0, 0);
                 }
         }
+        }
         if constexpr (DMA) {
             // tile t+1 must have landed for every wave; with the 3-tile ring tile t+2's pieces may stay in flight
             if (NBUF == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -311,8 +374,17 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
         }
     };
     const bool ragged = (a.Sk % BKV) != 0;
-    for (int t = 0; t < nt - 1; ++t) tile_body(t, std::false_type{});
-    if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
+    using dyn_slot = std::integral_constant<int, -1>;
+    int t = 0;
+    if constexpr (DMA && ATTN_STATIC_SLOTS) {
+        for (; t + NBUF <= nt - 1; t += NBUF) {
+            tile_body(t, std::false_type{}, std::integral_constant<int, 0>{});
+            tile_body(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+            if constexpr (NBUF == 3) tile_body(t + 2, std::false_type{}, std::integral_constant<int, 2>{});
+        }
+    }
+    for (; t < nt - 1; ++t) tile_body(t, std::false_type{}, dyn_slot{});
+    if (ragged) tile_body(nt - 1, std::true_type{}, dyn_slot{}); else tile_body(nt - 1, std::false_type{}, dyn_slot{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
