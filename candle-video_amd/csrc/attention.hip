@@ -405,6 +405,257 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     }
 }
 
+// ---- head_dim 64, q prescaled, no bias: two-tile software pipeline inside one wave --------------------------------
+// The kernel above runs a tile's phases back to back in each wave (S^T MFMAs -> max -> exp -> PV MFMAs) and leaves the
+// overlap of matrix and vector work to the three co-resident waves of a SIMD, which overlap poorly (one block per CU
+// already reaches 2/3 of the rate of three).  Here S^T of tile t+1 is issued BEFORE the softmax of tile t, so a single
+// wave's instruction stream carries independent matrix work beside its exp/max/convert work; the two S^T accumulator
+// sets alternate (loop unrolled by four = ring slots, all LDS addresses immediates).  K/V ring: four 16-KiB tiles,
+// tile t+3 in flight while tile t is multiplied; 64 KiB LDS and <= 256 registers -> two blocks per CU.
+// S^T(t+1) is formed against the running max as it stood BEFORE tile t's update; when tile t moves the max, the
+// pending accumulators are shifted with it.
+#ifndef ATTN_ABL
+#define ATTN_ABL 0      // timing ablations (wrong results): 1 no K/V loads in the loop, 2 no exp, 3 no barrier
+#endif
+#ifndef ATTN_ORDER
+#define ATTN_ORDER 0    // where tile t+3's LDS-DMA is issued: 0 top of the body, 1 after the S^T MFMAs, 2 after the exps
+#endif
+#ifndef ATTN_VEARLY
+#define ATTN_VEARLY 0   // 1: first V^T operand reads issued ahead of the softmax
+#endif
+#ifndef ATTN_PIPE_OCC
+#define ATTN_PIPE_OCC 2
+#endif
+__global__ __launch_bounds__(256, ATTN_PIPE_OCC) void attn_pipe64_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2;
+    constexpr int TILE_BYTES = BKV * (KROW + VROW), NSLOT = 4;
+    constexpr int RPP = 8, PW = 2, PIECES = 2 * PW;              // DMA pieces (1 KiB) per wave and tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int head, b, qb;
+    {
+        const int nqb = (a.Sq + BQ - 1) / BQ, per_b = nqb * a.heads;
+        int L = blockIdx.x;
+        b = L / per_b; L -= b * per_b;
+        if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / nqb); qb = j % nqb; }
+        else { head = L / nqb; qb = L - head * nqb; }
+    }
+    const int q0 = qb * BQ + wave * 32;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
+
+    bf16x8 qf[NKS];
+    {
+        int qr = q0 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+        const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+    const int nt = (a.Sk + BKV - 1) / BKV;
+    __amdgpu_buffer_rsrc_t rk_rsrc, rv_rsrc;
+    uint32_t k_voff[PW], v_voff[PW];
+    {
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
+        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
+        rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
+        rv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int row = (wave * PW + j) * RPP + lane / KCPR, pc = lane % KCPR;
+            k_voff[j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
+            v_voff[j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
+        }
+    }
+    auto dma_tile = [&](int t, int slot) {
+        unsigned char* Ks = smem + slot * TILE_BYTES;
+        unsigned char* Vs = Ks + BKV * KROW;
+        const uint32_t ks = (uint32_t)t * BKV * (uint32_t)a.ldk * 2u, vs = (uint32_t)t * BKV * (uint32_t)a.ldv * 2u;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_rsrc, (__attribute__((address_space(3))) void*)(Ks + (wave * PW + j) * 1024), 16, (int)k_voff[j], (int)ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv_rsrc, (__attribute__((address_space(3))) void*)(Vs + (wave * PW + j) * 1024), 16, (int)v_voff[j], (int)vs, 0, 0);
+        }
+    };
+
+    f32x16 acc_o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[d][i] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 minit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) minit[i] = 0.f;
+
+    // lane parts of the LDS addresses (tile row offsets and the ring slot are instruction immediates)
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t k_base[NKS], tr_base[NDB];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) k_base[ks] = smem_base + r * KROW + kswz<KCPR>(r, 2 * ks + h) * 16;   // rows r and r+32 swizzle alike
+    {
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+            tr_base[d] = smem_base + row * VROW + vswz<VCPR>(row, cv) * 16 + (trp & 1) * 8;
+        }
+    }
+
+    // S^T of one tile: two chains of four MFMAs, accumulators start at -m_run
+    auto qk_tile = [&](auto slot_tag, int slot_dyn, f32x16 (&sacc)[2]) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const uint32_t off = SLOT >= 0 ? 0u : (uint32_t)slot_dyn * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(
+                    k_base[ks] + off + (SLOT >= 0 ? SLOT : 0) * TILE_BYTES + kb * 32 * KROW);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? minit : sacc[kb], 0, 0, 0);
+            }
+    };
+
+    constexpr float RESCALE_THR = 5.0f;
+    // body of tile t: cur holds S^T(t) - m; nxt receives S^T(t+1)
+    auto body = [&](int t, auto slot_tag, auto last_tag, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;               // last tile: nothing to prefetch, tail keys masked
+        const int slot = SLOT >= 0 ? SLOT : (t & 3);
+        auto prefetch = [&] {
+#if ATTN_ABL != 1
+            if (t + 3 < nt) dma_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & 3 : (t + 3) & 3);
+#endif
+        };
+        // V^T operands: a rolling window of four MFMA operands (16 registers), first four issued ahead of the softmax
+        constexpr int NSTEP = NDB * 4;
+        u32x2 vr[4][2];
+        auto issue = [&](auto n_tag) {
+            constexpr int n = decltype(n_tag)::value, d = n >> 2, j = n & 3;
+            constexpr int rowc = (j >> 1) * 32 + (j & 1) * 16;
+            constexpr int imm = (SLOT >= 0 ? SLOT : 0) * TILE_BYTES + BKV * KROW + rowc * VROW;
+            const uint32_t vb = tr_base[d] + (SLOT >= 0 ? 0u : (uint32_t)slot * TILE_BYTES);
+            vr[j][0] = ds_tr_read<imm>(vb);
+            vr[j][1] = ds_tr_read<imm + 8 * VROW>(vb);
+        };
+        if (ATTN_ORDER == 0) prefetch();
+        if constexpr (!LAST) {
+            if constexpr (SLOT >= 0) qk_tile(std::integral_constant<int, (SLOT + 1) & 3>{}, 0, nxt);
+            else qk_tile(std::integral_constant<int, -1>{}, (t + 1) & 3, nxt);
+        }
+        if (ATTN_ORDER == 1) prefetch();
+        if (ATTN_VEARLY) static_for<0, 4>([&](auto n_tag) { issue(n_tag); });
+        if constexpr (LAST) {
+            const int kv0 = t * BKV;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= a.Sk) cur[kb][i] = -INFINITY;
+                }
+        }
+        float mt = fmaxf(cur[0][0], cur[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, cur[0][i]), cur[1][i]);
+        {
+            unsigned mu = __float_as_uint(mt);
+            auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (t == 0 || !__all(mt <= RESCALE_THR)) {
+            const float delta = t == 0 ? mt : fmaxf(mt, 0.f);
+            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_o[d][i] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                minit[i] = -m_run; cur[0][i] -= delta; cur[1][i] -= delta;
+                if constexpr (!LAST) { nxt[0][i] -= delta; nxt[1][i] -= delta; }
+            }
+        }
+        bf16x8 pf[2][2];
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+#if ATTN_ABL == 2
+                f32x2 p = {cur[kb][i], cur[kb][i + 1]};
+#else
+                f32x2 p = {__builtin_amdgcn_exp2f(cur[kb][i]), __builtin_amdgcn_exp2f(cur[kb][i + 1])};
+#endif
+                ls2 += p;
+                pf[kb][i >> 3][i & 7] = (bf16_t)p[0];
+                pf[kb][i >> 3][(i & 7) + 1] = (bf16_t)p[1];
+            }
+        l_run += ls2[0] + ls2[1];
+        if (ATTN_ORDER == 2) prefetch();
+        if (!ATTN_VEARLY) static_for<0, 4>([&](auto n_tag) { issue(n_tag); });
+        static_for<0, NSTEP>([&](auto n_tag) {
+            constexpr int n = decltype(n_tag)::value, d = n >> 2, j = n & 3;
+            constexpr int after = (NSTEP - 1 - n < 3 ? NSTEP - 1 - n : 3) * 2;
+            lds_wait<after>(vr[j][0], vr[j][1]);
+            union { u32x2 u[2]; bf16x8 v; } cvt;
+            cvt.u[0] = vr[j][0]; cvt.u[1] = vr[j][1];
+            acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf[j >> 1][j & 1], acc_o[d], 0, 0, 0);
+            if constexpr (n + 4 < NSTEP) issue(std::integral_constant<int, n + 4>{});
+        });
+        // tile t+2 (its K is read by the next body) must have landed for every wave; tile t+3's pieces stay in flight
+#if ATTN_ABL != 1
+        if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if ATTN_ABL != 3
+        __builtin_amdgcn_s_barrier();
+#endif
+    };
+
+    dma_tile(0, 0);
+    if (nt > 1) dma_tile(1, 1);
+    if (nt > 2) { dma_tile(2, 2); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 sA[2], sB[2];
+    qk_tile(std::integral_constant<int, 0>{}, 0, sA);
+    using dyn = std::integral_constant<int, -1>;
+    int t = 0;
+    for (; t + 4 <= nt - 1; t += 4) {
+        body(t, std::integral_constant<int, 0>{}, std::false_type{}, sA, sB);
+        body(t + 1, std::integral_constant<int, 1>{}, std::false_type{}, sB, sA);
+        body(t + 2, std::integral_constant<int, 2>{}, std::false_type{}, sA, sB);
+        body(t + 3, std::integral_constant<int, 3>{}, std::false_type{}, sB, sA);
+    }
+    for (; t + 2 <= nt - 1; t += 2) {
+        body(t, dyn{}, std::false_type{}, sA, sB);
+        body(t + 1, dyn{}, std::false_type{}, sB, sA);
+    }
+    if (t < nt - 1) { body(t, dyn{}, std::false_type{}, sA, sB); body(t + 1, dyn{}, std::true_type{}, sB, sA); }
+    else body(t, dyn{}, std::true_type{}, sA, sB);
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + r;
+    if (qr < a.Sq) {
+        bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;
+                bf16x4 o4 = {(bf16_t)(acc_o[d][4 * g4 + 0] * inv), (bf16_t)(acc_o[d][4 * g4 + 1] * inv),
+                             (bf16_t)(acc_o[d][4 * g4 + 2] * inv), (bf16_t)(acc_o[d][4 * g4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(O + dd) = o4;
+            }
+    }
+}
+
 // ---- exact-f32 flash attention (parity mode): one query per lane, 64 queries per block ----
 template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
@@ -472,6 +723,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 }  // namespace
 
+static bool attn_pipe_enabled() {
+    const char* e = getenv("LTX_ATTN_PIPE");                // "0" = one tile at a time per wave (A/B aid)
+    return !(e && e[0] == '0');
+}
+
 bool ltx_attention_prescale_ok(int hd) {
     const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
     return (hd == 64 || hd == 128) && !(e && e[0] == '0');
@@ -492,7 +748,8 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         switch (a.hd) {
             case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
             case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;
-            case 64: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
+            case 64: if (a.q_prescaled && attn_pipe_enabled()) hipLaunchKernelGGL(attn_pipe64_kernel, grid, block, 0, s, ax);
+                     else if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
                      else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);
                      break;
             case 128: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<128, true>), grid, block, 0, s, ax);

@@ -15,6 +15,16 @@ extern "C" int ltx_op_linear(const void* x, const void* w, const void* bias, voi
     return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_linear_segmented(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int seg_width,
+                                       int dtype, ltx_stream stream) {
+    if (!x || !w || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_segmented: null tensor");
+    if (seg_width <= 0 || (seg_width & (seg_width - 1)) || N % seg_width) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_segmented: seg_width must be a power of two dividing N");
+    GemmArgs g; g.A = x; g.W = w; g.C = y; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = seg_width;
+    g.c_seg_shift = __builtin_ctz((unsigned)seg_width); g.c_seg_stride = (int64_t)M * seg_width;
+    return ltx_launch_gemm(g, dtc(dtype), EPI_BIAS, (hipStream_t)stream);
+}
+
 extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float eps, const void* weight,
                               const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
                               int dtype, ltx_stream stream) {

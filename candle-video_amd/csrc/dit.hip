@@ -297,16 +297,27 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         // self attention
-        LTX_TRY(ltx_linear(b.qkv1, m->n.p, D, m->qkv.p, 3 * D, (int)M, dt, EPI_BIAS, s));
-        QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = 3 * D; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
+        // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
+        // of two: the attention kernel reads K/V rows of a dense matrix 7-11 % faster than column slices of [M, 3D]
+        const bool dense_qkv = (D & (D - 1)) == 0;
+        const int64_t seg = dense_qkv ? M * D : D;           // elements from q to k to v
+        const int ldqkv = dense_qkv ? D : 3 * D;
+        {
+            GemmArgs g;
+            g.A = m->n.p; g.W = b.qkv1.w; g.C = m->qkv.p; g.bias = b.qkv1.b;
+            g.M = (int)M; g.N = b.qkv1.out; g.K = b.qkv1.in; g.lda = D; g.ldc = ldqkv;
+            if (dense_qkv) { g.c_seg_shift = __builtin_ctz((unsigned)D); g.c_seg_stride = seg; }
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
+        }
+        QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = ldqkv; qa.seg_stride = seg; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
         qa.eps = 1e-5f; qa.cos = m->cosb.as<float>(); qa.sin = m->sinb.as<float>();
         // bf16: q leaves the norm already multiplied by scale*log2(e) (ONE bf16 rounding, of the product), so the
         // attention kernel's exponent is exp2(S - m) with no per-score multiply
         const bool fold_q = dt == LTX_DT_BF16 && ltx_attention_prescale_ok(hd);
         if (fold_q) qa.out_scale0 = attn_scale * 1.4426950408889634f;
         LTX_TRY(ltx_launch_qknorm_rope(qa, dt, s));
-        AttnArgs at; at.q = m->qkv.p; at.k = (char*)m->qkv.p + (size_t)D * esz; at.v = (char*)m->qkv.p + (size_t)2 * D * esz; at.o = m->attn.p;
-        at.ldq = at.ldk = at.ldv = 3 * D; at.ldo = D; at.B = B; at.Sq = S; at.Sk = S; at.heads = H; at.hd = hd; at.scale = attn_scale;
+        AttnArgs at; at.q = m->qkv.p; at.k = (char*)m->qkv.p + (size_t)seg * esz; at.v = (char*)m->qkv.p + (size_t)2 * seg * esz; at.o = m->attn.p;
+        at.ldq = at.ldk = at.ldv = ldqkv; at.ldo = D; at.B = B; at.Sq = S; at.Sk = S; at.heads = H; at.hd = hd; at.scale = attn_scale;
         at.q_prescaled = fold_q ? 1 : 0;
         LTX_TRY(ltx_launch_attention(at, dt, s));
         // h = h + gate_msa * to_out(attn)     (gate_msa = row 2)

@@ -396,7 +396,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     GemmArgs g = g_in;                                   // plain bias epilogue into a scratch [M, N] output
     void* scratch = nullptr;
     if (hipMalloc(&scratch, (size_t)g.M * g.N * sizeof(bf16_t)) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
-    g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr;
+    g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);

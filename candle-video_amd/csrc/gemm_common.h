@@ -51,6 +51,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
         for (int i = 0; i < 4; ++i) v[i] += b[i];
     }
     if constexpr (EPI == EPI_BIAS) {
+        if (g.c_seg_shift) { const int sg = nb >> g.c_seg_shift; C += sg * g.c_seg_stride; nb -= sg << g.c_seg_shift; }
         store4<T>(C + (int64_t)m * g.ldc + nb, v);
     } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll

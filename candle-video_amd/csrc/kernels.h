@@ -31,6 +31,9 @@ struct GemmArgs {
     int ntaps = 1, kh = 1, kw = 1, pad_t = 0;   // pad_t: frames of left temporal replicate padding
     // D2S / UNPATCH
     int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
+    // EPI_BIAS only: output split into column segments of width 1 << c_seg_shift, segment j a dense [M, ldc] matrix at
+    // C + j * c_seg_stride elements (fused q|k|v projection -> three contiguous matrices); 0 = one [M, ldc] matrix
+    int c_seg_shift = 0; int64_t c_seg_stride = 0;
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
     // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
     int sk_full = 0, sk_sf = 1;
@@ -63,6 +66,7 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 struct QkNormRopeArgs {
     void* x = nullptr;            // in place, nseg segments of width D at x + j*D in each row
     int64_t rows = 0; int D = 0; int ld = 0; int nseg = 1;
+    int64_t seg_stride = 0;       // elements from segment j to j+1 (0: D, i.e. adjacent column blocks of one row)
     const void* w0 = nullptr; const void* w1 = nullptr;   // T [D]
     float eps = 1e-5f;
     const float* cos = nullptr; const float* sin = nullptr;  // f32 [rows, D/2] or null (no RoPE)

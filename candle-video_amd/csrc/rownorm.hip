@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
         if (active) *reinterpret_cast<u32x4*>(x + c * CH) = o.u;
     };
     for (int seg = 0; seg < a.nseg; ++seg) {
-        T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * a.D;
+        T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * (a.seg_stride ? a.seg_stride : a.D);
         const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
         const float oscale = seg == 0 ? a.out_scale0 : 1.0f;
         if constexpr (CACHED) {
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
     const float* cs = rope ? a.cos + rr * (a.D / 2) : nullptr;
     const float* sn = rope ? a.sin + rr * (a.D / 2) : nullptr;
     T* x0 = reinterpret_cast<T*>(a.x) + rr * a.ld;
+    const int64_t sst = a.seg_stride ? a.seg_stride : a.D;
     Chunk16 v[2][NS];
     f32x4 co[NS], si[NS];
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
         const bool in = c < nch;
         v[0][i].u = (u32x4){0u, 0u, 0u, 0u}; v[1][i].u = (u32x4){0u, 0u, 0u, 0u};
         if (in) v[0][i].u = *reinterpret_cast<const u32x4*>(x0 + c * CH);
-        if (in && a.nseg == 2) v[1][i].u = *reinterpret_cast<const u32x4*>(x0 + a.D + c * CH);
+        if (in && a.nseg == 2) v[1][i].u = *reinterpret_cast<const u32x4*>(x0 + sst + c * CH);
         if (in && rope) { co[i] = *reinterpret_cast<const f32x4*>(cs + c * 4); si[i] = *reinterpret_cast<const f32x4*>(sn + c * 4); }
     }
 #pragma unroll
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
                 }
             }
             Chunk16 o; f32_to_chunk<T>(f, o);
-            if (active) *reinterpret_cast<u32x4*>(x0 + (int64_t)seg * a.D + c * CH) = o.u;
+            if (active) *reinterpret_cast<u32x4*>(x0 + seg * sst + c * CH) = o.u;
         }
     }
 }

@@ -104,6 +104,7 @@ _SIGS = {
     "ltx_pipeline_last_timing": [_vp],
     "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp],
     "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "ltx_op_linear_segmented": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
     "ltx_op_rope_table": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
@@ -691,6 +692,16 @@ class ops:
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         _check(lib.ltx_op_linear(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), M, N, K, _dt(x.dtype), epi,
                                  _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
+        return y
+
+    @staticmethod
+    def linear_segmented(x, w, bias, seg_width):
+        """x @ w^T + bias written as N/seg_width dense [M, seg_width] matrices (the DiT's q|k|v projection)."""
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(N // seg_width, M, seg_width, dtype=x.dtype, device=x.device)
+        _check(lib.ltx_op_linear_segmented(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), M, N, K, seg_width,
+                                           _dt(x.dtype), _stream()))
         return y
 
     @staticmethod

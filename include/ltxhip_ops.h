@@ -18,6 +18,12 @@ extern "C" {
 int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, int epi,
                   const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);
 
+/* The fused q|k|v projection of LtxAttention (ltx_transformer.rs:655-662: to_q, to_k, to_v on the same input) with the
+ * output written as N/seg_width DENSE matrices: y[j][M][seg_width] = (x @ w^T + bias)[:, j*seg_width:(j+1)*seg_width].
+ * seg_width a power of two dividing N. */
+int ltx_op_linear_segmented(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int seg_width,
+                            int dtype, ltx_stream stream);
+
 /* RmsNorm / LayerNormNoParams + AdaLN modulate (+SiLU) on rows (ltx_transformer.rs:72-119, 874-889;
  * vae.rs:148-153, 711-739): y = act(norm(x)[*weight]*(1+scale_b)+shift_b). kind 0 RMS / 1 LN. */
 int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float eps, const void* weight,

@@ -412,3 +412,24 @@ def test_fuzz_linear_and_conv_shapes(hip):
         got = ncthw(hip.ops.conv3d(cl(x).cuda(), w.cuda(), b.cuda(), causal=causal)).float().cpu()
         want = O.causal_conv3d(x.float(), w.float(), b.float(), causal)
         assert rel_l2(got, want) <= BF16_TOL, (it, Cin, Cout, T, H, W, causal, rel_l2(got, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("M,N,K,seg", [(4992, 6144, 2048, 2048), (300, 384, 128, 128), (77, 192, 64, 64)])
+def test_linear_segmented_matches_plain_linear(dtype, M, N, K, seg):
+    """The fused q|k|v projection written as dense per-segment matrices: bit-identical to slicing the plain output."""
+    import torch
+    from ltxhip import ops
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(dt)
+    b = torch.randn(N, device="cuda", generator=g).to(dt)
+    plain = ops.linear(x, w, b)
+    segd = ops.linear_segmented(x, w, b, seg)
+    assert segd.shape == (N // seg, M, seg)
+    for j in range(N // seg):
+        assert torch.equal(segd[j], plain[:, j * seg:(j + 1) * seg])
+    with pytest.raises(Exception):
+        ops.linear_segmented(x, w, b, 96)
