@@ -248,8 +248,8 @@ def main():
             ltxhip.prof_enable(True)
             step()
             kinds = {"gemm_big_kernel/gemm_p8_kernel<bf16> (Linear GEMMs, tile per shape)": 0,
-                     "gemm_big_kernel/gemm_p8_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_bf16_kernel<64> (self)": 2,
-                     "attn_bf16_kernel<64> (cross)": 3, "rownorm_kernel<bf16>": 4}
+                     "gemm_big_kernel/gemm_p8_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_pipe64_kernel (self attention)": 2,
+                     "attn_bf16_kernel<64> (cross attention)": 3, "rownorm_kernel<bf16>": 4}
             per = {}
             for name, k in kinds.items():
                 ms, work, cnt = ltxhip.prof_report(k)

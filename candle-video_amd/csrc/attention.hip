@@ -656,6 +656,154 @@ __global__ __launch_bounds__(256, ATTN_PIPE_OCC) void attn_pipe64_kernel(const A
     }
 }
 
+// ---- head_dim 64, at most 128 keys (the DiT's cross-attention over the text tokens, ltx_transformer.rs:719-740 with the
+// additive key mask): K and V of a head sit in LDS once per block, every wave then runs whole 32-query units on its own -
+// one-shot softmax over all keys (no running max, no rescale), no barrier after the initial load, next unit's Q
+// fragments in flight while the current unit is multiplied.  Keys past Sk read as zeros (buffer range) and get -inf.
+constexpr int XKV = 128;                                 // key capacity of the cross kernel
+__global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, int groups) {
+    constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2, NKB = XKV / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
+    __shared__ __attribute__((aligned(16))) float sbias[XKV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int grp = blockIdx.x % groups, bh = blockIdx.x / groups;
+    const int head = bh % a.heads, b = bh / a.heads;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
+    const float LOG2E = 1.4426950408889634f;
+    const float c = a.q_prescaled ? 1.0f : a.scale * LOG2E;
+
+    // K/V -> LDS by buffer LDS-DMA: 16 pieces of 8 rows per matrix, 4 + 4 per wave
+    {
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
+        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j, row = piece * 8 + lane / KCPR, pc = lane % KCPR;
+            const uint32_t ko = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
+            const uint32_t vo = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, (int)ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + XKV * KROW + piece * 1024), 16, (int)vo, 0, 0, 0);
+        }
+        if (tid < XKV) {
+            float bv = tid < a.Sk ? 0.f : -INFINITY;
+            if (a.bias && tid < a.Sk) bv = a.bias[(int64_t)b * a.Sk + tid] * LOG2E;
+            sbias[tid] = bv;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // per-lane bias tuples in accumulator order: key = kb*32 + (i&3) + 8*(i>>2) + 4h
+    f32x16 bias_t[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&sbias[kb * 32 + 8 * g4 + 4 * h]);
+            bias_t[kb][4 * g4] = bq[0]; bias_t[kb][4 * g4 + 1] = bq[1]; bias_t[kb][4 * g4 + 2] = bq[2]; bias_t[kb][4 * g4 + 3] = bq[3];
+        }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t k_base[NKS], tr_base[NDB];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) k_base[ks] = smem_base + r * KROW + kswz<KCPR>(r, 2 * ks + h) * 16;
+    {
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+            tr_base[d] = smem_base + XKV * KROW + row * VROW + vswz<VCPR>(row, cv) * 16 + (trp & 1) * 8;
+        }
+    }
+    const int nunits = (a.Sq + 31) / 32, ustride = groups * 4;
+    auto load_q = [&](int u, bf16x8 (&qf)[NKS]) {
+        int qr = u * 32 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+        const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    };
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    int u = grp * 4 + wave;
+    bf16x8 qf[NKS], qn[NKS];
+    if (u < nunits) load_q(u, qf);
+    for (; u < nunits; u += ustride) {
+        if (u + ustride < nunits) load_q(u + ustride, qn);
+        // S^T = K . Q^T for all keys
+        f32x16 sacc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(k_base[ks] + kb * 32 * KROW);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
+            }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[kb][i] = fmaf(sacc[kb][i], c, bias_t[kb][i]); mt = fmaxf(mt, sacc[kb][i]); }
+        {
+            unsigned mu = __float_as_uint(mt);
+            auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        bf16x8 pf[NKB][2];
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 p = {__builtin_amdgcn_exp2f(sacc[kb][i] - mt), __builtin_amdgcn_exp2f(sacc[kb][i + 1] - mt)};
+                ls2 += p;
+                pf[kb][i >> 3][i & 7] = (bf16_t)p[0];
+                pf[kb][i >> 3][(i & 7) + 1] = (bf16_t)p[1];
+            }
+        float l = ls2[0] + ls2[1];
+        l += __shfl_xor(l, 32);
+        // O^T = V^T . P^T
+        f32x16 acc_o[NDB];
+        constexpr int NSTEP = NDB * NKB * 2;                 // step n = d*(2*NKB) + kb*2 + s
+        u32x2 vr[4][2];
+        auto issue = [&](auto n_tag) {
+            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
+            constexpr int imm = ((j >> 1) * 32 + (j & 1) * 16) * VROW;
+            vr[n & 3][0] = ds_tr_read<imm>(tr_base[d]);
+            vr[n & 3][1] = ds_tr_read<imm + 8 * VROW>(tr_base[d]);
+        };
+        static_for<0, 4>([&](auto n_tag) { issue(n_tag); });
+        static_for<0, NSTEP>([&](auto n_tag) {
+            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
+            constexpr int after = (NSTEP - 1 - n < 3 ? NSTEP - 1 - n : 3) * 2;
+            lds_wait<after>(vr[n & 3][0], vr[n & 3][1]);
+            union { u32x2 u2[2]; bf16x8 v; } cvt;
+            cvt.u2[0] = vr[n & 3][0]; cvt.u2[1] = vr[n & 3][1];
+            acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf[j >> 1][j & 1], j == 0 ? zero16 : acc_o[d], 0, 0, 0);
+            if constexpr (n + 4 < NSTEP) issue(std::integral_constant<int, n + 4>{});
+        });
+        const float inv = 1.0f / l;
+        const int qr = u * 32 + r;
+        if (qr < a.Sq) {
+            bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = d * 32 + 8 * g4 + 4 * h;
+                    bf16x4 o4 = {(bf16_t)(acc_o[d][4 * g4 + 0] * inv), (bf16_t)(acc_o[d][4 * g4 + 1] * inv),
+                                 (bf16_t)(acc_o[d][4 * g4 + 2] * inv), (bf16_t)(acc_o[d][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(O + dd) = o4;
+                }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
+    }
+}
+
 // ---- exact-f32 flash attention (parity mode): one query per lane, 64 queries per block ----
 template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
@@ -723,6 +871,10 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 }  // namespace
 
+static bool attn_cross_enabled() {
+    const char* e = getenv("LTX_ATTN_CROSS");               // "0" = generic tiled kernel for short key sets too (A/B aid)
+    return !(e && e[0] == '0');
+}
 static bool attn_pipe_enabled() {
     const char* e = getenv("LTX_ATTN_PIPE");                // "0" = one tile at a time per wave (A/B aid)
     return !(e && e[0] == '0');
@@ -745,6 +897,16 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)
         ax.xcd_heads = (a.heads % 8 == 0 && !(xe && xe[0] == '0')) ? 1 : 0;
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
+        if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
+            // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
+            const int nunits = cdiv(a.Sq, 32);
+            int groups = cdiv(512, a.B * a.heads);
+            if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
+            if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
+            hipLaunchKernelGGL(attn_cross64_kernel, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
+            LTX_CHECK_LAUNCH();
+            return LTX_OK;
+        }
         switch (a.hd) {
             case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
             case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;

@@ -32,6 +32,8 @@ def classify(n):
     if "gemm_kernel" in n:
         # rocprofv3 cannot demangle the bf16 template argument of this kernel: "..., ELb1E>" is the CONV=true form
         return "conv3d implicit GEMM" if "Lb1" in n else "linear GEMM"
+    if "attn_pipe64_kernel" in n:
+        return "attention (self, q-prescaled)"
     if "attn_bf16_kernel" in n:
         return "attention (self, q-prescaled)" if len(a) > 1 and a[1] == "true" else "attention (cross / generic)"
     for k in ("attn_f32", "rownorm", "qknorm_rope", "cast_kernel", "pack_conv", "guidance", "denorm", "rope_table"):
