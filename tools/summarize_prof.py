@@ -32,6 +32,8 @@ def classify(n):
     if "gemm_kernel" in n:
         # rocprofv3 cannot demangle the bf16 template argument of this kernel: "..., ELb1E>" is the CONV=true form
         return "conv3d implicit GEMM" if "Lb1" in n else "linear GEMM"
+    if "attn_cross64_kernel" in n:
+        return "attention (cross / generic)"
     if "attn_pipe64_kernel" in n:
         return "attention (self, q-prescaled)"
     if "attn_bf16_kernel" in n:
