@@ -17,6 +17,12 @@
 #include <mutex>
 #include "gemm_common.h"
 
+#ifndef GEMM_SPREAD
+#define GEMM_SPREAD 0   // 1: next K tile's LDS-DMA pieces issued one at a time between the MFMA groups (measured -4...-8 %)
+#endif
+#ifndef GEMM_ABL
+#define GEMM_ABL 0   // timing ablations (wrong results): bit 0 no operand loads in the K loop, bit 1 no barrier, bit 2 loads never waited for, bit 3 loads all hit one 1-KiB line set
+#endif
 namespace {
 
 constexpr int ROWB = 128;          // bytes per LDS row (64 bf16)
@@ -28,6 +34,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV, bool PIN>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN;                       // waves per block, laid out WGM (M) x WGN (N)
+    constexpr bool SPREAD = GEMM_SPREAD && PIN;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     constexpr int AI = (BM + 8 * NW - 1) / (8 * NW), BI = BN / (8 * NW);   // glds instructions per wave per K-step (A, B)
     constexpr bool A_RAGGED = BM % (8 * NW) != 0;       // e.g. BM = 160: 20 eight-row pieces over 8 waves, the last round half empty
@@ -51,7 +58,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         const int nblk = g.sk_sf > 1 ? g.sk_full : (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int mt = bid / ntn, nt = bid - mt * ntn;
+    // Order of the tiles inside a run: row-major, or columns of group_m row-tiles.  The blocks that run at the same time
+    // on an XCD (32 CUs x blocks per CU, consecutive tile numbers) then cover a near-square patch of the output, and
+    // the A rows + W columns they stream through that XCD's L2 shrink from (1 x C) to (group_m x C/group_m) panels.
+    int mt, nt;
+    if (g.group_m > 1) {
+        const int ntm = (g.M + BM - 1) / BM, gsz = g.group_m * ntn;
+        const int grp = bid / gsz, w = bid - grp * gsz, gm0 = grp * g.group_m;
+        const int rows = ntm - gm0 < g.group_m ? ntm - gm0 : g.group_m;
+        nt = w / rows; mt = gm0 + (w - nt * rows);
+    } else { mt = bid / ntn; nt = bid - mt * ntn; }
     const int m0 = mt * BM, n0 = nt * BN;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
@@ -95,43 +111,56 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     }
     const uint32_t frame_bytes = CONV ? (uint32_t)g.H * g.Wd * g.Cin * 2u : 0u;
     auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
+#if GEMM_ABL & 8
+        voff = (threadIdx.x & 63) * 16; soff = 0;       // every piece re-reads the same 1 KiB (always a cache hit)
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
     };
 
-    auto stage = [&](int kt, int buf) {
-        unsigned char* As = big_smem + buf * STAGE;
-        unsigned char* Bs = As + BM * ROWB;
-        int tap = 0, kk = kt;
-        if constexpr (CONV) { tap = kt / ktiles; kk = kt - tap * ktiles; }
-        int dt = 0, vbit = 0; uint32_t a_soff = (uint32_t)kk * 128u;      // all wave-uniform (scalar) per tap
+    // One K step's operand staging = AI + BI LDS-DMA pieces per wave.  stage_begin resolves the wave-uniform part (tap, K
+    // offset), stage_piece issues piece idx; stage() issues them all back to back.
+    struct StageCtx { unsigned char* As; unsigned char* Bs; int kk, dt, vbit; uint32_t a_soff, b_soff; bool more; };
+    auto stage_begin = [&](int kt, int buf, bool more) {
+        StageCtx c;
+        c.As = big_smem + buf * STAGE; c.Bs = c.As + BM * ROWB; c.more = more;
+        int tap = 0; c.kk = kt;
+        if constexpr (CONV) { tap = kt / ktiles; c.kk = kt - tap * ktiles; }
+        c.dt = 0; c.vbit = 0; c.a_soff = (uint32_t)c.kk * 128u;         // all wave-uniform (scalar) per tap
         if constexpr (CONV) {
             const int khw = g.kh * g.kw;
             const int it = tap / khw; const int rem = tap - it * khw;
             const int ih = rem / g.kw; const int iw = rem - ih * g.kw;
             const int dh = ih - g.kh / 2, dw = iw - g.kw / 2;
-            dt = it - g.pad_t;
-            vbit = (1 << (dh + 1)) | (8 << (dw + 1));
-            a_soff += (uint32_t)((dh * g.Wd + dw) * g.Cin * 2);           // may be "negative": added modulo 2^32 to the lane offset
+            c.dt = it - g.pad_t;
+            c.vbit = (1 << (dh + 1)) | (8 << (dw + 1));
+            c.a_soff += (uint32_t)((dh * g.Wd + dw) * g.Cin * 2);         // may be "negative": added modulo 2^32 to the lane offset
         }
-#pragma unroll
-        for (int j = 0; j < AI; ++j) {
-            bool ok = kk * 64 + a_chunk[j] * 8 < Kdim;
-            if (A_RAGGED && (j * NW + wave) * 8 >= BM) continue;
+        c.b_soff = ((uint32_t)tap * (uint32_t)g.N * (uint32_t)Kdim + (uint32_t)c.kk * 64u) * 2u;
+        return c;
+    };
+    auto stage_piece = [&](const StageCtx& c, int idx) {
+        if (idx < AI) {
+            const int j = idx;
+            bool ok = c.more && c.kk * 64 + a_chunk[j] * 8 < Kdim;
+            if (A_RAGGED && (j * NW + wave) * 8 >= BM) return;
             if constexpr (CONV) {
-                int tt = ct[j] + dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);      // replicate pad on T (vae.rs:374-413)
-                ok = ok && (vmask[j] & vbit) == vbit;                                        // zero pad on H/W (vae.rs:337-349)
-                const uint32_t voff = a_off[j] + (uint32_t)(tt - ct[j]) * frame_bytes + a_soff;
-                dma(ra, ok ? voff : OOB, 0u, As + (j * NW + wave) * 1024);
+                int tt = ct[j] + c.dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);    // replicate pad on T (vae.rs:374-413)
+                ok = ok && (vmask[j] & c.vbit) == c.vbit;                                    // zero pad on H/W (vae.rs:337-349)
+                const uint32_t voff = a_off[j] + (uint32_t)(tt - ct[j]) * frame_bytes + c.a_soff;
+                dma(ra, ok ? voff : OOB, 0u, c.As + (j * NW + wave) * 1024);
             } else {
-                dma(ra, ok ? a_off[j] : OOB, a_soff, As + (j * NW + wave) * 1024);
+                dma(ra, ok ? a_off[j] : OOB, c.a_soff, c.As + (j * NW + wave) * 1024);
             }
+        } else {
+            const int j = idx - AI;
+            const bool ok = c.more && c.kk * 64 + b_chunk[j] * 8 < Kdim;
+            dma(rw, ok ? b_off[j] : OOB, c.b_soff, c.Bs + (j * NW + wave) * 1024);
         }
-        const uint32_t b_soff = ((uint32_t)tap * (uint32_t)g.N * (uint32_t)Kdim + (uint32_t)kk * 64u) * 2u;
+    };
+    auto stage = [&](int kt, int buf) {
+        const StageCtx c = stage_begin(kt, buf, true);
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            const bool ok = kk * 64 + b_chunk[j] * 8 < Kdim;
-            dma(rw, ok ? b_off[j] : OOB, b_soff, Bs + (j * NW + wave) * 1024);
-        }
+        for (int i = 0; i < AI + BI; ++i) stage_piece(c, i);
     };
 
     f32x4 acc[FM][FN];
@@ -148,7 +177,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     const int frow = lane & 15, fq = lane >> 4;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+        StageCtx nxt;
+#if !(GEMM_ABL & 1)
+        if constexpr (SPREAD) nxt = stage_begin(kt + 1 < kt1 ? kt + 1 : kt, buf ^ 1, kt + 1 < kt1);   // branch-free, pieces issued between the MFMA groups below
+        else if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+#endif
         const unsigned char* As = big_smem + buf * STAGE;
         const unsigned char* Bs = As + BM * ROWB;
         // Fragment stream: W fragments of the k-block stay in registers, A fragments are read ONE AHEAD of the
@@ -165,6 +198,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                 if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + swz_big(wm * WM + (fm + 1) * 16 + frow, kb * 4 + fq));
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
+#if !(GEMM_ABL & 1)
+                if constexpr (SPREAD) {
+                    constexpr int NG = 2 * FM, ND = AI + BI;
+                    const int gidx = kb * FM + fm;
+                    if (((gidx + 1) * ND) / NG > (gidx * ND) / NG) stage_piece(nxt, (gidx * ND) / NG);
+                }
+#endif
             }
         }
         if constexpr (PIN) {
@@ -175,10 +215,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                 for (int fm = 0; fm < FM; ++fm) {
                     if (fm + 1 < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // next A frag
                     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);            // MFMAs of the current A frag
+                    if constexpr (SPREAD) {
+                        // the next K tile's LDS-DMA pieces, one at a time between MFMA groups: a wave that issues them
+                        // back to back stalls in the load queue's back-pressure with no MFMA of its own in flight
+                        constexpr int NG = 2 * FM, ND = AI + BI;
+                        const int gidx = kb * FM + fm;
+                        static_assert(ND <= NG, "at most one piece per MFMA group");
+                        if (((gidx + 1) * ND) / NG > (gidx * ND) / NG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
         }
+#if GEMM_ABL & 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif GEMM_ABL & 4
+        __builtin_amdgcn_s_barrier();                  // loads issued but never waited for
+#else
         __syncthreads();
+#endif
     }
 
     if (split) {
@@ -298,6 +352,16 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
     LTX_TRY(plan_tail_split(&ga, tiles, BM, BN, 64 * WGM * WGN, smem, s));
+    {   // tile order inside an XCD's run: the C blocks one XCD runs at once (32 CUs x blocks per CU) should cover a
+        // patch of pm x pn tiles minimising pm*BM + pn*BN, i.e. pm = sqrt(C*BN/BM)
+        int per_cu = (160 * 1024) / smem; if (per_cu > 2048 / (64 * WGM * WGN)) per_cu = 2048 / (64 * WGM * WGN); if (per_cu < 1) per_cu = 1;
+        const int C = 32 * per_cu;
+        int gm = 1; while ((gm + 1) * (gm + 1) * BM <= C * BN) ++gm;
+        if (const char* e = getenv("LTX_GEMM_GROUP_M")) { const int env_gm = atoi(e); if (env_gm >= 0) gm = env_gm; }   // tuning aid: 0/1 row-major
+        const int ntm = cdiv(g.M, BM);
+        if (gm > ntm) gm = ntm;
+        ga.group_m = (CONV || gm < 2) ? 0 : gm;
+    }
     dim3 grid((unsigned)(ga.sk_sf > 1 ? ga.sk_full + (tiles - ga.sk_full) * ga.sk_sf : tiles)), block(64 * WGM * WGN);
     hipLaunchKernelGGL(kern, grid, block, smem, s, ga);
     LTX_CHECK_LAUNCH();
