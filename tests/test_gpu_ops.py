@@ -433,3 +433,42 @@ def test_linear_segmented_matches_plain_linear(dtype, M, N, K, seg):
         assert torch.equal(segd[j], plain[:, j * seg:(j + 1) * seg])
     with pytest.raises(Exception):
         ops.linear_segmented(x, w, b, 96)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Sk", [1, 7, 31, 32, 33, 64, 100, 127, 128])
+def test_attention_short_key_kernel_vs_cpu(hip, Sk, monkeypatch):
+    """head_dim 64, <= 128 keys (the DiT's cross-attention): K/V resident in LDS, one-shot softmax.  Against the f32 CPU
+    reference with and without the additive key mask, ragged query counts, batch 2; and against the generic tiled kernel."""
+    heads, hd = 3, 64
+    for Sq, B, biased in [(1, 1, False), (31, 2, True), (500, 2, True), (333, 1, False)]:
+        q, k, v = rnd(torch.bfloat16, B, Sq, heads * hd, seed=Sk), rnd(torch.bfloat16, B, Sk, heads * hd, seed=Sk + 1), rnd(torch.bfloat16, B, Sk, heads * hd, seed=Sk + 2)
+        bias = None
+        if biased:
+            bias = torch.zeros(B, Sk); bias[:, Sk // 3 + 1:] = -10000.0; bias[0, 0] = -1.5     # reference mask value (ltx_transformer.rs:1063)
+        args = (q.cuda(), k.cuda(), v.cuda(), heads, 0.125, bias.cuda() if biased else None)
+        o = hip.ops.attention(*args)
+        ref = ref_attention(q, k, v, heads, 0.125, bias)
+        assert rel_l2(o.float().cpu(), ref) <= BF16_TOL, (Sq, Sk, B, biased, rel_l2(o.float().cpu(), ref))
+        monkeypatch.setenv("LTX_ATTN_CROSS", "0")
+        o_generic = hip.ops.attention(*args)
+        monkeypatch.delenv("LTX_ATTN_CROSS")
+        assert rel_l2(o.float().cpu(), o_generic.float().cpu()) <= BF16_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Sk", [129, 192, 193, 256, 257, 320, 321, 384, 449, 512, 513, 577, 640, 4992])
+def test_attention_pipelined_kernel_tile_counts(hip, Sk, monkeypatch):
+    """The two-tile pipelined head_dim-64 kernel (4-slot LDS-DMA ring, loop unrolled by four): every prologue / remainder
+    path (3..10 tiles, full and ragged last tile) against the f32 CPU reference and the one-tile-at-a-time kernel."""
+    heads, hd, Sq = 2, 64, 200
+    q, k, v = rnd(torch.bfloat16, 1, Sq, heads * hd, seed=Sk), rnd(torch.bfloat16, 1, Sk, heads * hd, seed=Sk + 1), rnd(torch.bfloat16, 1, Sk, heads * hd, seed=Sk + 2)
+    k[0, Sk - 2] = q[0, 7] * 6.0                        # late dominant key: rescale on the last tile, pending S^T shifted with it
+    k[0, 70] = q[0, 9] * 5.0                            # and one on the second tile
+    qp = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
+    o = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
+    ref = ref_attention(qp, k, v, heads, math.log(2.0), None)
+    assert rel_l2(o.float().cpu(), ref) <= BF16_TOL, (Sk, rel_l2(o.float().cpu(), ref))
+    monkeypatch.setenv("LTX_ATTN_PIPE", "0")
+    o1 = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel_l2(o.float().cpu(), o1.float().cpu()) <= BF16_TOL
