@@ -123,12 +123,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     auto stage_begin = [&](int kt, int buf, bool more) {
         StageCtx c;
         c.As = big_smem + buf * STAGE; c.Bs = c.As + BM * ROWB; c.more = more;
+        // K-step order of a conv (shared by every bf16 conv kernel, so plans stay bit-identical): frame tap, then the
+        // 64-channel slice, then the kh x kw in-plane taps - consecutive steps re-read the same voxels shifted by one
         int tap = 0; c.kk = kt;
-        if constexpr (CONV) { tap = kt / ktiles; c.kk = kt - tap * ktiles; }
+        int it = 0, hw = 0;
+        if constexpr (CONV) {
+            const int khw = g.kh * g.kw, per_it = ktiles * khw;
+            it = kt / per_it; const int r2 = kt - it * per_it;
+            c.kk = r2 / khw; hw = r2 - c.kk * khw;
+            tap = it * khw + hw;
+        }
         c.dt = 0; c.vbit = 0; c.a_soff = (uint32_t)c.kk * 128u;         // all wave-uniform (scalar) per tap
         if constexpr (CONV) {
-            const int khw = g.kh * g.kw;
-            const int it = tap / khw; const int rem = tap - it * khw;
+            const int rem = hw;
             const int ih = rem / g.kw; const int iw = rem - ih * g.kw;
             const int dh = ih - g.kh / 2, dw = iw - g.kw / 2;
             c.dt = it - g.pad_t;

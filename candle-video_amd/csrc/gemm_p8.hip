@@ -94,10 +94,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
     // stage cursor: K-tile being staged -> (tap, k offset); advanced after the 4th half (A1) of a K-tile
     int c_kk = 0, c_it = 0, c_ih = 0, c_iw = 0, c_tap = 0, c_tile = 0;
     auto cursor_next = [&]() {
+        // same K-step order as gemm_big's conv mode: frame tap, 64-channel slice, in-plane taps (fastest)
         ++c_tile;
-        if (++c_kk == ktiles) {
-            c_kk = 0; ++c_tap;
-            if constexpr (CONV) { if (++c_iw == g.kw) { c_iw = 0; if (++c_ih == g.kh) { c_ih = 0; ++c_it; } } }
+        if constexpr (CONV) {
+            if (++c_iw == g.kw) { c_iw = 0; if (++c_ih == g.kh) { c_ih = 0; if (++c_kk == ktiles) { c_kk = 0; ++c_it; } } }
+            c_tap = (c_it * g.kh + c_ih) * g.kw + c_iw;
+        } else {
+            ++c_kk;
         }
     };
     auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
