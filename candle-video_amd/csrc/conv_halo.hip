@@ -1,0 +1,235 @@
+// 3x3x3 conv3d (LtxVideoCausalConv3d, vae.rs:308-465) as an implicit GEMM whose activation operand is staged ONCE per
+// (frame tap, 64-channel slice) for all nine in-plane taps.
+//
+// gemm_big / gemm_p8 in conv mode re-stage the M-tile's activation rows for every one of the 27 taps; their loads
+// (global -> LDS by LDS-DMA) cost 35-50 % of the kernel on the 128..512-channel VAE stages (timing ablations in
+// DESIGN.md).  Here the output tile is a 16 x 16 patch of voxels of one frame and LDS holds the patch plus its one-voxel
+// rim (18 x 18 "halo rows" of 64 channels, 41 KiB): the 3 x 3 in-plane taps of that frame tap and channel slice are
+// nine shifted fragment-read patterns over the same LDS image.  Per nine taps a block stages 41.5 KiB of activation
+// (was 9 x 32 KiB for a 256-row tile) plus the nine weight tiles: 2.5 x fewer LDS-DMA instructions per MFMA.
+//
+//   * 512 threads = 8 waves; BN = 128: 4(M) x 2(N) waves of 64 x 64, BN = 256: 2(M) x 4(N) waves of 128 x 64;
+//     v_mfma_f32_16x16x32_bf16, D = Wfrag x Afrag (a lane owns 4 consecutive output channels: shared epilogues);
+//   * K-step order = the order of every bf16 conv kernel here (frame tap, channel slice, in-plane tap), same MFMA and
+//     k-grouping, so this plan is bit-identical to the others;
+//   * halo image double-buffered (next slice's pieces are issued one round per step during the first six steps of the
+//     current slice), weight tiles double-buffered, one vmcnt(0) + barrier per step;
+//   * zero padding in H/W and the halo rows outside the image are out-of-range buffer offsets (read as zeros); the
+//     temporal replicate padding is a clamp of the frame index (vae.rs:374-413).
+#include <type_traits>
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int ROWB = 128;
+constexpr int PH = 16, PW = 16, HW = PW + 2, HROWS = (PH + 2) * HW;      // 18 x 18 = 324 halo rows
+constexpr int A_PIECES = (HROWS + 7) / 8;                                  // 41 pieces of 8 rows (1 KiB)
+constexpr int A_STAGE = A_PIECES * 1024;
+constexpr uint32_t OOB = 0x80000000u;
+
+__device__ __forceinline__ int swz_h(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+extern __shared__ __attribute__((aligned(16))) unsigned char halo_smem[];
+
+template <int BN, int WGM, int WGN, int EPI>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
+    constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    static_assert(NW == 8 && WM % 16 == 0 && WN % 16 == 0, "wave layout");
+    constexpr int AJ = (A_PIECES + NW - 1) / NW, BJ = BN / (8 * NW);
+    constexpr int B_STAGE = BN * ROWB;
+    unsigned char* Abuf = halo_smem;
+    unsigned char* Bbuf = halo_smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- tile: (batch*frame, patch row, patch column, n tile); each XCD gets a contiguous run (neighbouring patches
+    // share their rims and every patch's n tiles share the whole halo image through one L2)
+    const int ntn = g.N / BN, pwn = (g.Wd + PW - 1) / PW, phn = (g.H + PH - 1) / PH;
+    int bid = blockIdx.x;
+    {
+        const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int nt = bid % ntn; int rr = bid / ntn;
+    const int px = rr % pwn; rr /= pwn;
+    const int py = rr % phn; const int bt = rr / phn;
+    const int t = bt % g.T, b = bt / g.T;
+    const int y0 = py * PH, x0 = px * PW, n0 = nt * BN;
+
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
+    auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+    };
+
+    // ---- per-lane staging geometry.  Piece p of the halo image = halo rows 8p .. 8p+7; lane -> (row = lane>>3, physical
+    // 16-B chunk = lane&7); the bank swizzle (chunk ^ ((row>>1)&7)) is applied to the SOURCE chunk (lane-linear LDS image).
+    const int lr = lane >> 3, pc = lane & 7;
+    uint32_t a_voff[AJ], b_voff[BJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int hrow = (j * NW + wave) * 8 + lr;
+        const int hy = hrow / HW, hx = hrow - hy * HW;
+        const int lc = pc ^ ((hx >> 1) & 7);                 // halo image: swizzle by the COLUMN of the halo row (see the reads)
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = hrow < HROWS && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+        a_voff[j] = ok ? (uint32_t)(((y * g.Wd + x) * g.Cin + lc * 8) * 2) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (j * NW + wave) * 8 + lr;
+        const int lc = pc ^ ((row >> 1) & 7);
+        b_voff[j] = (uint32_t)((((n0 + row) * g.K) + lc * 8) * 2);
+    }
+    const int KC = g.Cin / 64;                              // 64-channel slices
+    const int KT = g.ntaps / 9;                             // frame taps (3)
+    const int G = KT * KC;                                  // (frame tap, slice) groups, nine steps each
+    const uint32_t frame_bytes = (uint32_t)g.H * g.Wd * g.Cin * 2u;
+    auto issue_a = [&](int grp, int j) {                    // piece round j of group grp's halo image
+        const int piece = j * NW + wave;
+        if (piece >= A_PIECES) return;
+        const int it = grp / KC, kc = grp - it * KC;
+        int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);          // replicate pad on T (vae.rs:374-413)
+        const uint32_t soff = (uint32_t)(b * g.T + tt) * frame_bytes + (uint32_t)kc * 128u;
+        dma(ra, a_voff[j], soff, Abuf + (grp & 1) * A_STAGE + piece * 1024);
+    };
+    auto issue_b = [&](int grp, int hw, int buf) {          // weight tile of step (grp, hw)
+        const int it = grp / KC, kc = grp - it * KC;
+        const uint32_t soff = ((uint32_t)(it * 9 + hw) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) dma(rw, b_voff[j], soff, Bbuf + buf * B_STAGE + (j * NW + wave) * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Fragment-read addresses of the halo image.  MFMA block fm = patch row wm*FM + fm, lane = patch column frow; tap
+    // (ih, iw) reads halo row (prow + ih) * HW + frow + iw.  The bank swizzle is a function of the halo COLUMN
+    // (frow + iw), so the address is  rowbase[fm] + colpart[iw][kb] + ih * HW * 128 : the ih shift is an instruction
+    // immediate and only 3 x 2 lane-dependent column terms exist (a swizzle by halo row would need one address
+    // register per tap, block and k half).
+    int rowbase[FM], colpart[3][2];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) rowbase[fm] = ((wm * FM + fm) * HW + frow) * ROWB;
+#pragma unroll
+    for (int iw = 0; iw < 3; ++iw)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) colpart[iw][kb] = iw * ROWB + (((kb * 4 + fq) ^ (((frow + iw) >> 1) & 7)) << 4);
+
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) issue_a(0, j);
+    issue_b(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto step = [&](int grp, auto hw_tag, int buf) {
+        constexpr int hw = decltype(hw_tag)::value;
+        constexpr int ih = hw / 3, iw = hw % 3;                     // dh = ih - 1, dw = iw - 1
+        // next step's weight tile; next group's halo image, one piece round per step
+        if (hw < 8) issue_b(grp, hw + 1, buf ^ 1); else if (grp + 1 < G) issue_b(grp + 1, 0, buf ^ 1);
+        if (hw < AJ && grp + 1 < G) issue_a(grp + 1, hw);
+        const unsigned char* As = Abuf + (grp & 1) * A_STAGE;
+        const unsigned char* Bs = Bbuf + buf * B_STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            Chunk16 af[FM], wf[FN];
+#pragma unroll
+            for (int f = 0; f < FN; ++f) wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_h(wn * WN + f * 16 + frow, kb * 4 + fq));
+            af[0].u = *reinterpret_cast<const u32x4*>(As + rowbase[0] + colpart[iw][kb] + ih * HW * ROWB);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + rowbase[fm + 1] + colpart[iw][kb] + ih * HW * ROWB);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            __builtin_amdgcn_sched_group_barrier(0x100, FN + 1, 0);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                if (fm + 1 < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    static_assert(AJ <= 9, "one halo piece round per step");
+    for (int grp = 0; grp < G; ++grp) {
+        // nine steps = 9 weight buffers alternations: the parity of the buffer flips between groups (9 is odd)
+        const int p = grp & 1;
+        step(grp, std::integral_constant<int, 0>{}, p);
+        step(grp, std::integral_constant<int, 1>{}, p ^ 1);
+        step(grp, std::integral_constant<int, 2>{}, p);
+        step(grp, std::integral_constant<int, 3>{}, p ^ 1);
+        step(grp, std::integral_constant<int, 4>{}, p);
+        step(grp, std::integral_constant<int, 5>{}, p ^ 1);
+        step(grp, std::integral_constant<int, 6>{}, p);
+        step(grp, std::integral_constant<int, 7>{}, p ^ 1);
+        step(grp, std::integral_constant<int, 8>{}, p);
+    }
+
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int y = y0 + wm * FM + fm, x = x0 + frow;
+        if (y >= g.H || x >= g.Wd) continue;
+        const int m = ((b * g.T + t) * g.H + y) * g.Wd + x;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+            float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
+            epilogue<bf16_t, EPI>(g, m, nb, v);
+        }
+    }
+}
+
+template <int BN, int WGM, int WGN, int EPI>
+int launch_halo(const GemmArgs& g, hipStream_t s) {
+    constexpr int smem = 2 * A_STAGE + 2 * BN * ROWB;
+    static bool attr_set = false;
+    auto kern = conv_halo_kernel<BN, WGM, WGN, EPI>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, g);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+template <int BN, int WGM, int WGN>
+int launch_halo_epi(const GemmArgs& g, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BIAS: return launch_halo<BN, WGM, WGN, EPI_BIAS>(g, s);
+        case EPI_RESID: return launch_halo<BN, WGM, WGN, EPI_RESID>(g, s);
+        case EPI_D2S: return launch_halo<BN, WGM, WGN, EPI_D2S>(g, s);
+    }
+    LTX_FAIL(LTX_ERR_ARG, "conv_halo: unsupported epilogue");
+}
+
+}  // namespace
+
+// whether the halo-staged kernel can run this conv with tile width bn (128 / 256)
+bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
+    if (!g.conv || g.ntaps != 27 || g.kh != 3 || g.kw != 3) return false;
+    if (g.Cin % 64 != 0 || g.K != g.Cin || g.N % bn != 0) return false;
+    if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
+    if (g.c_seg_shift) return false;
+    const double a_bytes = (double)g.M * g.Cin * 2.0, w_bytes = 27.0 * g.N * g.K * 2.0;
+    return a_bytes < 2147483648.0 && w_bytes < 2147483648.0;
+}
+
+int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
+    if (!ltx_conv_halo_eligible(g, epi, bn)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: shape not eligible");
+    if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
+    return launch_halo_epi<128, 4, 2>(g, epi, s);
+}

@@ -450,6 +450,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
 // LTX_GEMM_TILE / LTX_GEMM_P8 force a plan (tests, A/B runs).
 namespace {
 constexpr int kPlanP8 = 100;
+constexpr int kPlanHalo = 200;           // + {0: BN=128, 1: BN=256} (conv_halo.hip)
 struct PlanKey {
     int M, N, K, conv, ntaps, T, H, W;
     bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
@@ -458,6 +459,11 @@ std::map<PlanKey, int> g_plans;
 std::mutex g_plan_mu;
 
 int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
+    if (plan >= kPlanHalo) {
+        const int bn = plan == kPlanHalo ? 128 : 256;
+        if (ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
+        plan = ltx_gemm_big_pick_tile(g.M, g.N);           // an epilogue the halo kernel does not carry
+    }
     if (plan >= kPlanP8) return ltx_launch_gemm_p8(g, epi, plan == kPlanP8 ? 256 : 128, s);
     return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
 }
@@ -474,11 +480,16 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     float best = 1e30f;
     const char* p8e = getenv("LTX_GEMM_P8");
     const bool p8_off = p8e && p8e[0] == '0';
-    for (int plan = 0; plan < kPlanP8 + 2; ++plan) {
+    const char* he = getenv("LTX_CONV_HALO");
+    const bool halo_off = he && he[0] == '0';
+    for (int plan = 0; plan < kPlanHalo + 2; ++plan) {
         if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
             if (!tile_fits(kTiles[plan], g.N)) continue;
-        } else if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
+        } else if (plan < kPlanHalo) {
+            if (plan >= kPlanP8 + 2) { plan = kPlanHalo - 1; continue; }
+            if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
+        } else if (halo_off || !ltx_conv_halo_eligible(g, EPI_BIAS, plan == kPlanHalo ? 128 : 256)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
         // 3..16 of them, best of two rounds
         HIP_TRY(hipEventRecord(e0, s));
@@ -510,6 +521,10 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
     const char* xr = getenv("LTX_XCD_REMAP");
     g.xcd_remap = xr ? (xr[0] == '1') : 1;
+    if (const char* he = getenv("LTX_CONV_HALO")) {        // "128" / "256" force the halo-staged conv kernel where eligible (tests, A/B)
+        const int bn = atoi(he);
+        if ((bn == 128 || bn == 256) && ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
+    }
     const int p8 = ltx_gemm_p8_choice(g);
     if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
     int plan = ltx_gemm_big_pick_tile(g.M, g.N);
@@ -539,5 +554,6 @@ const char* ltx_gemm_plan_name(int M, int N, int K, int conv, int ntaps, int T, 
     std::lock_guard<std::mutex> lock(g_plan_mu);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) return "";
+    if (it->second >= kPlanHalo) return it->second == kPlanHalo ? "halo:128" : "halo:256";
     return it->second >= kPlanP8 ? (it->second == kPlanP8 ? "p8:256" : "p8:128") : kTiles[it->second].name;
 }

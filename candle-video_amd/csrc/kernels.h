@@ -48,7 +48,10 @@ int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
 int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table
 int ltx_gemm_p8_choice(const GemmArgs& g);  // gemm_p8.hip: phase-interleaved 256-row kernel; returns BN (256/128) or 0
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s);
-bool ltx_gemm_p8_fits(const GemmArgs& g);   // operands addressable with the kernel's 32-bit buffer offsets
+bool ltx_gemm_p8_fits(const GemmArgs& g);
+// conv_halo.hip: 3x3x3 conv with the activation patch + rim staged once per nine in-plane taps; bn = 128 / 256
+bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn);
+int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s);   // operands addressable with the kernel's 32-bit buffer offsets
 
 // ---------------- row norms (rownorm.hip) ----------------
 struct RowNormArgs {

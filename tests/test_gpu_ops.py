@@ -472,3 +472,29 @@ def test_attention_pipelined_kernel_tile_counts(hip, Sk, monkeypatch):
     monkeypatch.setenv("LTX_ATTN_PIPE", "0")
     o1 = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
     assert rel_l2(o.float().cpu(), o1.float().cpu()) <= BF16_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn", ["128", "256"])
+@pytest.mark.parametrize("B,Cin,Cout,T,H,W,causal", [(1, 64, 256, 3, 20, 37, False), (2, 128, 256, 2, 16, 16, True), (1, 192, 512, 4, 33, 18, False),
+                                                     (1, 128, 256, 1, 5, 7, True)])
+def test_conv3d_halo_staged_kernel(hip, bn, B, Cin, Cout, T, H, W, causal, monkeypatch):
+    """conv_halo.hip (activation patch + rim staged once per nine in-plane taps): bit-identical to the per-tap kernels
+    (same K-step order and MFMA), within bf16 tolerance of the CPU oracle; ragged patches, batch, causal / non-causal
+    temporal padding, residual and depth-to-space epilogues."""
+    dt = torch.bfloat16
+    x, w, b = rnd(dt, B, Cin, T, H, W), rnd(dt, Cout, Cin, 3, 3, 3, scale=(27 * Cin) ** -0.5), rnd(dt, Cout, scale=0.1)
+    r = rnd(dt, B, Cout, T, H, W, seed=5)
+    xc, rc = cl(x).cuda(), cl(r).cuda()
+    monkeypatch.setenv("LTX_CONV_HALO", "0")
+    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
+    base = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal)
+    base_res = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc)
+    base_up = hip.ops.upsample3d(xc, w.cuda(), b.cuda(), causal)
+    monkeypatch.setenv("LTX_CONV_HALO", bn)
+    y = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal)
+    assert torch.equal(y, base)
+    assert torch.equal(hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc), base_res)
+    assert torch.equal(hip.ops.upsample3d(xc, w.cuda(), b.cuda(), causal), base_up)
+    ref = O.causal_conv3d(x.float(), w.float(), b.float(), causal)
+    check(ncthw(y), ref, dt)
