@@ -17,6 +17,9 @@
 #include <mutex>
 #include "gemm_common.h"
 
+#ifndef GEMM_LOADERS
+#define GEMM_LOADERS 4   // 8: every wave issues its share of the LDS-DMA pieces; 4: the first wave of each SIMD issues them all
+#endif
 #ifndef GEMM_SPREAD
 #define GEMM_SPREAD 0   // 1: next K tile's LDS-DMA pieces issued one at a time between the MFMA groups (measured -4...-8 %)
 #endif
@@ -36,11 +39,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     constexpr int NW = WGM * WGN;                       // waves per block, laid out WGM (M) x WGN (N)
     constexpr bool SPREAD = GEMM_SPREAD && PIN;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
-    constexpr int AI = (BM + 8 * NW - 1) / (8 * NW), BI = BN / (8 * NW);   // glds instructions per wave per K-step (A, B)
-    constexpr bool A_RAGGED = BM % (8 * NW) != 0;       // e.g. BM = 160: 20 eight-row pieces over 8 waves, the last round half empty
-    static_assert(BM % 8 == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
+    // Loader waves.  All waves of a block queue at the CU's one load pipe (L2 -> LDS, ~110 GB/s per CU) when they issue
+    // their LDS-DMA pieces, and an in-order wave issues no MFMA while it waits there.  With GEMM_LOADERS = 4 only the
+    // first wave of every SIMD (waves 0..3) issues pieces, twice as many each; its SIMD partner (wave + 4) goes straight
+    // to its MFMAs and keeps the matrix pipe busy meanwhile (measured with tools/ubench/dma_vs_mfma.hip: a partner
+    // pushing a whole K-step's 64 KiB slows a wave's MFMA stream by 15 %).
+    constexpr int NL = (GEMM_LOADERS == 4 && NW == 8) ? 4 : NW;
+    constexpr int AI = (BM + 8 * NL - 1) / (8 * NL), BI = BN / (8 * NL);   // glds instructions per loader wave per K-step (A, B)
+    constexpr bool A_RAGGED = BM % (8 * NL) != 0;       // e.g. BM = 160: 20 eight-row pieces over 8 waves, the last round half empty
+    static_assert(BM % 8 == 0 && BN % (8 * NL) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
     constexpr int STAGE = (BM + BN) * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lwave = NL == NW ? wave : (wave & (NL - 1));            // piece owner index (non-loader waves compute offsets they never use)
+    const bool loader = NL == NW || __builtin_amdgcn_readfirstlane(wave) < NL;
     const int wm = wave / WGN, wn = wave % WGN;
     const int ntn = (g.N + BN - 1) / BN;
     // XCD-aware tile order (speed only, bijective for any grid): blocks b and b+8 share an XCD/L2, so XCD x is
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     uint32_t b_off[BI];
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-        const int row = 8 * (j * NW + wave) + lr;
+        const int row = 8 * (j * NL + lwave) + lr;
         a_chunk[j] = pc ^ ((row >> 1) & 7);
         int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
         if constexpr (CONV) {
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int row = 8 * (j * NW + wave) + lr;
+        const int row = 8 * (j * NL + lwave) + lr;
         b_chunk[j] = pc ^ ((row >> 1) & 7);
         int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
         b_off[j] = ((uint32_t)n * (uint32_t)Kdim + b_chunk[j] * 8) * 2u;
@@ -149,22 +160,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         if (idx < AI) {
             const int j = idx;
             bool ok = c.more && c.kk * 64 + a_chunk[j] * 8 < Kdim;
-            if (A_RAGGED && (j * NW + wave) * 8 >= BM) return;
+            if (A_RAGGED && (j * NL + lwave) * 8 >= BM) return;
             if constexpr (CONV) {
                 int tt = ct[j] + c.dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);    // replicate pad on T (vae.rs:374-413)
                 ok = ok && (vmask[j] & c.vbit) == c.vbit;                                    // zero pad on H/W (vae.rs:337-349)
                 const uint32_t voff = a_off[j] + (uint32_t)(tt - ct[j]) * frame_bytes + c.a_soff;
-                dma(ra, ok ? voff : OOB, 0u, c.As + (j * NW + wave) * 1024);
+                dma(ra, ok ? voff : OOB, 0u, c.As + (j * NL + lwave) * 1024);
             } else {
-                dma(ra, ok ? a_off[j] : OOB, c.a_soff, c.As + (j * NW + wave) * 1024);
+                dma(ra, ok ? a_off[j] : OOB, c.a_soff, c.As + (j * NL + lwave) * 1024);
             }
         } else {
             const int j = idx - AI;
             const bool ok = c.more && c.kk * 64 + b_chunk[j] * 8 < Kdim;
-            dma(rw, ok ? b_off[j] : OOB, c.b_soff, c.Bs + (j * NW + wave) * 1024);
+            dma(rw, ok ? b_off[j] : OOB, c.b_soff, c.Bs + (j * NL + lwave) * 1024);
         }
     };
     auto stage = [&](int kt, int buf) {
+        if (!loader) return;
         const StageCtx c = stage_begin(kt, buf, true);
 #pragma unroll
         for (int i = 0; i < AI + BI; ++i) stage_piece(c, i);
