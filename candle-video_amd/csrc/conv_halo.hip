@@ -19,6 +19,10 @@
 #include <type_traits>
 #include "gemm_common.h"
 
+#ifndef HALO_LOADERS
+#define HALO_LOADERS 4
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;
@@ -35,13 +39,18 @@ template <int BN, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     static_assert(NW == 8 && WM % 16 == 0 && WN % 16 == 0, "wave layout");
-    constexpr int AJ = (A_PIECES + NW - 1) / NW, BJ = BN / (8 * NW);
+    // loader waves: the first wave of every SIMD issues all LDS-DMA pieces, its partner (wave + 4) starts on its MFMAs at
+    // once (see gemm_big.hip)
+    constexpr int NL = (HALO_LOADERS == 4 && BN == 128) ? 4 : NW;      // measured: +3..9 % at BN = 128, -4 % at BN = 256
+    constexpr int AJ = (A_PIECES + NL - 1) / NL, BJ = BN / (8 * NL);
     constexpr int B_STAGE = BN * ROWB;
     unsigned char* Abuf = halo_smem;
     unsigned char* Bbuf = halo_smem + 2 * A_STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    const int lwave = wave & (NL - 1);
+    const bool loader = wave < NL;
     const int frow = lane & 15, fq = lane >> 4;
 
     // ---- tile: (batch*frame, patch row, patch column, n tile); each XCD gets a contiguous run (neighbouring patches
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     uint32_t a_voff[AJ], b_voff[BJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int hrow = (j * NW + wave) * 8 + lr;
+        const int hrow = (j * NL + lwave) * 8 + lr;
         const int hy = hrow / HW, hx = hrow - hy * HW;
         const int lc = pc ^ ((hx >> 1) & 7);                 // halo image: swizzle by the COLUMN of the halo row (see the reads)
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int row = (j * NW + wave) * 8 + lr;
+        const int row = (j * NL + lwave) * 8 + lr;
         const int lc = pc ^ ((row >> 1) & 7);
         b_voff[j] = (uint32_t)((((n0 + row) * g.K) + lc * 8) * 2);
     }
@@ -90,18 +99,19 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const int G = KT * KC;                                  // (frame tap, slice) groups, nine steps each
     const uint32_t frame_bytes = (uint32_t)g.H * g.Wd * g.Cin * 2u;
     auto issue_a = [&](int grp, int j) {                    // piece round j of group grp's halo image
-        const int piece = j * NW + wave;
-        if (piece >= A_PIECES) return;
+        const int piece = j * NL + lwave;
+        if (!loader || piece >= A_PIECES) return;
         const int it = grp / KC, kc = grp - it * KC;
         int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);          // replicate pad on T (vae.rs:374-413)
         const uint32_t soff = (uint32_t)(b * g.T + tt) * frame_bytes + (uint32_t)kc * 128u;
         dma(ra, a_voff[j], soff, Abuf + (grp & 1) * A_STAGE + piece * 1024);
     };
     auto issue_b = [&](int grp, int hw, int buf) {          // weight tile of step (grp, hw)
+        if (!loader) return;
         const int it = grp / KC, kc = grp - it * KC;
         const uint32_t soff = ((uint32_t)(it * 9 + hw) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) dma(rw, b_voff[j], soff, Bbuf + buf * B_STAGE + (j * NW + wave) * 1024);
+        for (int j = 0; j < BJ; ++j) dma(rw, b_voff[j], soff, Bbuf + buf * B_STAGE + (j * NL + lwave) * 1024);
     };
 
     f32x4 acc[FM][FN];
@@ -134,7 +144,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         constexpr int ih = hw / 3, iw = hw % 3;                     // dh = ih - 1, dw = iw - 1
         // next step's weight tile; next group's halo image, one piece round per step
         if (hw < 8) issue_b(grp, hw + 1, buf ^ 1); else if (grp + 1 < G) issue_b(grp + 1, 0, buf ^ 1);
-        if (hw < AJ && grp + 1 < G) issue_a(grp + 1, hw);
+        constexpr int RPS = (AJ + 8) / 9;                           // halo piece rounds per step
+        if (grp + 1 < G) {
+#pragma unroll
+            for (int rr = 0; rr < RPS; ++rr) if (hw * RPS + rr < AJ) issue_a(grp + 1, hw * RPS + rr);
+        }
         const unsigned char* As = Abuf + (grp & 1) * A_STAGE;
         const unsigned char* Bs = Bbuf + buf * B_STAGE;
 #pragma unroll
@@ -162,7 +176,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    static_assert(AJ <= 9, "one halo piece round per step");
     for (int grp = 0; grp < G; ++grp) {
         // nine steps = 9 weight buffers alternations: the parity of the buffer flips between groups (9 is odd)
         const int p = grp & 1;
