@@ -20,9 +20,6 @@
 #ifndef GEMM_LOADERS
 #define GEMM_LOADERS 4   // 8: every wave issues its share of the LDS-DMA pieces; 4: the first wave of each SIMD issues them all
 #endif
-#ifndef GEMM_SPREAD
-#define GEMM_SPREAD 0   // 1: next K tile's LDS-DMA pieces issued one at a time between the MFMA groups (measured -4...-8 %)
-#endif
 #ifndef GEMM_ABL
 #define GEMM_ABL 0   // timing ablations (wrong results): bit 0 no operand loads in the K loop, bit 1 no barrier, bit 2 loads never waited for, bit 3 loads all hit one 1-KiB line set
 #endif
@@ -37,7 +34,6 @@ extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV, bool PIN>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN;                       // waves per block, laid out WGM (M) x WGN (N)
-    constexpr bool SPREAD = GEMM_SPREAD && PIN;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     // Loader waves.  All waves of a block queue at the CU's one load pipe (L2 -> LDS, ~110 GB/s per CU) when they issue
     // their LDS-DMA pieces, and an in-order wave issues no MFMA while it waits there.  With GEMM_LOADERS = 4 only the
@@ -196,10 +192,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     const int frow = lane & 15, fq = lane >> 4;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        StageCtx nxt;
 #if !(GEMM_ABL & 1)
-        if constexpr (SPREAD) nxt = stage_begin(kt + 1 < kt1 ? kt + 1 : kt, buf ^ 1, kt + 1 < kt1);   // branch-free, pieces issued between the MFMA groups below
-        else if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
 #endif
         const unsigned char* As = big_smem + buf * STAGE;
         const unsigned char* Bs = As + BM * ROWB;
@@ -217,13 +211,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                 if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + swz_big(wm * WM + (fm + 1) * 16 + frow, kb * 4 + fq));
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
-#if !(GEMM_ABL & 1)
-                if constexpr (SPREAD) {
-                    constexpr int NG = 2 * FM, ND = AI + BI;
-                    const int gidx = kb * FM + fm;
-                    if (((gidx + 1) * ND) / NG > (gidx * ND) / NG) stage_piece(nxt, (gidx * ND) / NG);
-                }
-#endif
             }
         }
         if constexpr (PIN) {
@@ -234,14 +221,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                 for (int fm = 0; fm < FM; ++fm) {
                     if (fm + 1 < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // next A frag
                     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);            // MFMAs of the current A frag
-                    if constexpr (SPREAD) {
-                        // the next K tile's LDS-DMA pieces, one at a time between MFMA groups: a wave that issues them
-                        // back to back stalls in the load queue's back-pressure with no MFMA of its own in flight
-                        constexpr int NG = 2 * FM, ND = AI + BI;
-                        const int gidx = kb * FM + fm;
-                        static_assert(ND <= NG, "at most one piece per MFMA group");
-                        if (((gidx + 1) * ND) / NG > (gidx * ND) / NG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
                 }
             }
         }
