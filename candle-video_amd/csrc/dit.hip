@@ -299,8 +299,8 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         // self attention
         // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
         // of two: the attention kernel reads K/V rows of a dense matrix 7-11 % faster than column slices of [M, 3D]
-        static const bool dense_env = [] { const char* e = getenv("LTX_DENSE_QKV"); return !(e && e[0] == '0'); }();   // "0": column slices of [M, 3D] (A/B aid)
-        const bool dense_qkv = (D & (D - 1)) == 0 && dense_env;
+        const char* dense_e = getenv("LTX_DENSE_QKV");        // "0": column slices of [M, 3D] (A/B aid, and the path of a D that is not a power of two)
+        const bool dense_qkv = (D & (D - 1)) == 0 && !(dense_e && dense_e[0] == '0');
         const int64_t seg = dense_qkv ? M * D : D;           // elements from q to k to v
         const int ldqkv = dense_qkv ? D : 3 * D;
         {

@@ -87,6 +87,21 @@ def test_dit_batch_rows_are_independent(hip, golden):
         assert rel_max(o.float().cpu(), out[b:b + 1]) < 1e-5
 
 
+@pytest.mark.parametrize("mdt", [torch.float32, torch.bfloat16])
+def test_dit_dense_and_sliced_qkv_layouts_agree(hip, golden, mdt, monkeypatch):
+    """The fused q|k|v projection writes three dense [M, D] matrices (segmented GEMM output); LTX_DENSE_QKV=0 keeps the
+    column-slice layout that a D which is not a power of two takes.  Same arithmetic either way: identical outputs."""
+    g, md, w, out = _dit_case(hip, golden, "B", mdt)
+    cfgd = ast.literal_eval(md["cfg"])
+    Fr, H, W = ast.literal_eval(md["grid"])
+    model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, mdt)
+    args = (g["hidden"].to(DEV), g["enc"].to(DEV), g["timestep"], g["mask"].to(DEV), Fr, H, W, None, g["coords"].to(DEV), g["skip_layer_mask"])
+    o_dense = model.forward(*args)
+    monkeypatch.setenv("LTX_DENSE_QKV", "0")
+    o_sliced = model.forward(*args)
+    assert torch.equal(o_dense, o_sliced)
+
+
 def _vae(hip, dt, seed=7):
     cfg = O.VaeConfig(**VAE_CFG)
     w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=seed)
