@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     // first wave of every SIMD (waves 0..3) issues pieces, twice as many each; its SIMD partner (wave + 4) goes straight
     // to its MFMAs and keeps the matrix pipe busy meanwhile (measured with tools/ubench/dma_vs_mfma.hip: a partner
     // pushing a whole K-step's 64 KiB slows a wave's MFMA stream by 15 %).
-    constexpr int NL = (GEMM_LOADERS == 4 && NW == 8) ? 4 : NW;
+    constexpr int NL = (GEMM_LOADERS == 4 && (NW == 8 || NW == 16)) ? 4 : NW;
     constexpr int AI = (BM + 8 * NL - 1) / (8 * NL), BI = BN / (8 * NL);   // glds instructions per loader wave per K-step (A, B)
     constexpr bool A_RAGGED = BM % (8 * NL) != 0;       // e.g. BM = 160: 20 eight-row pieces over 8 waves, the last round half empty
     static_assert(BM % 8 == 0 && BN % (8 * NL) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile/wave layout");
@@ -391,6 +391,10 @@ int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         case 5: return launch_epi<128, 128, 2, 4, CONV>(g, epi, s);
         case 6: return launch_epi<160, 128, 2, 4, CONV>(g, epi, s);     // M = 4992 = 31.2 x 160: 32 x (N/128) tiles = whole rounds of 512
         case 7: return launch_epi<192, 64, 4, 2, CONV>(g, epi, s);      // narrow outputs (conv_out N = 48, proj_out): 4(M) x 2(N) waves of 48x32
+        // 16-wave blocks = two of the 2-per-CU tiles side by side sharing ONE activation tile in LDS (same wave shapes, same
+        // scheduling granularity, 28-30 % fewer operand bytes through the CU's load pipe per MFMA)
+        case 8: return launch_epi<160, 256, 2, 8, CONV>(g, epi, s);
+        case 9: return launch_epi<192, 256, 2, 8, CONV>(g, epi, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
@@ -402,6 +406,7 @@ const TileInfo kTiles[] = {
     {256, 256, 512, 1160, 1, "256x256"}, {192, 256, 512, 1190, 1, "192x256"}, {128, 256, 512, 1023, 1, "128x256"},
     {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
     {160, 128, 512, 1330, 2, "160x128"}, {192, 64, 512, 900, 2, "192x64"},
+    {160, 256, 1024, 1300, 1, "160x256w16"}, {192, 256, 1024, 1300, 1, "192x256w16"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // a tile is a candidate for an N-wide output: 64-wide tiles only for narrow outputs, 256-wide only beyond 128 columns
