@@ -395,6 +395,8 @@ int launch_tile(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         // scheduling granularity, 28-30 % fewer operand bytes through the CU's load pipe per MFMA)
         case 8: return launch_epi<160, 256, 2, 8, CONV>(g, epi, s);
         case 9: return launch_epi<192, 256, 2, 8, CONV>(g, epi, s);
+        case 10: return launch_epi<320, 256, 2, 8, CONV>(g, epi, s);    // M = 4992 = 15.6 x 320: ff1 (N = 8192) = 512 tiles = two full rounds
+        case 11: return launch_epi<256, 256, 4, 4, CONV>(g, epi, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_big: unsupported tile");
 }
@@ -407,6 +409,7 @@ const TileInfo kTiles[] = {
     {256, 128, 512, 989, 1, "256x128"},  {192, 128, 512, 1400, 2, "192x128"}, {128, 128, 512, 1032, 2, "128x128"},
     {160, 128, 512, 1330, 2, "160x128"}, {192, 64, 512, 900, 2, "192x64"},
     {160, 256, 1024, 1300, 1, "160x256w16"}, {192, 256, 1024, 1300, 1, "192x256w16"},
+    {320, 256, 1024, 1300, 1, "320x256w16"}, {256, 256, 1024, 1300, 1, "256x256w16"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // a tile is a candidate for an N-wide output: 64-wide tiles only for narrow outputs, 256-wide only beyond 128 columns
@@ -482,12 +485,13 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
             if (!tile_fits(kTiles[plan], g.N)) continue;
+            if (const char* ex = getenv("LTX_GEMM_EXCLUDE")) { if (strstr(ex, kTiles[plan].name)) continue; }   // A/B aid: tiles left out of the measurement
         } else if (plan < kPlanHalo) {
             if (plan >= kPlanP8 + 2) { plan = kPlanHalo - 1; continue; }
             if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
         } else if (halo_off || !ltx_conv_halo_eligible(g, EPI_BIAS, plan == kPlanHalo ? 128 : 256)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
-        // 3..16 of them, best of two rounds
+        // 3..16 of them, best of three rounds
         HIP_TRY(hipEventRecord(e0, s));
         int rc = run_plan(g, EPI_BIAS, plan, s);
         if (rc != LTX_OK) continue;
@@ -496,7 +500,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         int n = ms > 0.f ? (int)(1.5f / ms) : 16;
         n = n < 3 ? 3 : (n > 16 ? 16 : n);
-        for (int round = 0; round < 2; ++round) {
+        for (int round = 0; round < 3; ++round) {
             HIP_TRY(hipEventRecord(e0, s));
             for (int i = 0; i < n; ++i) run_plan(g, EPI_BIAS, plan, s);
             HIP_TRY(hipEventRecord(e1, s));

@@ -253,7 +253,7 @@ def test_errors_are_reported_not_crashed(hip):
 
 
 @pytest.mark.parametrize("tile", ["256x256", "192x256", "128x256", "256x128", "192x128", "128x128",
-                                  "160x128", "192x64", "p8:256", "p8:128"])
+                                  "160x128", "192x64", "160x256w16", "192x256w16", "320x256w16", "256x256w16", "p8:256", "p8:128"])
 def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
     """gemm_big.hip (LDS-DMA staged, 8 waves) and gemm_p8.hip (phase-interleaved): every tile shape, ragged M/N/K tails, every epilogue."""
     if tile.startswith("p8:"):
@@ -292,7 +292,8 @@ def test_gemm_plans_are_bit_identical_and_tuner_caches(hip, monkeypatch):
     xc, wc, bc = cl(rnd(dt, 1, 64, 3, 24, 20)).cuda(), rnd(dt, 128, 64, 3, 3, 3, scale=0.03).cuda(), rnd(dt, 128, scale=0.1).cuda()
     monkeypatch.setenv("LTX_GEMM_TUNE", "0")
     base_lin, base_conv = hip.ops.linear(x, w, b, epi=1), hip.ops.conv3d(xc, wc, bc)
-    for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128", "192x64"]:
+    for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128", "192x64",
+                 "160x256w16", "192x256w16", "320x256w16", "256x256w16"]:
         monkeypatch.setenv("LTX_GEMM_TILE", tile)
         assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), tile
         assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), tile
@@ -345,7 +346,7 @@ def test_attention_prescaled_dma_ring_screen(hip):
         assert rel_l2(outs[0].cpu(), ref.cpu()) <= 2 * BF16_TOL, (Sq, Sk, rel_l2(outs[0].cpu(), ref.cpu()))
 
 
-@pytest.mark.parametrize("tile", ["192x128", "160x128", "128x128", "256x256", "192x64"])
+@pytest.mark.parametrize("tile", ["192x128", "160x128", "128x128", "256x256", "192x64", "160x256w16", "256x256w16"])
 def test_gemm_tail_split_k(hip, tile, monkeypatch):
     """gemm_big cuts the tiles of a partly filled last round into K-ranges that meet in an in-launch reduction (f32 slabs,
     one release/acquire per tile).  Shapes chosen so that the split is active for every tile; repeated launches reuse the
