@@ -21,7 +21,7 @@
 #define GEMM_LOADERS 4   // 8: every wave issues its share of the LDS-DMA pieces; 4: the first wave of each SIMD issues them all
 #endif
 #ifndef GEMM_ABL
-#define GEMM_ABL 0   // timing ablations (wrong results): bit 0 no operand loads in the K loop, bit 1 no barrier, bit 2 loads never waited for, bit 3 loads all hit one 1-KiB line set
+#define GEMM_ABL 0   // timing ablations (wrong results): bit 0 no operand loads in the K loop, bit 1 no barrier, bit 2 loads never waited for, bit 3 loads all hit one 1-KiB line set, bit 4 no epilogue
 #endif
 namespace {
 
@@ -284,6 +284,95 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         }
     }
 
+    // ---- wide epilogue (linear layers, bf16): the MFMA layout gives a lane 4 consecutive columns, i.e. 8-byte stores that
+    // touch a 128-byte line from four different instructions (and from two waves where a wave spans 32 columns); the
+    // epilogue of a one-round grid is not hidden behind other blocks' K loops, and measured 8-30 % of a DiT GEMM.  Here
+    // the result tile goes through LDS (free after the K loop): every lane applies bias / GELU / gate / residual to its
+    // own elements exactly as epilogue() does (the residual tile is brought into the same LDS image first, by LDS-DMA, so
+    // its reads are row-contiguous too), writes bf16 in place, and the tile leaves as 16-byte row-contiguous stores.
+    // 16-byte chunk c of tile row r sits at chunk c ^ (r & 15) (bank spread for the 8-byte fragment accesses; r & 7 for 64-wide tiles).
+    // (measured per epilogue on the DiT shapes: bias +3..9 %, gate / residual +1..15 %, GELU -2..+2 % -> GELU keeps the direct stores)
+    constexpr bool WIDE = !CONV && (EPI == EPI_BIAS || EPI == EPI_GATE_RESID || EPI == EPI_RESID);
+    if constexpr (WIDE) {
+        if (g.wide_epi) {
+            constexpr int CPR = BN / 8;                                  // 16-byte chunks per tile row
+            constexpr int XM = (CPR < 16 ? CPR : 16) - 1;                // chunk XOR mask
+            constexpr int NPASS = (BM * BN * 2 + 2 * STAGE - 1) / (2 * STAGE);
+            static_assert(NPASS == 1 || (NPASS == 2 && WGM == 2), "result tile must fit LDS in at most two row passes");
+            constexpr int BMP = BM / NPASS;
+            constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
+            const int swave = __builtin_amdgcn_readfirstlane(wave);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.resid ? g.resid : g.C), 0, (int)OOB, 0x00020000);
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int prow0 = p * BMP;
+                if constexpr (HAS_R) {
+                    constexpr int RPP = 64 / CPR;                        // tile rows per 1-KiB piece
+                    for (int pi = swave; pi < BMP / RPP; pi += NW) {
+                        const int row = pi * RPP + lane / CPR, pc = lane % CPR;
+                        const int lc = pc ^ (row & XM);
+                        const int m = m0 + prow0 + row, n = n0 + lc * 8;
+                        const bool ok = m < g.M && n < g.N;
+                        dma(rr, ok ? (uint32_t)(((int64_t)m * g.ldr + n) * 2) : OOB, 0u, big_smem + pi * 1024);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (NPASS == 1 || wm == p) {
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) {
+                        const int row = (NPASS == 1 ? wm * WM : 0) + fm * 16 + frow;
+                        const int m = m0 + prow0 + row;
+                        const int mc = m < g.M ? m : g.M - 1;
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn) {
+                            const int col = wn * WN + fn * 16 + 4 * fq, nb = n0 + col;
+                            unsigned char* slot = big_smem + row * (CPR * 16) + (((col >> 3) ^ (row & XM)) << 4) + ((col >> 2) & 1) * 8;
+                            float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
+                            if (nb < g.N) {
+                                if (g.bias) {
+                                    float b[4];
+                                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nb, b);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[i] += b[i];
+                                }
+                                if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+                                } else if constexpr (HAS_R) {
+                                    float r[4];
+                                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), r);
+                                    if constexpr (EPI == EPI_GATE_RESID) {
+                                        const f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(mc / g.rows_per_batch) * g.gate_stride + nb);
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) v[i] += r[i];
+                                    }
+                                }
+                            }
+                            store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int id = tid; id < BMP * CPR; id += 64 * NW) {
+                    const int row = id / CPR, c = id - row * CPR;
+                    const int m = m0 + prow0 + row, n = n0 + c * 8;
+                    if (m >= g.M || n >= g.N) continue;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(big_smem + row * (CPR * 16) + ((c ^ (row & XM)) << 4));
+                    bf16_t* dst = Cb;
+                    int nc = n;
+                    if (g.c_seg_shift) { const int sg = n >> g.c_seg_shift; dst += sg * g.c_seg_stride; nc -= sg << g.c_seg_shift; }
+                    *reinterpret_cast<u32x4*>(dst + (int64_t)m * g.ldc + nc) = d;
+                }
+                if (p + 1 < NPASS) __syncthreads();
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * WM + fm * 16 + frow;
@@ -293,6 +382,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
             if (nb >= g.N) continue;
             float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
+#if GEMM_ABL & 16
+            if (v[0] == 123.456f)                          // no epilogue (no residual loads, no stores)
+#endif
             epilogue<bf16_t, EPI>(g, m, nb, v);
         }
     }
@@ -359,6 +451,12 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
         const int ntm = cdiv(g.M, BM);
         if (gm > ntm) gm = ntm;
         ga.group_m = (CONV || gm < 2) ? 0 : gm;
+    }
+    {   // wide epilogue: 16-byte chunks need 8-column granularity and 16-byte aligned rows
+        const char* we = getenv("LTX_GEMM_WIDE_EPI");       // "0": the fragment-wise 8-byte epilogue (A/B aid)
+        const bool seg_ok = !g.c_seg_shift || ((1 << g.c_seg_shift) % 8 == 0 && g.c_seg_stride % 8 == 0);
+        ga.wide_epi = !(we && we[0] == '0') && !CONV && g.N % 8 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 && seg_ok &&
+                      (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0)) && (double)g.M * g.ldr * 2.0 < 2147483648.0;
     }
     dim3 grid((unsigned)(ga.sk_sf > 1 ? ga.sk_full + (tiles - ga.sk_full) * ga.sk_sf : tiles)), block(64 * WGM * WGN);
     hipLaunchKernelGGL(kern, grid, block, smem, s, ga);

@@ -36,6 +36,7 @@ struct GemmArgs {
     int c_seg_shift = 0; int64_t c_seg_stride = 0;
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
     int group_m = 0;              // gemm_big: tile order inside that run: columns of group_m row-tiles (0/1: row-major)
+    int wide_epi = 0;             // gemm_big (set by its launcher): result tile through LDS, 16-byte row-contiguous stores
     // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
     int sk_full = 0, sk_sf = 1;
     float* sk_ws = nullptr;       // f32 slabs [tail tile][part][BM*BN]
