@@ -19,6 +19,9 @@
 #include <type_traits>
 #include "gemm_common.h"
 
+#ifndef HALO_WIDE_EPI
+#define HALO_WIDE_EPI 1
+#endif
 #ifndef HALO_LOADERS
 #define HALO_LOADERS 4
 #endif
@@ -190,6 +193,63 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         step(grp, std::integral_constant<int, 8>{}, p);
     }
 
+    // ---- wide epilogue (bias / residual): the result tile goes through LDS and leaves as 16-byte stores along the channel
+    // rows, the residual tile comes in the same way by LDS-DMA (see gemm_big.hip); same arithmetic as epilogue()
+    constexpr bool WIDE = HALO_WIDE_EPI && (EPI == EPI_BIAS || EPI == EPI_RESID);
+    if constexpr (WIDE) {
+        if (g.wide_epi) {
+            constexpr int CPR = BN / 8, XM = 15, RPP = 64 / CPR;
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.resid ? g.resid : g.C), 0, (int)OOB, 0x00020000);
+            auto row_m = [&](int row, bool& inside) {                 // tile row (patch voxel) -> output row index
+                const int y = y0 + (row >> 4), x = x0 + (row & 15);
+                inside = y < g.H && x < g.Wd;
+                return ((b * g.T + t) * g.H + y) * g.Wd + x;
+            };
+            if constexpr (EPI == EPI_RESID) {
+                for (int pi = wave; pi < BM / RPP; pi += NW) {
+                    const int row = pi * RPP + lane / CPR, pc = lane % CPR;
+                    const int lc = pc ^ (row & XM);
+                    bool inside; const int m = row_m(row, inside);
+                    dma(rr, inside ? (uint32_t)(((int64_t)m * g.ldr + n0 + lc * 8) * 2) : OOB, 0u, halo_smem + pi * 1024);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int row = (wm * FM + fm) * 16 + frow;
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    const int col = wn * WN + fn * 16 + 4 * fq, nb = n0 + col;
+                    unsigned char* slot = halo_smem + row * (CPR * 16) + (((col >> 3) ^ (row & XM)) << 4) + ((col >> 2) & 1) * 8;
+                    float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
+                    if (g.bias) {
+                        float bb[4];
+                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nb, bb);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += bb[i];
+                    }
+                    if constexpr (EPI == EPI_RESID) {
+                        float r[4];
+                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), r);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += r[i];
+                    }
+                    store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                }
+            }
+            __syncthreads();
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+            for (int id = tid; id < BM * CPR; id += 512) {
+                const int row = id / CPR, c = id - row * CPR;
+                bool inside; const int m = row_m(row, inside);
+                if (!inside) continue;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(halo_smem + row * (CPR * 16) + ((c ^ (row & XM)) << 4));
+                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * g.ldc + n0 + c * 8) = d;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int y = y0 + wm * FM + fm, x = x0 + frow;
@@ -214,7 +274,11 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, g);
+    GemmArgs ga = g;
+    const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
+    ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                  (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.M * g.ldr * 2.0 < 2147483648.0));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
