@@ -61,6 +61,25 @@ template <int CPR> __device__ __forceinline__ int vswz(int row, int c) {
     else return c;
 }
 
+// O^T accumulators -> bf16 rows with 16-byte stores.  A lane holds, per 32-wide d block, four groups of 4 consecutive
+// columns at 8*g4 + 4*h; lanes l and l^32 (h = 0 / 1) exchange one packed group per pair with v_permlane32_swap so
+// that each ends up with 8 consecutive columns: four 16-byte stores per lane instead of eight 8-byte ones.
+template <int NDB>
+__device__ __forceinline__ void store_o_wide(const f32x16 (&acc_o)[NDB], float inv, bf16_t* O, int h) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            union { bf16x4 v; unsigned u[2]; } a, b;
+            a.v = (bf16x4){(bf16_t)(acc_o[d][8 * k + 0] * inv), (bf16_t)(acc_o[d][8 * k + 1] * inv), (bf16_t)(acc_o[d][8 * k + 2] * inv), (bf16_t)(acc_o[d][8 * k + 3] * inv)};
+            b.v = (bf16x4){(bf16_t)(acc_o[d][8 * k + 4] * inv), (bf16_t)(acc_o[d][8 * k + 5] * inv), (bf16_t)(acc_o[d][8 * k + 6] * inv), (bf16_t)(acc_o[d][8 * k + 7] * inv)};
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            *reinterpret_cast<u32x4*>(O + d * 32 + 16 * k + 8 * h) = o;
+        }
+}
+
 // PRE: q already carries scale*log2(e) (folded into the q RMSNorm+RoPE kernel, one bf16 rounding of the product), no key bias.
 // The running max (log2 units) then enters the S^T MFMA chain as its INITIAL ACCUMULATOR (a persistent 16-register
 // tuple holding -m, rewritten only when the max moves), so the accumulator comes out as S - m and p = exp2(acc):
@@ -391,6 +410,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     const int qr = q0 + r;
     if (qr < a.Sq) {
         bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+        if (HD % 32 == 0 && a.wide_o) { store_o_wide<NDB>(acc_o, inv, O, h); return; }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -644,6 +664,7 @@ __global__ __launch_bounds__(256, ATTN_PIPE_OCC) void attn_pipe64_kernel(const A
     const int qr = q0 + r;
     if (qr < a.Sq) {
         bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+        if (a.wide_o) { store_o_wide<NDB>(acc_o, inv, O, h); return; }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -789,6 +810,8 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
         const int qr = u * 32 + r;
         if (qr < a.Sq) {
             bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
+            if (a.wide_o) store_o_wide<NDB>(acc_o, inv, O, h);
+            else
 #pragma unroll
             for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -896,6 +919,8 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         AttnArgs ax = a;
         const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)
         ax.xcd_heads = (a.heads % 8 == 0 && !(xe && xe[0] == '0')) ? 1 : 0;
+        const char* wo = getenv("LTX_ATTN_WIDE_O");          // "0": 8-byte output stores (A/B aid)
+        ax.wide_o = (a.ldo % 8 == 0 && ((uintptr_t)a.o & 15) == 0 && a.hd % 8 == 0 && !(wo && wo[0] == '0')) ? 1 : 0;
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
         if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU

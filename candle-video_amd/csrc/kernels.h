@@ -98,6 +98,7 @@ struct AttnArgs {
     const float* bias = nullptr;                  // f32 [B, Sk] additive key bias or null
     int q_prescaled = 0;                          // bf16, no bias: q already carries scale*log2(e) (qknorm_rope out_scale0)
     int xcd_heads = 0;                            // set by the launcher: whole heads per XCD (block order, speed only)
+    int wide_o = 0;                               // set by the launcher: 16-byte output stores (ldo % 8 == 0, 16-byte aligned o)
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
