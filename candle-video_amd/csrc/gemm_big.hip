@@ -20,6 +20,9 @@
 #ifndef GEMM_LOADERS
 #define GEMM_LOADERS 4   // 8: every wave issues its share of the LDS-DMA pieces; 4: the first wave of each SIMD issues them all
 #endif
+#ifndef GEMM_PRIO
+#define GEMM_PRIO 0      // experiment: static s_setprio 1 for the non-loader waves (1: -2...-6 %) or the loader waves (2: +-1 %)
+#endif
 #ifndef GEMM_ABL
 #define GEMM_ABL 0   // timing ablations (wrong results): bit 0 no operand loads in the K loop, bit 1 no barrier, bit 2 loads never waited for, bit 3 loads all hit one 1-KiB line set, bit 4 no epilogue
 #endif
@@ -190,6 +193,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     __syncthreads();                                   // emits vmcnt(0) for the outstanding LDS-DMA
 
     const int frow = lane & 15, fq = lane >> 4;
+#if GEMM_PRIO == 1
+    if (!loader) __builtin_amdgcn_s_setprio(1);         // measured: -2...-6 %
+#elif GEMM_PRIO == 2
+    if (loader && NL != NW) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
 #if !(GEMM_ABL & 1)
