@@ -240,12 +240,45 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             }
             __syncthreads();
             bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+            // a thread's chunk column is the same in every iteration (512 % CPR == 0): its modulation values load once
+            float pn_sc[8], pn_sh[8];
+            bool pn_mod = false;
+            if constexpr (EPI == EPI_BIAS) {
+                if (g.pn_on && g.pn_scale) {
+                    pn_mod = true;
+                    const int c0 = tid % CPR;
+                    const f32x4* scp = reinterpret_cast<const f32x4*>(g.pn_scale + (int64_t)b * g.pn_mod_stride + c0 * 8);
+                    const f32x4* shp = reinterpret_cast<const f32x4*>(g.pn_shift + (int64_t)b * g.pn_mod_stride + c0 * 8);
+                    const f32x4 s0 = scp[0], s1 = scp[1], h0 = shp[0], h1 = shp[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { pn_sc[j] = 1.0f + s0[j]; pn_sc[4 + j] = 1.0f + s1[j]; pn_sh[j] = h0[j]; pn_sh[4 + j] = h1[j]; }
+                }
+            }
             for (int id = tid; id < BM * CPR; id += 512) {
                 const int row = id / CPR, c = id - row * CPR;
                 bool inside; const int m = row_m(row, inside);
+                Chunk16 cc; cc.u = *reinterpret_cast<const u32x4*>(halo_smem + row * (CPR * 16) + ((c ^ (row & XM)) << 4));
+                if constexpr (EPI == EPI_BIAS) {
+                    if (g.pn_on) {                                   // the tile spans all N channels: CPR consecutive lanes hold one voxel's row
+                        float f[8]; chunk_to_f32<bf16_t>(cc, f);
+                        float ss = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+#pragma unroll
+                        for (int o = CPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                        const float rinv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)BN) + g.pn_eps);      // as rownorm.hip's narrow rows
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float n = f[j] * rinv;
+                            if (pn_mod) n = n * pn_sc[j] + pn_sh[j];
+                            if (g.pn_act == 1) n = silu_f(n);
+                            f[j] = n;
+                        }
+                        f32_to_chunk<bf16_t>(f, cc);
+                    }
+                }
                 if (!inside) continue;
-                const u32x4 d = *reinterpret_cast<const u32x4*>(halo_smem + row * (CPR * 16) + ((c ^ (row & XM)) << 4));
-                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * g.ldc + n0 + c * 8) = d;
+                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * g.ldc + n0 + c * 8) = cc.u;
             }
             return;
         }
@@ -278,6 +311,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
                   (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.M * g.ldr * 2.0 < 2147483648.0));
+    if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;

@@ -37,6 +37,11 @@ struct GemmArgs {
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
     int group_m = 0;              // gemm_big: tile order inside that run: columns of group_m row-tiles (0/1: row-major)
     int wide_epi = 0;             // gemm_big (set by its launcher): result tile through LDS, 16-byte row-contiguous stores
+    // conv_halo, EPI_BIAS, tile as wide as the output (BN == N): the per-voxel RMS norm + modulation + SiLU that the
+    // consumer would run as its own pass (LtxVideoResnetBlock3d norm2, vae.rs:779-801) applied to the bf16-rounded
+    // result rows while they sit in LDS: y = silu(x * rsqrt(mean(x^2) + pn_eps) * (1 + scale[b][c]) + shift[b][c])
+    int pn_on = 0; float pn_eps = 0.f; int pn_act = 0; int pn_mod_stride = 0;
+    const float* pn_scale = nullptr; const float* pn_shift = nullptr;   // f32 [B, pn_mod_stride] or null
     // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
     int sk_full = 0, sk_sf = 1;
     float* sk_ws = nullptr;       // f32 slabs [tail tile][part][BM*BN]

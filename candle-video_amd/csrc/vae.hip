@@ -205,8 +205,30 @@ int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
 
 struct Dims { int B, T, H, W; int64_t vox() const { return (int64_t)B * T * H * W; } };
 
-int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, int epi, const void* resid, int post, hipStream_t s) {
+struct PostNorm { int on = 0; float eps = 0.f; int act = 0; int mod_stride = 0; const float* scale = nullptr; const float* shift = nullptr; };
+
+GemmArgs conv_args(ltx_vae* v, const ConvW& cw, const Dims& d) {
     GemmArgs g;
+    g.W = cw.w; g.bias = cw.b;
+    g.M = (int)d.vox(); g.N = cw.cout; g.K = cw.cin; g.ldc = cw.cout; g.ldr = cw.cout;
+    g.conv = 1; g.B = d.B; g.T = d.T; g.H = d.H; g.Wd = d.W; g.Cin = cw.cin;
+    g.ntaps = 27; g.kh = 3; g.kw = 3;
+    g.pad_t = v->cfg.decoder_causal ? 2 : 1;
+    return g;
+}
+
+// whether conv1 of a resnet can carry norm2 in its epilogue: bf16, the halo-staged kernel with BN == channels
+bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d, int ch) {
+    auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
+    if (off("LTX_VAE_FUSE_NORM") || off("LTX_GEMM_WIDE_EPI") || off("LTX_CONV_HALO") || off("LTX_GEMM_BIG")) return false;
+    if (v->dtype != LTX_DT_BF16 || (ch != 128 && ch != 256) || cw.cout != ch) return false;
+    const GemmArgs g = conv_args(v, cw, d);
+    return ltx_gemm_big_eligible(g, v->dtype) && ltx_conv_halo_eligible(g, EPI_BIAS, ch);
+}
+
+int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, int epi, const void* resid, int post, hipStream_t s, const PostNorm* pn = nullptr) {
+    GemmArgs g;
+    if (pn && pn->on) { g.pn_on = 1; g.pn_eps = pn->eps; g.pn_act = pn->act; g.pn_mod_stride = pn->mod_stride; g.pn_scale = pn->scale; g.pn_shift = pn->shift; }
     g.A = x; g.W = cw.w; g.C = y; g.bias = cw.b; g.resid = resid;
     g.M = (int)d.vox(); g.N = cw.cout; g.K = cw.cin; g.ldc = cw.cout; g.ldr = cw.cout;
     g.conv = 1; g.B = d.B; g.T = d.T; g.H = d.H; g.Wd = d.W; g.Cin = cw.cin;
@@ -236,6 +258,15 @@ int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims&
     rn.kind = 0; rn.eps = 1e-8f; rn.act = 1; rn.rows_per_batch = (int64_t)d.T * d.H * d.W; rn.mod_stride = 4 * ch;
     if (mod) { rn.shift = mod; rn.scale = mod + ch; }
     LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    // norm2 + modulation + SiLU inside conv1's epilogue where one conv tile spans all channels (128 / 256): no pass of
+    // its own over the stage's largest tensor
+    if (fuse_norm2(v, r.c1, d, ch)) {
+        PostNorm pn; pn.on = 1; pn.eps = rn.eps; pn.act = 1; pn.mod_stride = 4 * ch;
+        if (mod) { pn.shift = mod + 2 * ch; pn.scale = mod + 3 * ch; }
+        LTX_TRY(conv3d(v, r.c1, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s, &pn));
+        LTX_TRY(conv3d(v, r.c2, v->C.p, v->X.p, d, EPI_RESID, v->X.p, 0, s));   // X = conv2(..) + X, in place
+        return LTX_OK;
+    }
     LTX_TRY(conv3d(v, r.c1, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s));
     rn.x = v->C.p;
     if (mod) { rn.shift = mod + 2 * ch; rn.scale = mod + 3 * ch; }

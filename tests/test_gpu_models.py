@@ -109,6 +109,34 @@ def _vae(hip, dt, seed=7):
     return cfg, w, model
 
 
+def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch):
+    """Where one conv tile spans all channels (128 / 256-channel stages, >= 1024 voxels) the resnet's norm2 + modulation +
+    SiLU runs inside conv1's wide epilogue.  A decoder with 512 / 256 / 128-channel stages: fused vs the separate norm
+    pass (LTX_VAE_FUSE_NORM=0) agree to bf16 rounding of the row statistics' summation order, with and without timestep
+    conditioning, and both stay within the bf16 bar of the f32-mode decode."""
+    cfgd = dict(latent_channels=16, decoder_block_out_channels=(256, 512), decoder_layers_per_block=(1, 1, 1))
+    cfg = O.VaeConfig(**cfgd)
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=11)
+    wd = {"decoder." + k: v.to(DEV) for k, v in w.items()}
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 16, 3, 10, 12, generator=g)
+    outs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        model = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**cfgd), wd, dt)
+        outs[dt] = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
+        if dt == torch.bfloat16:
+            assert torch.equal(outs[dt], model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu())
+            no_t = model.decode(z.to(DEV), None).float().cpu()
+            monkeypatch.setenv("LTX_VAE_FUSE_NORM", "0")
+            sep = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
+            sep_no_t = model.decode(z.to(DEV), None).float().cpu()
+            monkeypatch.delenv("LTX_VAE_FUSE_NORM")
+            assert rel_l2(outs[dt], sep) <= 5e-3, rel_l2(outs[dt], sep)
+            assert rel_l2(no_t, sep_no_t) <= 5e-3
+        del model
+    assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) <= 3e-2
+
+
 def test_vae_decode_f32_fixture(hip, golden):
     g = golden("oracle_vae.safetensors")
     _, _, model = _vae(hip, torch.float32)
