@@ -499,3 +499,30 @@ def test_conv3d_halo_staged_kernel(hip, bn, B, Cin, Cout, T, H, W, causal, monke
     assert torch.equal(hip.ops.upsample3d(xc, w.cuda(), b.cuda(), causal), base_up)
     ref = O.causal_conv3d(x.float(), w.float(), b.float(), causal)
     check(ncthw(y), ref, dt)
+
+
+@pytest.mark.gpu
+def test_real_shape_plans_are_bit_identical(hip, monkeypatch):
+    """At the DiT's and the VAE's own shapes (not the small test shapes): the 16-wave GEMM tiles, the wide epilogue and the
+    halo-staged conv give exactly the bits of the 8-wave / fragment-store / per-tap forms."""
+    dt = torch.bfloat16
+    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
+    S = 4992
+    x, w, b = rnd(dt, S, 2048).cuda(), rnd(dt, 2048, 2048, scale=2048 ** -0.5).cuda(), rnd(dt, 2048, scale=0.1).cuda()
+    r, gate = rnd(dt, S, 2048, seed=3).cuda(), rnd(torch.float32, 1, 2048, seed=4).cuda()
+    outs = []
+    for tile, wide in [("160x128", "0"), ("160x256w16", "1"), ("256x256w16", "1"), ("320x256w16", "0"), ("192x128", "1")]:
+        monkeypatch.setenv("LTX_GEMM_TILE", tile); monkeypatch.setenv("LTX_GEMM_WIDE_EPI", wide)
+        outs.append((hip.ops.linear(x, w, b), hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S), hip.ops.linear(x, w, b, epi=1)))
+    for o in outs[1:]:
+        assert all(torch.equal(a, c) for a, c in zip(o, outs[0]))
+    monkeypatch.delenv("LTX_GEMM_TILE"); monkeypatch.delenv("LTX_GEMM_WIDE_EPI")
+    # the 128-channel VAE stage's plane (128 x 192) with 4 frames
+    xc, wc, bc = cl(rnd(dt, 1, 128, 4, 128, 192)).cuda(), rnd(dt, 128, 128, 3, 3, 3, scale=(27 * 128) ** -0.5).cuda(), rnd(dt, 128, scale=0.1).cuda()
+    rc = cl(rnd(dt, 1, 128, 4, 128, 192, seed=6)).cuda()
+    monkeypatch.setenv("LTX_CONV_HALO", "0")
+    base = hip.ops.conv3d(xc, wc, bc, True, resid=rc)
+    monkeypatch.setenv("LTX_CONV_HALO", "128")
+    assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
+    monkeypatch.setenv("LTX_GEMM_WIDE_EPI", "0")
+    assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
