@@ -898,6 +898,10 @@ static bool attn_cross_enabled() {
     const char* e = getenv("LTX_ATTN_CROSS");               // "0" = generic tiled kernel for short key sets too (A/B aid)
     return !(e && e[0] == '0');
 }
+static bool attn_q64_enabled() {
+    const char* e = getenv("LTX_ATTN_Q64");                 // "0" = 32-query waves, two blocks per CU (attn_pipe64_kernel; A/B aid)
+    return !(e && e[0] == '0');
+}
 static bool attn_pipe_enabled() {
     const char* e = getenv("LTX_ATTN_PIPE");                // "0" = one tile at a time per wave (A/B aid)
     return !(e && e[0] == '0');
@@ -935,7 +939,8 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         switch (a.hd) {
             case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
             case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;
-            case 64: if (a.q_prescaled && attn_pipe_enabled()) hipLaunchKernelGGL(attn_pipe64_kernel, grid, block, 0, s, ax);
+            case 64: if (a.q_prescaled && attn_q64_enabled()) return ltx_launch_attention_q64(ax, s);
+                     else if (a.q_prescaled && attn_pipe_enabled()) hipLaunchKernelGGL(attn_pipe64_kernel, grid, block, 0, s, ax);
                      else if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
                      else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);
                      break;

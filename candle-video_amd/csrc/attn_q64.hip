@@ -1,0 +1,630 @@
+// DiT self-attention, head_dim 64, q prescaled by scale*log2(e), no key bias (candle-flash-attn at
+// ltx_transformer.rs:699-712): one wave per SIMD, 64 queries per wave.
+//
+// Why this shape (attention): at d = 64 the SIMD's vector issue port, not the matrix pipe, bounds the
+// kernel - per 64-key tile a wave must issue one v_exp per score, one v_cvt_pk per two, the K/V fragment reads and its
+// share of the LDS-DMA pieces.  Per FLOP, a wave that owns 64 queries (two 32-query MFMA column blocks) reads each K
+// and V^T fragment once for both blocks and issues half the DMA pieces of a 32-query wave.  That needs the whole
+// 512-register file (two S^T accumulator sets of 64, O^T 64, Q^T 32, K 32, V^T 32 fragments) -> one wave per SIMD, so
+// the overlap of matrix and vector work cannot come from a SIMD partner: it is written into the instruction stream.
+//
+//   * workgroup = 4 waves = 256 queries of one head ("big" block) or 128 queries (QB = 1, 32 queries per wave: the
+//     blocks that fill the last, partial round of the grid - see ltx_launch_attention_q64);
+//   * K/V tiles of 64 keys arrive by buffer LDS-DMA into a ring of four 16-KiB slots, tile t+4 issued in iteration t,
+//     counted vmcnt, one barrier per tile; the LDS images and fragment maps are those of attention.hip (K rows
+//     chunk-XOR-swizzled, V row-major read through ds_read_b64_tr_b16, P^T kept in registers as the B operand);
+//   * software pipeline over tiles: iteration t issues S^T(t+1) = K(t+1) . Q^T (accumulators start at -m) and
+//     O^T += V^T(t) . P^T(t); the exp/convert work of tile t is spread two v_exp + one v_cvt_pk per MFMA over ALL
+//     MFMAs of the iteration (groups of eight: QK block 0 | QK block 1 | PV block 0 | PV block 1), pinned with
+//     sched_barrier between MFMAs; V^T(t) fragments are read under the QK groups, K(t+2) fragments and the DMA pieces
+//     of tile t+4 under the PV groups;
+//   * row sums come from the matrix pipe: one v_mfma_f32_16x16x32_bf16 per P operand against a constant 0/1 matrix
+//     sums the bf16-rounded P of a query over its 8 keys x 2 lane halves straight into a running f32 accumulator
+//     (64 v_add per tile -> 8 short MFMAs; the normaliser is the sum of exactly the P values that enter P.V);
+//   * FIXED max: m of a query = its maximum over the FIRST key tile (prologue); p = exp2(s - m) is then evaluated with
+//     no per-tile max, no rescale and no branch.  Softmax is invariant to m; f32 sums and bf16's 8-bit exponent make
+//     the rounding independent of the magnitude of p, so the only failure is overflow (a later score exceeding the
+//     first tile's maximum by ~127 in log2 units).  Overflow leaves inf/NaN in l or O^T, which is checked once per
+//     block; the block then computes the exact row maxima over all keys (plain loads, no pipeline) and runs again
+//     with those: a slow, always-correct path that ordinary activations never take.
+#include <type_traits>
+#include "common.h"
+#include "kernels.h"
+
+#ifndef Q64_ROWSUM_MFMA
+#define Q64_ROWSUM_MFMA 1      // 0: row sums by VALU adds
+#endif
+#ifndef Q64_PIN
+#define Q64_PIN 1              // 0: leave the MFMA / VALU interleave to the compiler's scheduler
+#endif
+#ifndef Q64_ABL
+#define Q64_ABL 0              // timing ablations (wrong results): 1 no DMA in the loop, 2 no exp, 3 no barrier
+#endif
+
+#ifndef Q64_ASM_LOOP
+#define Q64_ASM_LOOP 1         // 0: the compiler-scheduled C++ loop for every tile (reference for the asm loop)
+#endif
+
+namespace {
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#include "attn_q64_loop.inc"
+
+constexpr int BKV = 64, KROW = 128, VROW = 128, TILE_BYTES = BKV * (KROW + VROW), NSLOT = 4;
+constexpr int PW = 2, PIECES = 2 * PW;          // 1-KiB LDS-DMA pieces per wave and tile (K: 2, V: 2)
+constexpr int FLAG_OFF = NSLOT * TILE_BYTES;    // one word behind the ring: "a wave saw inf/NaN"
+
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+__device__ __forceinline__ int kswz8(int row, int c) { return c ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int vswz8(int row, int c) { return c ^ (((row >> 1) & 1) << 2); }
+
+// LDS reads outside the compiler's memory model (it cannot tell them from the pending LDS-DMA writes of the other ring
+// slots and would drain vmcnt to 0 before each); waited for with explicit lgkmcnt statements that name the registers.
+template <int OFF> __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 lds_tr(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void wait_k(bf16x8 (&k)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7]));
+}
+__device__ __forceinline__ void wait_v(u32x2 (&v)[8][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1]),
+                 "+v"(v[4][0]), "+v"(v[4][1]), "+v"(v[5][0]), "+v"(v[5][1]), "+v"(v[6][0]), "+v"(v[6][1]), "+v"(v[7][0]), "+v"(v[7][1]));
+}
+__device__ __forceinline__ void pin() {
+#if Q64_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// MFMAs of the compiler-scheduled parts (prologue, ragged tail iterations, exact-max pass): builtins, so that hipcc
+// pads their hazards.  The bulk of the work runs in the generated asm loop (attn_q64_loop.inc).
+__device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& k, const bf16x8& q, const f32x16& init) {
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k, q, init, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& k, const bf16x8& q) {
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k, q, s, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& v, const bf16x8& p) {
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, p, o, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_l(f32x4& l, const bf16x8& ones, const bf16x8& p) {
+    l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p, l, 0, 0, 0);
+}
+__device__ __forceinline__ void settle(f32x16&) {}
+__device__ __forceinline__ void mfma_drain() {}
+
+// 16-byte row stores of O (attention.hip store_o_wide): lanes l and l^32 exchange one packed column group per pair
+__device__ __forceinline__ void store_o64(const f32x16 (&acc_o)[2], float inv, bf16_t* O, int h, bool wide) {
+    if (wide) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                union { bf16x4 v; unsigned u[2]; } a, b;
+                a.v = (bf16x4){(bf16_t)(acc_o[d][8 * k + 0] * inv), (bf16_t)(acc_o[d][8 * k + 1] * inv), (bf16_t)(acc_o[d][8 * k + 2] * inv), (bf16_t)(acc_o[d][8 * k + 3] * inv)};
+                b.v = (bf16x4){(bf16_t)(acc_o[d][8 * k + 4] * inv), (bf16_t)(acc_o[d][8 * k + 5] * inv), (bf16_t)(acc_o[d][8 * k + 6] * inv), (bf16_t)(acc_o[d][8 * k + 7] * inv)};
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<u32x4*>(O + d * 32 + 16 * k + 8 * h) = o;
+            }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;
+                bf16x4 o4 = {(bf16_t)(acc_o[d][4 * g4 + 0] * inv), (bf16_t)(acc_o[d][4 * g4 + 1] * inv),
+                             (bf16_t)(acc_o[d][4 * g4 + 2] * inv), (bf16_t)(acc_o[d][4 * g4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(O + dd) = o4;
+            }
+    }
+}
+
+// One workgroup: queries [q_first, q_first + 128*QB) of (batch b, head).  QB = 32-query column blocks per wave.
+template <int QB>
+__device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char* smem, int b, int head, int q_first) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = q_first + wave * 32 * QB;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * 64;
+    const int nt = (a.Sk + BKV - 1) / BKV;
+    const bool ragged = (a.Sk % BKV) != 0;
+
+    // Q^T operand fragments (B operand: k = d, col = query); rows past Sq repeat the last one (never stored)
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qr = q0 + 32 * qb + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+        const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // ---- LDS-DMA geometry (attention.hip): pieces of 8 rows x 128 B, wave w issues pieces 2w, 2w+1 of K and of V;
+    // the tile's bank swizzles are applied to the SOURCE chunk; rows past Sk are out of the buffer's range -> zeros
+    __amdgpu_buffer_rsrc_t rk_rsrc, rv_rsrc;
+    uint32_t k_voff[PW], v_voff[PW];
+    {
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + 128u;
+        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
+        rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
+        rv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int row = (wave * PW + j) * 8 + (lane >> 3), pc = lane & 7;
+            k_voff[j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz8(row, pc) * 16u;
+            v_voff[j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz8(row, pc) * 16u;
+        }
+    }
+    // the same two descriptors as plain words in SGPRs, for the generated loop
+    u32x4 rk_words, rv_words;
+    {
+        const uint64_t kp = (uint64_t)(uintptr_t)K, vp = (uint64_t)(uintptr_t)V;
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + 128u, v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
+        rk_words = (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kp >> 32)) & 0xffffu,
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)k_bytes), 0x00020000u};
+        rv_words = (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vp >> 32)) & 0xffffu,
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)v_bytes), 0x00020000u};
+    }
+    auto dma_piece = [&](int t, int slot, int which) {       // which: 0,1 = K pieces, 2,3 = V pieces
+        unsigned char* Ks = smem + slot * TILE_BYTES;
+        const int j = which & 1;
+        if (which < 2) {
+            const uint32_t ks = (uint32_t)t * BKV * (uint32_t)a.ldk * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_rsrc, (__attribute__((address_space(3))) void*)(Ks + (wave * PW + j) * 1024), 16, (int)k_voff[j], (int)ks, 0, 0);
+        } else {
+            const uint32_t vs = (uint32_t)t * BKV * (uint32_t)a.ldv * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv_rsrc, (__attribute__((address_space(3))) void*)(Ks + BKV * KROW + (wave * PW + j) * 1024), 16, (int)v_voff[j], (int)vs, 0, 0);
+        }
+    };
+    auto dma_tile = [&](int t, int slot) { for (int w = 0; w < 4; ++w) dma_piece(t, slot, w); };
+
+    // lane parts of the LDS read addresses (row offsets inside a tile and static ring slots are immediates)
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t k_base[4], tr_base[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_base[ks] = smem_base + r * KROW + kswz8(r, 2 * ks + h) * 16;   // rows r, r+32 swizzle alike
+    {
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+            tr_base[d] = smem_base + row * VROW + vswz8(row, cv) * 16 + (trp & 1) * 8;
+        }
+    }
+    // K fragment i = kb*4 + ks of the tile in ring slot SLOT (>= 0: immediate) or slot_dyn
+    auto read_k = [&](auto slot_tag, int slot_dyn, auto i_tag, bf16x8 (&kf)[8]) {
+        constexpr int SLOT = decltype(slot_tag)::value, i = decltype(i_tag)::value, kb = i >> 2, ks = i & 3;
+        constexpr int imm = (SLOT >= 0 ? SLOT : 0) * TILE_BYTES + kb * 32 * KROW;
+        kf[i] = lds_b128<imm>(k_base[ks] + (SLOT >= 0 ? 0u : (uint32_t)slot_dyn * TILE_BYTES));
+    };
+    // V^T operand n = d*4 + j (keys (j>>1)*32 + (j&1)*16 .. +15 of d block d): half hf of its two transpose reads
+    auto read_v = [&](auto slot_tag, int slot_dyn, auto n_tag, auto hf_tag, u32x2 (&vf)[8][2]) {
+        constexpr int SLOT = decltype(slot_tag)::value, n = decltype(n_tag)::value, hf = decltype(hf_tag)::value, d = n >> 2, j = n & 3;
+        constexpr int rowc = (j >> 1) * 32 + (j & 1) * 16 + 8 * hf;
+        constexpr int imm = (SLOT >= 0 ? SLOT : 0) * TILE_BYTES + BKV * KROW + rowc * VROW;
+        vf[n][hf] = lds_tr<imm>(tr_base[d] + (SLOT >= 0 ? 0u : (uint32_t)slot_dyn * TILE_BYTES));
+    };
+
+    // constant A operand of the row-sum MFMA (16x16x32): A[i][k] = 1 where the parities of row i and of k's group of 8
+    // agree -> D[even rows][c] = sum over lanes c, c+32 (query c), D[odd rows][c] = lanes 16+c, 48+c (query 16+c);
+    // a lane finds its own query's sum in register (lane >> 4) & 1 of the result
+    bf16x8 ones;
+    {
+        const bf16_t v1 = (bf16_t)(((lane & 1) == ((lane >> 4) & 1)) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ones[i] = v1;
+    }
+
+    f32x16 S[2][QB][2];            // S^T accumulator sets: [set][query block][key block]
+    constexpr int NPS = QB == 1 ? 2 : 1;   // QB = 1 exponentiates tile t+1's first slice while P.V reads tile t's -> two sets
+    bf16x8 P[NPS][QB][2][2];       // P^T operands: [set][query block][key block][k-step]
+    f32x16 acc_o[QB][2];
+    f32x16 minit[QB];              // -m in all 16 registers (a lane owns one query column)
+    f32x4 lacc[QB];
+    float lsum[QB];                // Q64_ROWSUM_MFMA == 0
+    bf16x8 kf[8];
+    u32x2 vf[8][2];
+    float m_fix[QB];
+
+    // exp2 + convert of one key block of one query block: 16 v_exp + 8 v_cvt_pk, cut into 8 slices (one per MFMA gap)
+    auto exp_slice = [&](f32x16& s, bf16x8 (&p)[2], float& ls, auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;          // slice i: registers 2i, 2i+1
+#if Q64_ABL == 2
+        const float p0 = s[2 * i], p1 = s[2 * i + 1];
+#else
+        const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
+#endif
+#if !Q64_ROWSUM_MFMA
+        ls += p0 + p1;
+#endif
+        p[i >> 2][(2 * i) & 7] = (bf16_t)p0;
+        p[i >> 2][((2 * i) & 7) + 1] = (bf16_t)p1;
+    };
+    auto mask_tail = [&](f32x16 (&s)[QB][2], int t) {      // keys past Sk of tile t -> -inf
+        const int kv0 = t * BKV;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= a.Sk) s[qb][kb][i] = -INFINITY;
+                }
+    };
+    auto qk_mfma = [&](f32x16& s, const bf16x8& k, const bf16x8& q, const f32x16& init, auto first_tag) {
+        if constexpr (decltype(first_tag)::value) mfma_s_first(s, k, q, init); else mfma_s(s, k, q);
+    };
+
+    // ---- iteration t.  cur = set holding S^T(t) - m (its block-0 / key-block-0 slice already exponentiated),
+    // nxt = set receiving S^T(t+1).  FLAGS: bit 0 = tile t+1 exists, bit 1 = tile t+2 exists, bit 2 = tile t+1 is the
+    // ragged last tile.  Static bodies (SLOT >= 0) have all of bits 0,1 set.
+    auto body = [&](int t, auto slot_tag, auto cur_tag, int flags) {
+        constexpr int SLOT = decltype(slot_tag)::value, CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+        constexpr int PC = QB == 1 ? CUR : 0, PN = QB == 1 ? NXT : 0;
+        constexpr bool STATIC = SLOT >= 0;
+        const bool next1 = STATIC || (flags & 1), next2 = STATIC || (flags & 2);
+        const int slot = STATIC ? SLOT : (t & 3);
+        using vslot = std::integral_constant<int, SLOT>;
+        using kslot = std::integral_constant<int, STATIC ? ((SLOT + 2) & 3) : -1>;
+        const int kslot_dyn = (t + 2) & 3;
+        // --- QK groups: S^T(t+1), exps of tile t, V^T(t) reads
+        sfor<0, QB>([&](auto qb_tag) {
+            constexpr int qb = decltype(qb_tag)::value;
+            sfor<0, 8>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value, kb = i >> 2, ks = i & 3;
+                if (next1) qk_mfma(S[NXT][qb][kb], kf[i], qf[qb][ks], minit[qb], std::bool_constant<ks == 0>{});
+                // exps: QB = 2: group 0 -> (q0, k1), group 1 -> (q1, k0);  QB = 1: group 0 -> (q0, k1)
+                if constexpr (QB == 2 && qb == 1) exp_slice(S[CUR][1][0], P[PC][1][0], lsum[1], i_tag);
+                else exp_slice(S[CUR][0][1], P[PC][0][1], lsum[0], i_tag);
+                // V^T(t): 16 transpose reads over the QK gaps
+                if constexpr (QB == 2) read_v(vslot{}, slot, std::integral_constant<int, ((qb * 8 + i) / 2)>{}, std::integral_constant<int, ((qb * 8 + i) & 1)>{}, vf);
+                else { read_v(vslot{}, slot, i_tag, std::integral_constant<int, 0>{}, vf); read_v(vslot{}, slot, i_tag, std::integral_constant<int, 1>{}, vf); }
+                pin();
+            });
+        });
+        if constexpr (!STATIC) { if ((flags & 4)) mask_tail(S[NXT], t + 1); }
+        // --- tile t+2 landed for every wave (tile t+3's pieces may stay in flight); V^T(t) fragments are in
+#if Q64_ABL != 1
+        if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        wait_v(vf);
+#if Q64_ABL != 3
+        __builtin_amdgcn_s_barrier();
+#endif
+        pin();
+        // --- PV groups: O^T += V^T(t) . P^T(t), row sums, remaining exps, K(t+2) reads, DMA of tile t+4
+        const bool do_dma = Q64_ABL != 1 && (t + 4 < nt);
+        sfor<0, QB>([&](auto qb_tag) {
+            constexpr int qb = decltype(qb_tag)::value;
+            sfor<0, 8>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value, d = i >> 2, j = i & 3;
+                union { u32x2 u[2]; bf16x8 v; } cvt;
+                cvt.u[0] = vf[i][0]; cvt.u[1] = vf[i][1];
+                mfma_o(acc_o[qb][d], cvt.v, P[PC][qb][j >> 1][j & 1]);
+                // exps: QB = 2: group 0 -> (q1, k1) of tile t, group 1 -> (q0, k0) of tile t+1;  QB = 1: (q0, k0) of tile t+1
+                if constexpr (QB == 2 && qb == 0) exp_slice(S[CUR][1][1], P[PC][1][1], lsum[1], i_tag);
+                else { if (next1) exp_slice(S[NXT][0][0], P[PN][0][0], lsum[0], i_tag); }
+                // K(t+2) fragments: one per gap of the first PV group
+                if constexpr (qb == 0) { if (next2) read_k(kslot{}, kslot_dyn, i_tag, kf); }
+                // DMA pieces of tile t+4 (slot of tile t, free since the barrier): last PV group, every other gap
+                if constexpr (qb == QB - 1 && (i & 1) == 0) { if (do_dma) dma_piece(t + 4, slot, i >> 1); }
+#if Q64_ROWSUM_MFMA
+                if constexpr (i >= 4) mfma_l(lacc[qb], ones, P[PC][qb][(i - 4) >> 1][(i - 4) & 1]);
+#endif
+                pin();
+            });
+        });
+        if (next2) wait_k(kf);
+        pin();
+    };
+
+    // ---- one pass over all keys with the row maxima m_fix[] ------------------------------------------------------
+    auto run_pass = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { minit[qb][i] = -m_fix[qb]; acc_o[qb][0][i] = 0.f; acc_o[qb][1][i] = 0.f; }
+            lacc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lsum[qb] = 0.f;
+        }
+        // S^T(0) - m with K(0), then K(1) fragments, then the first exp slice of tile 0
+        sfor<0, 8>([&](auto i_tag) { read_k(std::integral_constant<int, 0>{}, 0, i_tag, kf); });
+        wait_k(kf);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) settle(minit[qb]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+            sfor<0, 8>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                qk_mfma(S[0][qb][i >> 2], kf[i], qf[qb][i & 3], minit[qb], std::bool_constant<(i & 3) == 0>{});
+            });
+        mfma_drain();
+        if (nt == 1 && ragged) mask_tail(S[0], 0);
+        if (nt > 1) { sfor<0, 8>([&](auto i_tag) { read_k(std::integral_constant<int, 1>{}, 0, i_tag, kf); }); wait_k(kf); }
+        sfor<0, 8>([&](auto i_tag) { exp_slice(S[0][0][0], P[0][0][0], lsum[0], i_tag); });
+        pin();
+        int t = 0;
+#if Q64_ASM_LOOP
+        // the generated loop runs every iteration whose next tile needs no masking: all of them, or all but the last two
+        if (const int N = ragged ? nt - 2 : nt; N > 0) {
+            union B8 { bf16x8 v; uint32_t u[4]; };
+            u32x32 pk, kk; u32x4 ones_u, kbase_u, dma_u; u32x2 tr_u;
+            { B8 c; c.v = ones; ones_u = (u32x4){c.u[0], c.u[1], c.u[2], c.u[3]}; }
+            kbase_u = (u32x4){k_base[0], k_base[1], k_base[2], k_base[3]};
+            tr_u = (u32x2){tr_base[0], tr_base[1]};
+            dma_u = (u32x4){k_voff[0], k_voff[1], v_voff[0], v_voff[1]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { B8 c; c.v = kf[i]; kk[4 * i] = c.u[0]; kk[4 * i + 1] = c.u[1]; kk[4 * i + 2] = c.u[2]; kk[4 * i + 3] = c.u[3]; }
+            int cnt = N;
+            const uint32_t kstep = (uint32_t)BKV * (uint32_t)a.ldk * 2u, vstep = (uint32_t)BKV * (uint32_t)a.ldv * 2u;
+            uint32_t koff = 4u * kstep, voff = 4u * vstep;
+            const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
+            if constexpr (QB == 2) {
+                f32x32 sx0, sx1, sy0, sy1, mi, o0, o1; f32x8 la; u32x32 qq;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sx0[i] = S[0][0][0][i]; sx0[16 + i] = S[0][0][1][i]; sx1[i] = S[0][1][0][i]; sx1[16 + i] = S[0][1][1][i];
+                    sy0[i] = 0.f; sy0[16 + i] = 0.f; sy1[i] = 0.f; sy1[16 + i] = 0.f;
+                    mi[i] = minit[0][i]; mi[16 + i] = minit[1][i];
+                    o0[i] = acc_o[0][0][i]; o0[16 + i] = acc_o[0][1][i]; o1[i] = acc_o[1][0][i]; o1[16 + i] = acc_o[1][1][i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { la[i] = lacc[0][i]; la[4 + i] = lacc[1][i]; }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { B8 c; c.v = qf[qb][ks]; for (int w = 0; w < 4; ++w) qq[(qb * 4 + ks) * 4 + w] = c.u[w]; }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { B8 c; c.v = P[0][qb][kb][s2]; for (int w = 0; w < 4; ++w) pk[((qb * 2 + kb) * 2 + s2) * 4 + w] = c.u[w]; }
+                q64_loop_qb2(sx0, sx1, sy0, sy1, pk, mi, la, o0, o1, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw);
+                const bool odd = (N & 1) != 0;                 // tile N (if any) sits in set N & 1: the tail below wants it in set 0
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[0][0][0][i] = odd ? sy0[i] : sx0[i]; S[0][0][1][i] = odd ? sy0[16 + i] : sx0[16 + i];
+                    S[0][1][0][i] = odd ? sy1[i] : sx1[i]; S[0][1][1][i] = odd ? sy1[16 + i] : sx1[16 + i];
+                    acc_o[0][0][i] = o0[i]; acc_o[0][1][i] = o0[16 + i]; acc_o[1][0][i] = o1[i]; acc_o[1][1][i] = o1[16 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { lacc[0][i] = la[i]; lacc[1][i] = la[4 + i]; }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { B8 c; for (int w = 0; w < 4; ++w) c.u[w] = pk[((qb * 2 + kb) * 2 + s2) * 4 + w]; P[0][qb][kb][s2] = c.v; }
+            } else {
+                f32x32 sx0, sy0, o0; f32x16 mi; f32x4 la; u32x16 qq;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sx0[i] = S[0][0][0][i]; sx0[16 + i] = S[0][0][1][i]; sy0[i] = 0.f; sy0[16 + i] = 0.f;
+                    mi[i] = minit[0][i]; o0[i] = acc_o[0][0][i]; o0[16 + i] = acc_o[0][1][i];
+                }
+                la = lacc[0];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { B8 c; c.v = qf[0][ks]; for (int w = 0; w < 4; ++w) qq[ks * 4 + w] = c.u[w]; }
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { B8 c; c.v = P[ps][0][kb][s2]; for (int w = 0; w < 4; ++w) pk[ps * 16 + (kb * 2 + s2) * 4 + w] = c.u[w]; }
+                q64_loop_qb1(sx0, sy0, pk, mi, la, o0, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw);
+                const bool odd = (N & 1) != 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[0][0][0][i] = odd ? sy0[i] : sx0[i]; S[0][0][1][i] = odd ? sy0[16 + i] : sx0[16 + i];
+                    acc_o[0][0][i] = o0[i]; acc_o[0][1][i] = o0[16 + i];
+                }
+                lacc[0] = la;
+                // P set of tile N -> set 0
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) { B8 c; for (int w = 0; w < 4; ++w) c.u[w] = odd ? pk[16 + (kb * 2 + s2) * 4 + w] : pk[(kb * 2 + s2) * 4 + w]; P[0][0][kb][s2] = c.v; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { B8 c; c.u[0] = kk[4 * i]; c.u[1] = kk[4 * i + 1]; c.u[2] = kk[4 * i + 2]; c.u[3] = kk[4 * i + 3]; kf[i] = c.v; }
+            t = N;
+        }
+        // remaining (ragged) iterations: tile t sits in set 0, so the parity of the compiler-scheduled bodies restarts
+        using dyn0 = std::integral_constant<int, -1>;
+        auto flags0 = [&](int tt) { return (tt + 1 < nt ? 1 : 0) | (tt + 2 < nt ? 2 : 0) | ((ragged && tt + 1 == nt - 1) ? 4 : 0); };
+        for (int u = 0; t < nt; t += 2, ++u) {
+            body(t, dyn0{}, std::integral_constant<int, 0>{}, flags0(t));
+            if (t + 1 < nt) body(t + 1, dyn0{}, std::integral_constant<int, 1>{}, flags0(t + 1));
+        }
+        mfma_drain();
+        return;
+#endif
+        for (; t <= nt - 6; t += 4) {
+            body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 3);
+            body(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 3);
+            body(t + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, 3);
+            body(t + 3, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 3);
+        }
+        using dyn = std::integral_constant<int, -1>;
+        auto flags_of = [&](int tt) { return (tt + 1 < nt ? 1 : 0) | (tt + 2 < nt ? 2 : 0) | ((ragged && tt + 1 == nt - 1) ? 4 : 0); };
+        for (; t < nt; t += 2) {
+            body(t, dyn{}, std::integral_constant<int, 0>{}, flags_of(t));
+            if (t + 1 < nt) body(t + 1, dyn{}, std::integral_constant<int, 1>{}, flags_of(t + 1));
+        }
+        mfma_drain();
+    };
+
+    // ---- prologue: first four tiles in flight, row maxima over tile 0 -------------------------------------------
+    auto issue_prologue = [&]() {
+        dma_tile(0, 0);
+        if (nt > 1) dma_tile(1, 1);
+        if (nt > 2) dma_tile(2, 2);
+        if (nt > 3) dma_tile(3, 3);
+        // tiles 0 and 1 landed; tiles 2, 3 may stay in flight
+        if (nt > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto lane_pair_max = [&](float mt) {
+        unsigned mu = __float_as_uint(mt);
+        auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    issue_prologue();
+    {
+        f32x16 zero16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+        sfor<0, 8>([&](auto i_tag) { read_k(std::integral_constant<int, 0>{}, 0, i_tag, kf); });
+        wait_k(kf);
+        settle(zero16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            sfor<0, 8>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                qk_mfma(S[0][qb][i >> 2], kf[i], qf[qb][i & 3], zero16, std::bool_constant<(i & 3) == 0>{});
+            });
+        }
+        mfma_drain();
+        if (nt == 1 && ragged) mask_tail(S[0], 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mt = fmaxf(S[0][qb][0][0], S[0][qb][1][0]);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, S[0][qb][0][i]), S[0][qb][1][i]);
+            m_fix[qb] = lane_pair_max(mt);
+        }
+    }
+    run_pass();
+
+    // ---- overflow check (block-uniform), exact-max second pass -----------------------------------------------------
+    auto own_l = [&](int qb) {
+#if Q64_ROWSUM_MFMA
+        return (lane & 16) ? lacc[qb][1] : lacc[qb][0];
+#else
+        return lsum[qb] + __shfl_xor(lsum[qb], 32);
+#endif
+    };
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF);
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            chk += own_l(qb) * 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) chk += acc_o[qb][0][i] * 0.f + acc_o[qb][1][i] * 0.f;
+        }
+        const bool bad = !(chk == 0.f);                    // inf * 0 and NaN * 0 are NaN
+        if (tid == 0) *flag = 0u;
+        __syncthreads();
+        if (__any(bad) && lane == 0) *flag = 1u;
+        __syncthreads();
+    }
+    if (*flag != 0u) {
+        // exact row maxima over all keys: K fragments by plain global loads (32 rows x 32 B each; slow path)
+        float mx[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mx[qb] = -INFINITY;
+        f32x16 zero16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+        for (int kb = 0; kb < 2 * nt; ++kb) {
+            int key = kb * 32 + r; const bool tailrow = key > a.Sk - 1; if (tailrow) key = a.Sk - 1;
+            bf16x8 kk[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kk[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * a.ldk + 16 * ks + 8 * h);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x16 s = zero16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kk[ks], qf[qb][ks], s, 0, 0, 0);
+                // rows past Sk repeat the last key: harmless for a maximum
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx[qb] = fmaxf(mx[qb], s[i]);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) m_fix[qb] = lane_pair_max(mx[qb]);
+        __syncthreads();                                   // every wave is done with the ring before it is refilled
+        issue_prologue();
+        run_pass();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float inv = 1.0f / own_l(qb);
+        const int qr = q0 + 32 * qb + r;
+        if (qr < a.Sq) {
+            bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * 64;
+            store_o64(acc_o[qb], inv, O, h, a.wide_o != 0);
+        }
+    }
+}
+
+// Grid: per batch, first heads*nbig big blocks (256 queries: [i*256, +256)), then heads*nsmall small blocks
+// (128 queries: [nbig*256 + i*128, +128)).  Inside each class blocks L, L+8 share an XCD, which is given whole heads.
+__global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnArgs a, int nbig, int nsmall) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * TILE_BYTES + 16];
+    const int per_b = a.heads * (nbig + nsmall);
+    int L = blockIdx.x;
+    const int b = L / per_b; L -= b * per_b;
+    const bool big = L < a.heads * nbig;
+    if (!big) L -= a.heads * nbig;
+    const int n = big ? nbig : nsmall;
+    int head, qb;
+    if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / n); qb = j % n; }
+    else { head = L / n; qb = L - head * n; }
+    if (big) attn_q64_block<2>(a, smem, b, head, qb * 256);
+    else attn_q64_block<1>(a, smem, b, head, nbig * 256 + qb * 128);
+}
+
+}  // namespace
+
+// Split of a head's queries into big (256) and small (128) blocks: as many big blocks as fill whole rounds of the
+// chip's CUs (one block per CU), the rest as small blocks that run in about half a big block's time, so the last
+// round of the grid is short instead of running a few long blocks on a mostly idle chip.
+int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) LTX_FAIL(LTX_ERR_HIP, "attention: device query failed");
+        n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    const int heads_total = a.heads * a.B;
+    const int nbig_max = a.Sq / 256;                                   // whole big blocks per head
+    int nbig = nbig_max;
+    if (const char* e = getenv("LTX_ATTN_Q64_BIG")) { nbig = atoi(e); if (nbig > nbig_max) nbig = nbig_max; if (nbig < 0) nbig = 0; }
+    else {
+        // big blocks in whole rounds; if the queries left over (as small blocks) would exceed one round, keep adding rounds
+        const int64_t total_big = (int64_t)heads_total * nbig_max;
+        const int64_t rounds = total_big / n_cu;
+        nbig = (int)(rounds * n_cu / heads_total);
+        if (nbig > nbig_max) nbig = nbig_max;
+    }
+    const int rest = a.Sq - nbig * 256;
+    const int nsmall = (rest + 127) / 128;
+    AttnArgs ax = a;
+    dim3 grid((unsigned)(heads_total * (nbig + nsmall))), block(256);
+    hipLaunchKernelGGL(attn_q64_kernel, grid, block, 0, s, ax, nbig, nsmall);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}

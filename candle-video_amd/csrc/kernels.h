@@ -106,6 +106,7 @@ struct AttnArgs {
     int wide_o = 0;                               // set by the launcher: 16-byte output stores (ldo % 8 == 0, 16-byte aligned o)
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
 bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
