@@ -45,13 +45,27 @@
 #define Q64_ASM_LOOP 1         // 0: the compiler-scheduled C++ loop for every tile (reference for the asm loop)
 #endif
 
+#ifndef Q64_STAMP
+#define Q64_STAMP 0            // 1 (diagnostic builds, loop generated with stamp=1): cycle / realtime stamps around the asm loop
+#endif
+#if Q64_STAMP
+__device__ unsigned long long q64_dbg[8 * 4096];   // per workgroup (wave 0): loop cycles, realtime ticks, iterations, QB, prologue cycles, epilogue cycles
+__device__ unsigned long long q64_t_asm_end;
+extern "C" int ltx_dbg_q64_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(q64_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 namespace {
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-#include "attn_q64_loop.inc"
+#ifndef Q64_LOOP_INC
+#define Q64_LOOP_INC "attn_q64_loop.inc"
+#endif
+#include Q64_LOOP_INC
 
 constexpr int BKV = 64, KROW = 128, VROW = 128, TILE_BYTES = BKV * (KROW + VROW), NSLOT = 4;
 constexpr int PW = 2, PIECES = 2 * PW;          // 1-KiB LDS-DMA pieces per wave and tile (K: 2, V: 2)
@@ -139,6 +153,9 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int q0 = q_first + wave * 32 * QB;
+#if Q64_STAMP
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * 64;
@@ -147,13 +164,15 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
 
     // Q^T operand fragments (B operand: k = d, col = query); rows past Sq repeat the last one (never stored)
     bf16x8 qf[QB][4];
+    auto load_q = [&]() {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        int qr = q0 + 32 * qb + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
-        const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
+        for (int qb = 0; qb < QB; ++qb) {
+            int qr = q0 + 32 * qb + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+            const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
+            for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+        }
+    };
 
     // ---- LDS-DMA geometry (attention.hip): pieces of 8 rows x 128 B, wave w issues pieces 2w, 2w+1 of K and of V;
     // the tile's bank swizzles are applied to the SOURCE chunk; rows past Sk are out of the buffer's range -> zeros
@@ -372,9 +391,16 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
 #pragma unroll
             for (int i = 0; i < 8; ++i) { B8 c; c.v = kf[i]; kk[4 * i] = c.u[0]; kk[4 * i + 1] = c.u[1]; kk[4 * i + 2] = c.u[2]; kk[4 * i + 3] = c.u[3]; }
             int cnt = N;
-            const uint32_t kstep = (uint32_t)BKV * (uint32_t)a.ldk * 2u, vstep = (uint32_t)BKV * (uint32_t)a.ldv * 2u;
+            const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
+            const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
             uint32_t koff = 4u * kstep, voff = 4u * vstep;
             const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
+#if Q64_STAMP
+            unsigned long long st0 = 0, sr0 = 0, st1 = 0, sr1 = 0;
+#define Q64_ST , st0, sr0, st1, sr1
+#else
+#define Q64_ST
+#endif
             if constexpr (QB == 2) {
                 f32x32 sx0, sx1, sy0, sy1, mi, o0, o1; f32x8 la; u32x32 qq;
 #pragma unroll
@@ -396,7 +422,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) { B8 c; c.v = P[0][qb][kb][s2]; for (int w = 0; w < 4; ++w) pk[((qb * 2 + kb) * 2 + s2) * 4 + w] = c.u[w]; }
-                q64_loop_qb2(sx0, sx1, sy0, sy1, pk, mi, la, o0, o1, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw);
+                q64_loop_qb2(sx0, sx1, sy0, sy1, pk, mi, la, o0, o1, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw Q64_ST);
                 const bool odd = (N & 1) != 0;                 // tile N (if any) sits in set N & 1: the tail below wants it in set 0
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -428,7 +454,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) { B8 c; c.v = P[ps][0][kb][s2]; for (int w = 0; w < 4; ++w) pk[ps * 16 + (kb * 2 + s2) * 4 + w] = c.u[w]; }
-                q64_loop_qb1(sx0, sy0, pk, mi, la, o0, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw);
+                q64_loop_qb1(sx0, sy0, pk, mi, la, o0, qq, kk, ones_u, kbase_u, tr_u, dma_u, rk_words, rv_words, cnt, koff, kstep, voff, vstep, ldsw Q64_ST);
                 const bool odd = (N & 1) != 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -444,6 +470,13 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) { B8 c; c.u[0] = kk[4 * i]; c.u[1] = kk[4 * i + 1]; c.u[2] = kk[4 * i + 2]; c.u[3] = kk[4 * i + 3]; kf[i] = c.v; }
+#if Q64_STAMP
+            if (tid == 0 && blockIdx.x < 4096) {
+                q64_dbg[8 * blockIdx.x] = st1 - st0; q64_dbg[8 * blockIdx.x + 1] = sr1 - sr0;
+                q64_dbg[8 * blockIdx.x + 2] = (unsigned long long)N; q64_dbg[8 * blockIdx.x + 3] = QB;
+                q64_dbg[8 * blockIdx.x + 4] = st0 - t_entry; q64_dbg[8 * blockIdx.x + 5] = st1;
+            }
+#endif
             t = N;
         }
         // remaining (ragged) iterations: tile t sits in set 0, so the parity of the compiler-scheduled bodies restarts
@@ -488,34 +521,6 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
         auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
         return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     };
-    issue_prologue();
-    {
-        f32x16 zero16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-        sfor<0, 8>([&](auto i_tag) { read_k(std::integral_constant<int, 0>{}, 0, i_tag, kf); });
-        wait_k(kf);
-        settle(zero16);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            sfor<0, 8>([&](auto i_tag) {
-                constexpr int i = decltype(i_tag)::value;
-                qk_mfma(S[0][qb][i >> 2], kf[i], qf[qb][i & 3], zero16, std::bool_constant<(i & 3) == 0>{});
-            });
-        }
-        mfma_drain();
-        if (nt == 1 && ragged) mask_tail(S[0], 0);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float mt = fmaxf(S[0][qb][0][0], S[0][qb][1][0]);
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, S[0][qb][0][i]), S[0][qb][1][i]);
-            m_fix[qb] = lane_pair_max(mt);
-        }
-    }
-    run_pass();
-
-    // ---- overflow check (block-uniform), exact-max second pass -----------------------------------------------------
     auto own_l = [&](int qb) {
 #if Q64_ROWSUM_MFMA
         return (lane & 16) ? lacc[qb][1] : lacc[qb][0];
@@ -524,48 +529,141 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
 #endif
     };
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF);
-    {
-        float chk = 0.f;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            chk += own_l(qb) * 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) chk += acc_o[qb][0][i] * 0.f + acc_o[qb][1][i] * 0.f;
-        }
-        const bool bad = !(chk == 0.f);                    // inf * 0 and NaN * 0 are NaN
+    auto block_any = [&](bool bad) {                       // block-uniform OR through one LDS word
         if (tid == 0) *flag = 0u;
         __syncthreads();
         if (__any(bad) && lane == 0) *flag = 1u;
         __syncthreads();
-    }
-    if (*flag != 0u) {
-        // exact row maxima over all keys: K fragments by plain global loads (32 rows x 32 B each; slow path)
-        float mx[QB];
+        return *flag != 0u;
+    };
+#ifndef Q64_NO_FALLBACK
+#define Q64_NO_FALLBACK 0   // 1: timing ablations whose garbage results must not start the second pass
+#endif
+#ifndef Q64_ASM_FULL
+#define Q64_ASM_FULL 1      // 0: compiler-scheduled prologue / epilogue around the generated loop for every shape
+#endif
+
+    bool need_exact = false;
+#if Q64_ASM_LOOP && Q64_ASM_FULL && Q64_ROWSUM_MFMA
+    // ---- fast path (key count a multiple of 64): prologue, loop and epilogue are one generated asm statement; only
+    // the addresses come from here.  It stores its result; the overflow check below decides whether that stands.
+    if (!ragged) {
+        union B8 { bf16x8 v; uint32_t u[4]; };
+        u32x4 ones_u; { B8 c; c.v = ones; ones_u = (u32x4){c.u[0], c.u[1], c.u[2], c.u[3]}; }
+        const u32x4 kbase_u = {k_base[0], k_base[1], k_base[2], k_base[3]};
+        const u32x2 tr_u = {tr_base[0], tr_base[1]};
+        const u32x4 dma_u = {k_voff[0], k_voff[1], v_voff[0], v_voff[1]};
+        u32x2 qoff, ooff;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) mx[qb] = -INFINITY;
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qr = q0 + 32 * (qb < QB ? qb : 0) + r;
+            const int qc = qr > a.Sq - 1 ? a.Sq - 1 : qr;
+            qoff[qb] = (uint32_t)qc * (uint32_t)a.ldq * 2u + 16u * h;
+            ooff[qb] = qr < a.Sq ? (uint32_t)qr * (uint32_t)a.ldo * 2u + 16u * h : 0x80000000u;     // rows past Sq: out of range, dropped
+        }
+        const uint64_t qp = (uint64_t)(uintptr_t)Q;
+        const uint64_t op = (uint64_t)(uintptr_t)(reinterpret_cast<bf16_t*>(a.o) + (int64_t)b * a.Sq * a.ldo + head * 64);
+        const u32x4 rq_words = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qp >> 32)) & 0xffffu,
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a.Sq - 1) * (uint32_t)a.ldq * 2u + 128u)), 0x00020000u};
+        const u32x4 ro_words = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)op), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(op >> 32)) & 0xffffu,
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a.Sq - 1) * (uint32_t)a.ldo * 2u + 128u)), 0x00020000u};
+        const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
+        const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
+        const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
+        const int nt_u = __builtin_amdgcn_readfirstlane(nt);
+        const uint32_t sel = (lane & 16) ? 1u : 0u;
+#if Q64_STAMP
+        unsigned long long sp0 = 0, sq0 = 0, st0 = 0, sr0 = 0, st1 = 0, sr1 = 0, sp1 = 0, sq1 = 0;
+#define Q64_STF , sp0, sq0, st0, sr0, st1, sr1, sp1, sq1
+#else
+#define Q64_STF
+#endif
+        bool bad = false;
+        if constexpr (QB == 2) {
+            f32x8 la;
+            q64_full_qb2(la, ones_u, kbase_u, tr_u, dma_u, qoff, ooff, sel, rk_words, rv_words, rq_words, ro_words, nt_u, kstep, vstep, ldsw Q64_STF);
+            const float l0 = (lane & 16) ? la[1] : la[0], l1 = (lane & 16) ? la[5] : la[4];
+            bad = !(l0 < 0x1p100f) || !(l1 < 0x1p100f);
+        } else {
+            f32x4 la;
+            q64_full_qb1(la, ones_u, kbase_u, tr_u, dma_u, qoff, ooff, sel, rk_words, rv_words, rq_words, ro_words, nt_u, kstep, vstep, ldsw Q64_STF);
+            const float l0 = (lane & 16) ? la[1] : la[0];
+            bad = !(l0 < 0x1p100f);
+        }
+#if Q64_STAMP
+        if (tid == 0 && blockIdx.x < 4096) {
+            q64_dbg[8 * blockIdx.x] = st1 - st0; q64_dbg[8 * blockIdx.x + 1] = sr1 - sr0;
+            q64_dbg[8 * blockIdx.x + 2] = (unsigned long long)nt; q64_dbg[8 * blockIdx.x + 3] = QB;
+            q64_dbg[8 * blockIdx.x + 4] = st0 - t_entry; q64_dbg[8 * blockIdx.x + 5] = sp1 - st1;
+        }
+#endif
+        // l beyond 2^100 (or NaN): some p overflowed, or came within 2^27 of it - O^T is then not to be trusted either
+        if (Q64_NO_FALLBACK || !block_any(bad)) return;
+        need_exact = true;
+    }
+#endif
+
+    // ---- generic path: ragged key counts, and the exact-max pass after an overflow.  Pass 0 takes the row maxima
+    // from the first tile; pass 1 (only after an overflow) computes them over all keys first.
+    load_q();
+    for (int pass = need_exact ? 1 : 0; pass < 2; ++pass) {
         f32x16 zero16;
 #pragma unroll
         for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-        for (int kb = 0; kb < 2 * nt; ++kb) {
-            int key = kb * 32 + r; const bool tailrow = key > a.Sk - 1; if (tailrow) key = a.Sk - 1;
-            bf16x8 kk[4];
+        if (pass == 1) {
+            // exact row maxima over all keys: K fragments by plain global loads (32 rows x 32 B each; slow path)
+            float mx[QB];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kk[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * a.ldk + 16 * ks + 8 * h);
+            for (int qb = 0; qb < QB; ++qb) mx[qb] = -INFINITY;
+            for (int kb = 0; kb < 2 * nt; ++kb) {
+                int key = kb * 32 + r; if (key > a.Sk - 1) key = a.Sk - 1;     // rows past Sk repeat the last key: harmless for a maximum
+                bf16x8 kk[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kk[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * a.ldk + 16 * ks + 8 * h);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    f32x16 sc = zero16;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kk[ks], qf[qb][ks], sc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mx[qb] = fmaxf(mx[qb], sc[i]);
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) m_fix[qb] = lane_pair_max(mx[qb]);
+            __syncthreads();                               // every wave is done with the ring before it is refilled
+        }
+        issue_prologue();
+        if (pass == 0) {
+            sfor<0, 8>([&](auto i_tag) { read_k(std::integral_constant<int, 0>{}, 0, i_tag, kf); });
+            wait_k(kf);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                f32x16 s = zero16;
+                sfor<0, 8>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    qk_mfma(S[0][qb][i >> 2], kf[i], qf[qb][i & 3], zero16, std::bool_constant<(i & 3) == 0>{});
+                });
+            }
+            if (nt == 1 && ragged) mask_tail(S[0], 0);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kk[ks], qf[qb][ks], s, 0, 0, 0);
-                // rows past Sk repeat the last key: harmless for a maximum
+            for (int qb = 0; qb < QB; ++qb) {
+                float mt = fmaxf(S[0][qb][0][0], S[0][qb][1][0]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mx[qb] = fmaxf(mx[qb], s[i]);
+                for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, S[0][qb][0][i]), S[0][qb][1][i]);
+                m_fix[qb] = lane_pair_max(mt);
             }
         }
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) m_fix[qb] = lane_pair_max(mx[qb]);
-        __syncthreads();                                   // every wave is done with the ring before it is refilled
-        issue_prologue();
         run_pass();
+        if (pass == 0) {
+            float chk = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                chk += own_l(qb) * 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) chk += acc_o[qb][0][i] * 0.f + acc_o[qb][1][i] * 0.f;
+            }
+            if (Q64_NO_FALLBACK || !block_any(!(chk == 0.f))) break;      // inf * 0 and NaN * 0 are NaN
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -578,6 +676,10 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
             store_o64(acc_o[qb], inv, O, h, a.wide_o != 0);
         }
     }
+#if Q64_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && blockIdx.x < 4096) q64_dbg[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime() - q64_dbg[8 * blockIdx.x + 5];
+#endif
 }
 
 // Grid: per batch, first heads*nbig big blocks (256 queries: [i*256, +256)), then heads*nsmall small blocks

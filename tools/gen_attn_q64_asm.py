@@ -34,9 +34,26 @@ KROW = VROW = 128
 VBASE = 64 * KROW
 
 
-def gen(QB):
+DEFAULTS = dict(abl="", cvt_lag=1, v_early=1, stamp=0, v_gaps="", k_gaps="", dma_gaps="", row_gaps="", v_gaps1="", k_gaps1="", dma_gaps1="", row_gaps1="")
+
+
+def gen(QB, opt=None, full=False):
+    o_ = dict(DEFAULTS); o_.update(opt or {})
+    abl = set(x for x in str(o_["abl"]).split("+") if x)
+    lag = int(o_["cvt_lag"])
     L = []
-    emit = L.append
+    def emit(ins):
+        op = ins.split()[0]
+        if "nodma" in abl and (op.startswith("buffer_load") or ins.startswith("s_add_u32 m0")): return
+        if "noexp" in abl and op.startswith("v_exp"): ins = ins.replace("v_exp_f32_e32", "v_mov_b32_e32")
+        if "dropexp" in abl and (op.startswith("v_exp") or op.startswith("v_cvt_pk")): return
+        if "nobar" in abl and op == "s_barrier": return
+        if "norow" in abl and op.startswith("v_mfma_f32_16x16x32"): return
+        if "nolds" in abl and op.startswith("ds_read"): return
+        if "nomfma" in abl and op.startswith("v_mfma_f32_32x32"): return
+        if "halfexp" in abl and op.startswith("v_exp") and (int(ins.split()[1].strip("v,")) & 1): return
+        if "nocvt" in abl and op.startswith("v_cvt_pk"): return
+        L.append(ins)
     SW = 32 * QB                      # registers per S^T set
     def S(st, qb, kb):                # first register of S^T block
         return st * SW + (qb * 2 + kb) * 16
@@ -59,76 +76,179 @@ def gen(QB):
     def vr(a, n): return f"v[{a}:{a + n - 1}]"
     def ar(a, n): return f"a[{a}:{a + n - 1}]"
 
+    pending = [None]                  # cvt_lag = 1: (dst, t0, t1) of the previous gap's pair
     def exp_slice(sbase, pbase2, i, filler):
         """registers 2i, 2i+1 of the S^T block at sbase -> word (i & 3) of P operand s = i >> 2"""
         t0, t1 = temps()
+        dst = pbase2[i >> 2] + (i & 3)
+        if lag:
+            if pending[0]: emit("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % pending[0])
+            emit(f"v_exp_f32_e32 v{t0}, v{sbase + 2 * i}")
+            emit(f"v_exp_f32_e32 v{t1}, v{sbase + 2 * i + 1}")
+            for ins in filler: emit(ins)
+            pending[0] = (dst, t0, t1)
+            return
         emit(f"v_exp_f32_e32 v{t0}, v{sbase + 2 * i}")
         emit(f"v_exp_f32_e32 v{t1}, v{sbase + 2 * i + 1}")
         for ins in filler: emit(ins)
         if not filler: emit("s_nop 0")                       # trans result -> VALU read needs one state
-        emit(f"v_cvt_pk_bf16_f32 v{pbase2[i >> 2] + (i & 3)}, v{t0}, v{t1}")
+        emit(f"v_cvt_pk_bf16_f32 v{dst}, v{t0}, v{t1}")
+
+    NG = 16 * QB                      # MFMA gaps per iteration: QK groups then PV groups, 8 gaps each
+
+    def parse(key, default):
+        v = o_.get(key + ("1" if QB == 1 else "")) or default
+        return [int(x) for x in str(v).split(",")] if isinstance(v, str) else list(v)
+    # ---- placement tables (gap indices inside one iteration; QK gaps 0 .. 8*QB-1, PV gaps 8*QB .. 16*QB-1) ----
+    PV0 = 8 * QB
+    if QB == 2:
+        v_def = [i // 2 for i in range(16)] if int(o_["v_early"]) else list(range(16))
+        k_def = [PV0 + i for i in range(8)]
+        d_def = [PV0 + 8 + 2 * p for p in range(4)]
+        r_def = [PV0 + 4 + i for i in range(4)] + [PV0 + 12 + i for i in range(4)]
+    else:
+        v_def = [i // 2 for i in range(16)]
+        k_def = [PV0 + i for i in range(8)]
+        d_def = [PV0 + 2 * p for p in range(4)]
+        r_def = [PV0 + 4 + i for i in range(4)]
+    v_gaps, k_gaps = parse("v_gaps", v_def), parse("k_gaps", k_def)
+    d_gaps, r_gaps = parse("dma_gaps", d_def), parse("row_gaps", r_def)
+    assert len(v_gaps) == 16 and len(k_gaps) == 8 and len(d_gaps) == 4 and len(r_gaps) == 4 * QB
+    assert all(0 <= x < PV0 for x in v_gaps) and all(PV0 <= x < NG for x in k_gaps + d_gaps)
 
     def body(slot, cur):
         nxt = cur ^ 1
         pc, pn = (cur, nxt) if QB == 1 else (0, 0)
         kslot = (slot + 2) & 3
-        # ---- QK groups
+        for gp in range(NG):
+            grp, i = gp // 8, gp % 8
+            if gp == PV0:                                     # tile t+2 landed for every wave, V^T(t) fragments in
+                emit("s_waitcnt vmcnt(4)")
+                emit("s_waitcnt lgkmcnt(0)")
+                emit("s_barrier")
+            pre = []
+            fill = []
+            if gp < PV0:                                      # ---- QK gap
+                qb, kb, ks = grp, i >> 2, i & 3
+                d = vr(S(nxt, qb, kb), 16)
+                c = vr(MINIT(qb), 16) if ks == 0 else d
+                main = f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {c}"
+                if QB == 2 and qb == 1: sb, pb = S(cur, 1, 0), [P(pc, 1, 0, 0), P(pc, 1, 0, 1)]
+                else: sb, pb = S(cur, 0, 1), [P(pc, 0, 1, 0), P(pc, 0, 1, 1)]
+            else:                                             # ---- PV gap
+                qb, dd, j = grp - QB, i >> 2, i & 3
+                o = ar(O(qb, dd), 16)
+                main = f"v_mfma_f32_32x32x16_bf16 {o}, {ar(VF(i), 4)}, {vr(P(pc, qb, j >> 1, j & 1), 4)}, {o}"
+                if QB == 2 and qb == 0: sb, pb = S(cur, 1, 1), [P(pc, 1, 1, 0), P(pc, 1, 1, 1)]
+                else: sb, pb = S(nxt, 0, 0), [P(pn, 0, 0, 0), P(pn, 0, 0, 1)]
+            for hidx, vg in enumerate(v_gaps):                # V^T(t) transpose reads
+                if vg != gp: continue
+                n, hf = hidx >> 1, hidx & 1
+                d2, j2 = n >> 2, n & 3
+                rowc = (j2 >> 1) * 32 + (j2 & 1) * 16 + 8 * hf
+                fill.append(f"ds_read_b64_tr_b16 {ar(VF(n) + 2 * hf, 2)}, v{212 + d2} offset:{slot * TILE + VBASE + rowc * VROW}")
+            for ki, kg in enumerate(k_gaps):                  # K(t+2) fragments
+                if kg != gp: continue
+                fill.append(f"ds_read_b128 {ar(KF(ki), 4)}, v{208 + (ki & 3)} offset:{kslot * TILE + (ki >> 2) * 32 * KROW}")
+            for p, dg in enumerate(d_gaps):                   # DMA piece p of tile t+4 into the slot of tile t
+                if dg != gp: continue
+                imm = slot * TILE + (VBASE if p >= 2 else 0) + (p & 1) * 1024
+                pre.append(f"s_add_u32 m0, %[ldsw], {imm}")   # M0 written >= 2 instructions ahead of the load
+                if p < 2: fill.append(f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], %[koff] offen lds")
+                else: fill.append(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], %[voff] offen lds")
+            for ri, rg in enumerate(r_gaps):                  # row-sum MFMA ri: query block ri / 4, operand (kb, s) = ri % 4
+                if rg != gp: continue
+                rq, ro = ri // 4, ri % 4
+                l = vr(LACC(rq), 4)
+                fill.append(f"v_mfma_f32_16x16x32_bf16 {l}, {ar(ONES, 4)}, {vr(P(pc, rq, ro >> 1, ro & 1), 4)}, {l}")
+            emit(main)
+            for ins in pre: emit(ins)
+            exp_slice(sb, pb, i, fill)
+        emit("s_add_u32 %[koff], %[koff], %[kstep]")
+        emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        if pending[0]:                                        # cvt_lag: the body's last pair (two SALU since its exps)
+            emit("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % pending[0]); pending[0] = None
+        emit("s_waitcnt lgkmcnt(0)")
+
+    def stamp(a, b_):
+        if int(o_["stamp"]):
+            emit(f"s_memtime %[{a}]"); emit(f"s_memrealtime %[{b_}]"); emit("s_waitcnt lgkmcnt(0)")
+
+    def prologue():
+        """full flavour: Q^T fragments, first four tiles in flight, S^T(0), row maxima over tile 0, -m tuples, K(1)
+        fragments, first exp slice, O^T / l zeroed.  Tiles past the last one are out of the buffers' range (zeros)."""
+        for qb in range(QB):
+            for ks in range(4):
+                off = f" offset:{32 * ks}" if ks else ""
+                emit(f"buffer_load_dwordx4 {ar(Q(qb, ks), 4)}, v{218 + qb}, %[rq], 0 offen{off}")
+        for tl in range(4):
+            for p in range(4):
+                imm = tl * TILE + (VBASE if p >= 2 else 0) + (p & 1) * 1024
+                emit(f"s_add_u32 m0, %[ldsw], {imm}")
+                emit("s_nop 0")
+                if p < 2: emit(f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], %[koff] offen lds")
+                else: emit(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], %[voff] offen lds")
+            emit("s_add_u32 %[koff], %[koff], %[kstep]")
+            emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        emit("s_waitcnt vmcnt(8)")                           # Q^T and tiles 0, 1 landed; tiles 2, 3 stay in flight
+        emit("s_barrier")
+        for i in range(8):
+            emit(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + (i & 3)} offset:{(i >> 2) * 32 * KROW}")
+        emit("s_waitcnt lgkmcnt(0)")
         for qb in range(QB):
             for i in range(8):
                 kb, ks = i >> 2, i & 3
-                d = vr(S(nxt, qb, kb), 16)
-                c = vr(MINIT(qb), 16) if ks == 0 else d
-                emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {c}")
-                if QB == 2:
-                    sb = S(cur, 0, 1) if qb == 0 else S(cur, 1, 0)
-                    pb = [P(pc, 0, 1, 0), P(pc, 0, 1, 1)] if qb == 0 else [P(pc, 1, 0, 0), P(pc, 1, 0, 1)]
-                    halves = [qb * 8 + i]
-                else:
-                    sb = S(cur, 0, 1); pb = [P(pc, 0, 1, 0), P(pc, 0, 1, 1)]
-                    halves = [2 * i, 2 * i + 1]
-                fill = []
-                for hidx in halves:
-                    n, hf = hidx >> 1, hidx & 1
-                    dd, j = n >> 2, n & 3
-                    rowc = (j >> 1) * 32 + (j & 1) * 16 + 8 * hf
-                    imm = slot * TILE + VBASE + rowc * VROW
-                    fill.append(f"ds_read_b64_tr_b16 {ar(VF(n) + 2 * hf, 2)}, v{212 + dd} offset:{imm}")
-                exp_slice(sb, pb, i, fill)
-        # ---- tile t+2 landed for every wave, V^T(t) fragments in
-        emit("s_waitcnt vmcnt(4)")
-        emit("s_waitcnt lgkmcnt(0)")
-        emit("s_barrier")
-        # ---- PV groups
+                d = vr(S(0, qb, kb), 16)
+                emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {'0' if ks == 0 else d}")
+        for i in range(8):                                   # K(1) fragments (the MFMAs above have read theirs long before these land)
+            emit(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + (i & 3)} offset:{TILE + (i >> 2) * 32 * KROW}")
+        for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
+        for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
+        for qb in range(QB):                                 # row maxima: 32 scores in the lane, then the other lane half
+            s0 = S(0, qb, 0); m = 200 + qb
+            emit(f"v_max3_f32 v{m}, v{s0}, v{s0 + 1}, v{s0 + 2}")
+            for i in range(3, 31, 2): emit(f"v_max3_f32 v{m}, v{m}, v{s0 + i}, v{s0 + i + 1}")
+            emit(f"v_max_f32_e32 v{m}, v{m}, v{s0 + 31}")
+            emit(f"v_mov_b32_e32 v{202 + qb}, v{m}")
+        emit("s_nop 1")
+        for qb in range(QB): emit(f"v_permlane32_swap_b32_e32 v{200 + qb}, v{202 + qb}")
+        for qb in range(QB): emit(f"v_max_f32_e32 v{200 + qb}, v{200 + qb}, v{202 + qb}")
         for qb in range(QB):
-            for i in range(8):
-                d, j = i >> 2, i & 3
-                o = ar(O(qb, d), 16)
-                emit(f"v_mfma_f32_32x32x16_bf16 {o}, {ar(VF(i), 4)}, {vr(P(pc, qb, j >> 1, j & 1), 4)}, {o}")
-                fill = []
-                if QB == 2 and qb == 0:
-                    sb = S(cur, 1, 1); pb = [P(pc, 1, 1, 0), P(pc, 1, 1, 1)]
-                else:
-                    sb = S(nxt, 0, 0); pb = [P(pn, 0, 0, 0), P(pn, 0, 0, 1)]
-                if qb == 0:                                   # K(t+2) fragment i
-                    kb, ks = i >> 2, i & 3
-                    fill.append(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + ks} offset:{kslot * TILE + kb * 32 * KROW}")
-                if qb == QB - 1 and i % 2 == 0:               # DMA piece i/2 of tile t+4 into the slot of tile t
-                    p = i >> 1
-                    imm = slot * TILE + (VBASE if p >= 2 else 0) + (p & 1) * 1024
-                    pre = f"s_add_u32 m0, %[ldsw], {imm}"
-                    if p < 2: ld = f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], %[koff] offen lds"
-                    else: ld = f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], %[voff] offen lds"
-                    emit(pre)                                 # M0 written >= 2 instructions ahead of the load
-                    fill.append(ld)
-                if i >= 4:
-                    l = vr(LACC(qb), 4)
-                    fill.append(f"v_mfma_f32_16x16x32_bf16 {l}, {ar(ONES, 4)}, {vr(P(pc, qb, (i - 4) >> 1, (i - 4) & 1), 4)}, {l}")
-                exp_slice(sb, pb, i, fill)
-        emit("s_add_u32 %[koff], %[koff], %[kstep]")
-        emit("s_add_u32 %[voff], %[voff], %[vstep]")
+            for i in range(16): emit(f"v_xor_b32_e32 v{MINIT(qb) + i}, 0x80000000, v{200 + qb}")
+            for i in range(32): emit(f"v_sub_f32_e32 v{S(0, qb, 0) + i}, v{S(0, qb, 0) + i}, v{200 + qb}")
         emit("s_waitcnt lgkmcnt(0)")
+        for i in range(8):                                   # first exp slice: (tile 0, q0, k0)
+            t0, t1 = temps()
+            emit(f"v_exp_f32_e32 v{t0}, v{S(0, 0, 0) + 2 * i}")
+            emit(f"v_exp_f32_e32 v{t1}, v{S(0, 0, 0) + 2 * i + 1}")
+            emit("s_nop 0")
+            emit(f"v_cvt_pk_bf16_f32 v{P(0, 0, 0, i >> 2) + (i & 3)}, v{t0}, v{t1}")
+        tmp[0] = 0
+
+    def epilogue():
+        """full flavour: O^T / l -> bf16 rows, 16-byte stores (lanes l, l^32 exchange column groups, attention.hip store_o_wide)"""
+        emit("v_cmp_ne_u32_e32 vcc, 0, v222")
+        for qb in range(QB):
+            emit(f"v_cndmask_b32_e32 v{204 + qb}, v{LACC(qb)}, v{LACC(qb) + 1}, vcc")
+        for qb in range(QB): emit(f"v_rcp_f32_e32 v{206 + qb}, v{204 + qb}")
+        R = 0                                                # S^T registers are free now
+        for qb in range(QB):
+            for d in range(2):
+                for k in range(2):
+                    base = R; R = (R + 16) % 96
+                    for e in range(8): emit(f"v_accvgpr_read_b32 v{base + e}, a{O(qb, d) + 8 * k + e}")
+                    for e in range(8): emit(f"v_mul_f32_e32 v{base + e}, v{206 + qb}, v{base + e}")
+                    for w in range(4): emit(f"v_cvt_pk_bf16_f32 v{base + 8 + w}, v{base + 2 * w}, v{base + 2 * w + 1}")
+                    emit("s_nop 1")
+                    emit(f"v_permlane32_swap_b32_e32 v{base + 8}, v{base + 10}")
+                    emit(f"v_permlane32_swap_b32_e32 v{base + 9}, v{base + 11}")
+                    emit(f"buffer_store_dwordx4 {vr(base + 8, 4)}, v{220 + qb}, %[ro], 0 offen offset:{d * 64 + 32 * k}")
 
     emit("s_nop 15")                                        # operands set up by compiler-scheduled VALU / accvgpr writes
+    if full:
+        stamp("sp0", "sq0")
+        prologue()
+    stamp("st0", "sr0")
     for it in range(4):
         if it == 0: emit("1:")
         body(it, it & 1)
@@ -137,14 +257,18 @@ def gen(QB):
         if it < 3: emit("s_cbranch_scc1 2f")
         else: emit("s_cbranch_scc0 1b")
     emit("2:")
+    stamp("st1", "sr1")
     emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")
     emit("s_nop 15")
+    if full:
+        epilogue()
+        stamp("sp1", "sq1")
     return L
 
 
-def c_function(QB):
-    lines = gen(QB)
+def c_function(QB, opt=None):
+    lines = gen(QB, opt)
     text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
     if QB == 2:
         sig = ("f32x32& sx0, f32x32& sx1, f32x32& sy0, f32x32& sy1, u32x32& p, const f32x32& minit, f32x8& lacc, "
@@ -156,12 +280,15 @@ def c_function(QB):
         sig = ("f32x32& sx0, f32x32& sy0, u32x32& p, const f32x16& minit, f32x4& lacc, f32x32& o0, const u32x16& q, u32x32& kf, ")
         outs = ('"+{v[0:31]}"(sx0), "+{v[32:63]}"(sy0), "+{v[128:159]}"(p), "+{v[192:195]}"(lacc), "+{a[0:31]}"(o0), "+{a[96:127]}"(kf), ')
         ins = '"{v[160:175]}"(minit), "{a[64:79]}"(q), '
+    stamp = int((dict(DEFAULTS, **(opt or {})))["stamp"])
+    st_sig = ", unsigned long long& st0, unsigned long long& sr0, unsigned long long& st1, unsigned long long& sr1" if stamp else ""
+    st_out = ', [st0] "=&s"(st0), [sr0] "=&s"(sr0), [st1] "=&s"(st1), [sr1] "=&s"(sr1)' if stamp else ""
     clob = ['"v200"', '"v201"', '"v202"', '"v203"', '"v204"', '"v205"', '"v206"', '"v207"'] + [f'"a{i}"' for i in range(128, 160)] + ['"scc"', '"memory"']
     return f"""// GENERATED by tools/gen_attn_q64_asm.py - do not edit.  {len(lines)} instructions, QB = {QB}.
 __device__ __forceinline__ void q64_loop_qb{QB}({sig}const u32x4& ones, const u32x4& kbase, const u32x2& trbase, const u32x4& dmaoff,
-        const u32x4& rk, const u32x4& rv, int& cnt, uint32_t& koff, uint32_t kstep, uint32_t& voff, uint32_t vstep, uint32_t ldsw) {{
+        const u32x4& rk, const u32x4& rv, int& cnt, uint32_t& koff, uint32_t kstep, uint32_t& voff, uint32_t vstep, uint32_t ldsw{st_sig}) {{
     asm volatile(
-{text}        : {outs}[cnt] "+s"(cnt), [koff] "+s"(koff), [voff] "+s"(voff)
+{text}        : {outs}[cnt] "+s"(cnt), [koff] "+s"(koff), [voff] "+s"(voff){st_out}
         : {ins}"{{a[160:163]}}"(ones), "{{v[208:211]}}"(kbase), "{{v[212:213]}}"(trbase), "{{v[214:217]}}"(dmaoff),
           [rk] "s"(rk), [rv] "s"(rv), [kstep] "s"(kstep), [vstep] "s"(vstep), [ldsw] "s"(ldsw)
         : {", ".join(clob)});
@@ -169,14 +296,52 @@ __device__ __forceinline__ void q64_loop_qb{QB}({sig}const u32x4& ones, const u3
 """
 
 
+def c_function_full(QB, opt=None):
+    lines = gen(QB, opt, full=True)
+    text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
+    stamp = int((dict(DEFAULTS, **(opt or {})))["stamp"])
+    names = ["sp0", "sq0", "st0", "sr0", "st1", "sr1", "sp1", "sq1"]
+    st_sig = "".join(f", unsigned long long& {n}" for n in names) if stamp else ""
+    st_out = "".join(f', [{n}] "=&s"({n})' for n in names) if stamp else ""
+    lout = '"={v[192:199]}"(lacc)' if QB == 2 else '"={v[192:195]}"(lacc)'
+    ltype = "f32x8" if QB == 2 else "f32x4"
+    used_v = [i for i in range(0, 192)] + [i for i in range(192 + 4 * QB, 208)]
+    clob = [f'"v{i}"' for i in used_v] + [f'"a{i}"' for i in range(0, 160)] + ['"vcc"', '"scc"', '"memory"']
+    return f"""// GENERATED by tools/gen_attn_q64_asm.py - do not edit.  {len(lines)} instructions, QB = {QB}: prologue + loop + epilogue.
+__device__ __forceinline__ void q64_full_qb{QB}({ltype}& lacc, const u32x4& ones, const u32x4& kbase, const u32x2& trbase, const u32x4& dmaoff,
+        const u32x2& qoff, const u32x2& ooff, uint32_t sel, const u32x4& rk, const u32x4& rv, const u32x4& rq, const u32x4& ro,
+        int cnt, uint32_t kstep, uint32_t vstep, uint32_t ldsw{st_sig}) {{
+    uint32_t koff = 0, voff = 0;
+    asm volatile(
+{text}        : {lout}, [cnt] "+s"(cnt), [koff] "+s"(koff), [voff] "+s"(voff){st_out}
+        : "{{a[160:163]}}"(ones), "{{v[208:211]}}"(kbase), "{{v[212:213]}}"(trbase), "{{v[214:217]}}"(dmaoff), "{{v[218:219]}}"(qoff),
+          "{{v[220:221]}}"(ooff), "{{v222}}"(sel), [rk] "s"(rk), [rv] "s"(rv), [rq] "s"(rq), [ro] "s"(ro),
+          [kstep] "s"(kstep), [vstep] "s"(vstep), [ldsw] "s"(ldsw)
+        : {", ".join(clob)});
+}}
+"""
+
+
 def main():
+    """usage: gen_attn_q64_asm.py [--out FILE] [key=value ...]   (keys: see DEFAULTS; the shipped file uses the defaults)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "candle-video_amd", "csrc", "attn_q64_loop.inc")
+    opt = {}
+    args = sys.argv[1:]
+    while args:
+        a = args.pop(0)
+        if a == "--out": out = args.pop(0)
+        else:
+            k, v = a.split("="); assert k in DEFAULTS, k; opt[k] = v
     with open(out, "w") as f:
-        f.write(c_function(2))
+        f.write(c_function(2, opt))
         f.write("\n")
-        f.write(c_function(1))
-    print("wrote", out)
+        f.write(c_function(1, opt))
+        f.write("\n")
+        f.write(c_function_full(2, opt))
+        f.write("\n")
+        f.write(c_function_full(1, opt))
+    print("wrote", out, opt)
 
 
 if __name__ == "__main__":
