@@ -573,8 +573,8 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
         const int nt_u = __builtin_amdgcn_readfirstlane(nt);
         const uint32_t sel = (lane & 16) ? 1u : 0u;
 #if Q64_STAMP
-        unsigned long long sp0 = 0, sq0 = 0, st0 = 0, sr0 = 0, st1 = 0, sr1 = 0, sp1 = 0, sq1 = 0;
-#define Q64_STF , sp0, sq0, st0, sr0, st1, sr1, sp1, sq1
+        unsigned long long sp0 = 0, sq0 = 0, st0 = 0, sr0 = 0, st1 = 0, sr1 = 0, sp1 = 0, sq1 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa4 = 0;
+#define Q64_STF , sp0, sq0, st0, sr0, st1, sr1, sp1, sq1, sa1, sa2, sa3, sa4
 #else
 #define Q64_STF
 #endif
@@ -595,6 +595,8 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
             q64_dbg[8 * blockIdx.x] = st1 - st0; q64_dbg[8 * blockIdx.x + 1] = sr1 - sr0;
             q64_dbg[8 * blockIdx.x + 2] = (unsigned long long)nt; q64_dbg[8 * blockIdx.x + 3] = QB;
             q64_dbg[8 * blockIdx.x + 4] = st0 - t_entry; q64_dbg[8 * blockIdx.x + 5] = sp1 - st1;
+            q64_dbg[8 * blockIdx.x + 6] = ((sp0 - t_entry) << 48) | ((sa1 - sp0) << 32) | ((sa2 - sa1) << 16) | (sa3 - sa2);
+            q64_dbg[8 * blockIdx.x + 7] = ((sa4 - sa3) << 32) | (st0 - sa4);
         }
 #endif
         // l beyond 2^100 (or NaN): some p overflowed, or came within 2^27 of it - O^T is then not to be trusted either

@@ -80,6 +80,10 @@ def measure():
             res[f"{kind}_cyc"] = round(float(np.median(a[:, 0] / a[:, 2])), 1)
             res[f"{kind}_GHz"] = round(float(np.median(a[:, 0] / a[:, 1]) * 0.1), 3)
             res[f"{kind}_pro"] = round(float(np.median(a[:, 4])), 0); res[f"{kind}_epi"] = round(float(np.median(a[:, 5])), 0)
+            raw = np.array(buf[:], dtype=np.uint64).reshape(-1, 8); raw = raw[raw[:, 2] > 0]
+            w6, w7 = raw[:, 6], raw[:, 7]
+            parts = [w6 >> np.uint64(48), (w6 >> np.uint64(32)) & np.uint64(0xffff), (w6 >> np.uint64(16)) & np.uint64(0xffff), w6 & np.uint64(0xffff), w7 >> np.uint64(32), w7 & np.uint64(0xffffffff)]
+            res[f"{kind}_pro_parts"] = [int(np.median(x)) for x in parts]   # C++ setup | issue Q+DMA | wait vmcnt | barrier | S0,max,sub,K1 | exp slice
         os.environ.pop("LTX_ATTN_Q64_BIG")
     print(json.dumps(res), flush=True)
 

@@ -50,6 +50,9 @@ def gen(QB, opt=None, full=False):
         if "nobar" in abl and op == "s_barrier": return
         if "norow" in abl and op.startswith("v_mfma_f32_16x16x32"): return
         if "nolds" in abl and op.startswith("ds_read"): return
+        if "nokread" in abl and op.startswith("ds_read_b128"): return
+        if "novread" in abl and op.startswith("ds_read_b64_tr"): return
+        if "nosadd" in abl and ins.startswith("s_add_u32 m0"): return
         if "nomfma" in abl and op.startswith("v_mfma_f32_32x32"): return
         if "halfexp" in abl and op.startswith("v_exp") and (int(ins.split()[1].strip("v,")) & 1): return
         if "nocvt" in abl and op.startswith("v_cvt_pk"): return
@@ -190,8 +193,11 @@ def gen(QB, opt=None, full=False):
                 else: emit(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], %[voff] offen lds")
             emit("s_add_u32 %[koff], %[koff], %[kstep]")
             emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        if int(o_["stamp"]): emit("s_memtime %[sa1]")
         emit("s_waitcnt vmcnt(8)")                           # Q^T and tiles 0, 1 landed; tiles 2, 3 stay in flight
+        if int(o_["stamp"]): emit("s_memtime %[sa2]")
         emit("s_barrier")
+        if int(o_["stamp"]): emit("s_memtime %[sa3]")
         for i in range(8):
             emit(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + (i & 3)} offset:{(i >> 2) * 32 * KROW}")
         emit("s_waitcnt lgkmcnt(0)")
@@ -217,6 +223,7 @@ def gen(QB, opt=None, full=False):
             for i in range(16): emit(f"v_xor_b32_e32 v{MINIT(qb) + i}, 0x80000000, v{200 + qb}")
             for i in range(32): emit(f"v_sub_f32_e32 v{S(0, qb, 0) + i}, v{S(0, qb, 0) + i}, v{200 + qb}")
         emit("s_waitcnt lgkmcnt(0)")
+        if int(o_["stamp"]): emit("s_memtime %[sa4]")
         for i in range(8):                                   # first exp slice: (tile 0, q0, k0)
             t0, t1 = temps()
             emit(f"v_exp_f32_e32 v{t0}, v{S(0, 0, 0) + 2 * i}")
@@ -300,7 +307,7 @@ def c_function_full(QB, opt=None):
     lines = gen(QB, opt, full=True)
     text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
     stamp = int((dict(DEFAULTS, **(opt or {})))["stamp"])
-    names = ["sp0", "sq0", "st0", "sr0", "st1", "sr1", "sp1", "sq1"]
+    names = ["sp0", "sq0", "st0", "sr0", "st1", "sr1", "sp1", "sq1", "sa1", "sa2", "sa3", "sa4"]
     st_sig = "".join(f", unsigned long long& {n}" for n in names) if stamp else ""
     st_out = "".join(f', [{n}] "=&s"({n})' for n in names) if stamp else ""
     lout = '"={v[192:199]}"(lacc)' if QB == 2 else '"={v[192:195]}"(lacc)'
