@@ -300,11 +300,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 template <int BN, int WGM, int WGN, int EPI>
 int launch_halo(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * A_STAGE + 2 * BN * ROWB;
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_devs{0};
     auto kern = conv_halo_kernel<BN, WGM, WGN, EPI>;
-    if (!attr_set) {
+    if (ltx_once_per_device(attr_devs)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
     GemmArgs ga = g;

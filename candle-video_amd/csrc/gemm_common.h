@@ -108,3 +108,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
 
 
 }  // namespace
+
+// hipFuncSetAttribute is per device: a per-kernel-instantiation bit mask of the devices already configured
+// (several devices in one process).  Returns true the first time it is called for the current device.
+#include <atomic>
+static inline bool ltx_once_per_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    return (mask.fetch_or(bit) & bit) == 0;
+}

@@ -260,11 +260,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
 template <int BN, int WGM, int WGN, int EPI, bool CONV>
 int launch_one8(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (2 * 128 * 128 + BN * 128);
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_devs{0};
     auto kern = gemm_p8_kernel<BN, WGM, WGN, EPI, CONV>;
-    if (!attr_set) {
+    if (ltx_once_per_device(attr_devs)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     dim3 grid((unsigned)(cdiv(g.M, 256) * cdiv(g.N, BN))), block(512);
     hipLaunchKernelGGL(kern, grid, block, smem, s, g);

@@ -148,11 +148,17 @@ PipeCache& pipe_cache(int device) {
 struct PipeScratch {
     void *p_text = nullptr, *p_uncond = nullptr, *p_pert = nullptr, *coords = nullptr, *stats = nullptr;   // borrowed from PipeCache
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> dit_ev, gs_ev;
+    std::vector<hipEvent_t> step_ev;        // three per denoise step (start, after the forwards, after the update); every
+                                            // event is owned exactly once and pushed here the moment it exists
+    int new_event(hipEvent_t* out) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        step_ev.push_back(e); *out = e;
+        return LTX_OK;
+    }
     ~PipeScratch() {
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
-        for (auto& pr : dit_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-        for (auto& pr : gs_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto e : step_ev) (void)hipEventDestroy(e);
     }
 };
 }  // namespace
@@ -227,8 +233,7 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     for (int i = 0; i < N; ++i) {
         float tvals[8]; for (int b = 0; b < 8; ++b) tvals[b] = (float)ts[i];       // Tensor::full(t as f32, (b,))
         hipEvent_t e0, e1, e2;
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-        sc.dit_ev.emplace_back(e0, e1); sc.gs_ev.emplace_back(e1, e2);
+        LTX_TRY(sc.new_event(&e0)); LTX_TRY(sc.new_event(&e1)); LTX_TRY(sc.new_event(&e2));
         HIP_TRY(hipEventRecord(e0, s));
         if (do_cfg) LTX_TRY(ltx_dit_forward(dit, latents, neg_embeds, tvals, neg_mask, B, S, K, F, H, W, nullptr, coords, nullptr, LTX_F32, sc.p_uncond, s));
         LTX_TRY(ltx_dit_forward(dit, latents, prompt_embeds, tvals, prompt_mask, B, S, K, F, H, W, nullptr, coords, nullptr, LTX_F32, sc.p_text, s));
@@ -257,10 +262,45 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     HIP_TRY(hipEventRecord(sc.ev[2], s));
     HIP_TRY(hipStreamSynchronize(s));
     float dit_ms = 0, gs_ms = 0, t = 0;
-    for (auto& pr : sc.dit_ev) { HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second)); dit_ms += t; }
-    for (auto& pr : sc.gs_ev) { HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second)); gs_ms += t; }
+    for (size_t i = 0; i + 3 <= sc.step_ev.size(); i += 3) {
+        HIP_TRY(hipEventElapsedTime(&t, sc.step_ev[i], sc.step_ev[i + 1])); dit_ms += t;
+        HIP_TRY(hipEventElapsedTime(&t, sc.step_ev[i + 1], sc.step_ev[i + 2])); gs_ms += t;
+    }
     g_timing[0] = dit_ms; g_timing[1] = gs_ms;
     HIP_TRY(hipEventElapsedTime(&g_timing[2], sc.ev[1], sc.ev[2]));
     HIP_TRY(hipEventElapsedTime(&g_timing[3], sc.ev[0], sc.ev[2]));
+    return LTX_OK;
+}
+
+// ---- warm-up: everything a first call would otherwise do inside the caller's forward --------------------------------
+// Runs one DiT forward and one decode of the given geometry on scratch buffers: GEMM plans are measured (or taken from a
+// loaded plan file), workspaces are sized, code objects are loaded.  Afterwards calls of this geometry enqueue work only.
+extern "C" int ltx_warmup(ltx_dit* dit, ltx_vae* vae, int B, int F, int H, int W, int K, ltx_stream stream) {
+    if (B < 1 || B > 8 || F < 1 || H < 1 || W < 1 || K < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_warmup: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = F * H * W;
+    float tvals[8] = {500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f};
+    if (dit) {
+        ltx_dit_config dc; LTX_TRY(ltx_dit_get_config(dit, &dc));
+        struct Tmp { DevBuf b; ~Tmp() { b.release(); } void* p() const { return b.p; } int ensure(size_t n) { return b.ensure(n); } } x, enc, out;
+        LTX_TRY(x.ensure((size_t)B * S * dc.in_channels * sizeof(float)));
+        LTX_TRY(enc.ensure((size_t)B * K * dc.caption_channels * sizeof(float)));
+        LTX_TRY(out.ensure((size_t)B * S * dc.out_channels * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(x.p(), 0, (size_t)B * S * dc.in_channels * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(enc.p(), 0, (size_t)B * K * dc.caption_channels * sizeof(float), s));
+        LTX_TRY(ltx_dit_forward(dit, x.p(), enc.p(), tvals, nullptr, B, S, K, F, H, W, nullptr, nullptr, nullptr, LTX_F32, out.p(), s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (vae) {
+        ltx_vae_config vc; LTX_TRY(ltx_vae_get_config(vae, &vc));
+        const int To = (F - 1) * vc.temporal_compression_ratio + 1, Ho = H * vc.spatial_compression_ratio, Wo = W * vc.spatial_compression_ratio;
+        struct Tmp { DevBuf b; ~Tmp() { b.release(); } void* p() const { return b.p; } int ensure(size_t n) { return b.ensure(n); } } z, vid;
+        LTX_TRY(z.ensure((size_t)B * S * vc.latent_channels * sizeof(float)));
+        LTX_TRY(vid.ensure((size_t)B * 3 * To * Ho * Wo * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(z.p(), 0, (size_t)B * S * vc.latent_channels * sizeof(float), s));
+        LTX_TRY(ltx_vae_decode_tokens(vae, reinterpret_cast<const float*>(z.p()), nullptr, tvals, vc.timestep_conditioning ? tvals : nullptr, B, F, H, W, nullptr, 0,
+                                      reinterpret_cast<float*>(vid.p()), s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     return LTX_OK;
 }

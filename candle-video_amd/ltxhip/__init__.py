@@ -98,6 +98,7 @@ _SIGS = {
     "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
     "ltx_calculate_shift": [_i, _i, _i, _f, _f],
     "ltx_pcg32_randn": [C.c_uint64, C.c_uint64, _sz, _vp],
+    "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -170,6 +171,11 @@ def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
     return t.contiguous()
+
+
+def _expect(name: str, t: torch.Tensor, shape):
+    if tuple(t.shape) != tuple(shape):
+        raise LtxError(f"{name}: shape {tuple(t.shape)} does not match the call's geometry {tuple(shape)}")
 
 
 def _make_weights(weights: Dict[str, torch.Tensor]):
@@ -250,6 +256,7 @@ class LtxVideoTransformer3DModel:
         """keep the text-side projections (caption projection, cross-attention K/V) of repeated forwards with the same
         embeddings/mask pointers; LtxPipeline::call scopes it to one denoise loop."""
         _check(lib.ltx_dit_context_cache(self._h, int(enable)))
+        self._ctx_cache = bool(enable)
 
     def set_skip_block_list(self, blocks: Sequence[int]):
         arr = (C.c_int * max(len(blocks), 1))(*blocks)
@@ -271,6 +278,12 @@ class LtxVideoTransformer3DModel:
         if len(t) != B:
             raise LtxError(f"timestep must have {B} entries")
         m = _dev(encoder_attention_mask, torch.float32) if encoder_attention_mask is not None else None
+        if getattr(self, "_ctx_cache", False):
+            # the cache identifies a context by its device POINTERS: a converted / re-laid-out temporary is freed after this
+            # call and its address reused by the next one, which would hit the cache with another context's K/V
+            if e.data_ptr() != encoder_hidden_states.data_ptr() or (m is not None and m.data_ptr() != encoder_attention_mask.data_ptr()):
+                raise LtxError("context_cache(True) needs encoder_hidden_states / encoder_attention_mask that are already contiguous and of "
+                               "the dtype the call uses (hidden_states' dtype / float32): a temporary copy has no stable identity")
         vc = _dev(video_coords, torch.float32) if video_coords is not None else None
         slm = None
         if skip_layer_mask is not None:
@@ -616,7 +629,22 @@ class LtxPipeline:
         ne = _dev(negative_prompt_embeds, torch.float32) if negative_prompt_embeds is not None else None
         nm = _dev(negative_prompt_attention_mask, torch.float32) if negative_prompt_attention_mask is not None else None
         dn = _dev(decode_noise, torch.float32) if decode_noise is not None else None
+        if pe.dim() != 3 or lat.dim() != 3:
+            raise LtxError("latents must be [B, F*H*W, in_channels] and prompt_embeds [B, K, caption_channels]")
         B, K = pe.shape[0], pe.shape[1]
+        # latent geometry as LtxPipeline::call derives it (t2v_pipeline.rs:743-747), checked against every tensor handed over:
+        # the C entry takes raw pointers, a mismatch would be out-of-bounds device traffic
+        tr = self.vae.config.temporal_compression_ratio if self.vae is not None else 8
+        sr = self.vae.config.spatial_compression_ratio if self.vae is not None else 32
+        F, H, W = (args.num_frames - 1) // tr + 1, args.height // sr, args.width // sr
+        Cin = self.transformer.config.in_channels
+        _expect("latents", lat, (B, F * H * W, Cin))
+        _expect("prompt_embeds", pe, (B, K, self.transformer.config.caption_channels))
+        _expect("prompt_attention_mask", pm, (B, K))
+        if ne is not None: _expect("negative_prompt_embeds", ne, (B, K, self.transformer.config.caption_channels))
+        if nm is not None: _expect("negative_prompt_attention_mask", nm, (B, K))
+        if dn is not None: _expect("decode_noise", dn, (B, Cin, F, H, W))
+        if step_noise is not None: _expect("step_noise", step_noise, (args.num_inference_steps, B, F * H * W, Cin))
         p = PipelineParamsC()
         lib.ltx_pipeline_params_default(C.byref(p))
         p.height, p.width, p.num_frames, p.frame_rate = args.height, args.width, args.num_frames, args.frame_rate
@@ -648,7 +676,8 @@ class LtxPipeline:
         if not args.output_latent:
             if self.vae is None:
                 raise LtxError("decode requested but the pipeline has no VAE")
-            video = torch.empty(B, 3, args.num_frames, args.height, args.width, dtype=torch.float32, device=lat.device)
+            # the decoder's own output shape (vae.rs:2101-2136): (F-1)*tr+1 frames, which is num_frames only for tr*k+1
+            video = torch.empty(B, 3, (F - 1) * tr + 1, H * sr, W * sr, dtype=torch.float32, device=lat.device)
         _check(lib.ltx_pipeline_call(self.transformer._h, self.vae._h if self.vae is not None else None, C.byref(p),
                                      _ptr(lat), _ptr(pe), _ptr(pm), _ptr(ne), _ptr(nm), _ptr(dn), B, K,
                                      _ptr(video), _stream()))
@@ -656,6 +685,24 @@ class LtxPipeline:
         _check(lib.ltx_pipeline_last_timing(ms))
         self.last_timing_ms = tuple(ms)
         return lat, video
+
+
+# ------------------------------------------------------------------ start-up control (include/ltxhip.h)
+def warmup(transformer: Optional[LtxVideoTransformer3DModel], vae: Optional["AutoencoderKLLtxVideo"], B: int, F: int, H: int, W: int, K: int = 128):
+    """ltx_warmup: plan measurement / workspace sizing for the latent geometry (F, H, W), outside the first real call."""
+    _check(lib.ltx_warmup(transformer._h if transformer is not None else None, vae._h if vae is not None else None, B, F, H, W, K, _stream()))
+
+
+def set_autotune(enabled: bool):
+    _check(lib.ltx_set_autotune(int(enabled)))
+
+
+def plan_save(path: str):
+    _check(lib.ltx_plan_save(path.encode()))
+
+
+def plan_load(path: str):
+    _check(lib.ltx_plan_load(path.encode()))
 
 
 # ------------------------------------------------------------------ frame output (include/ltxhip_frames.h)

@@ -351,6 +351,13 @@ class ShardedLtxPipeline:
         spr = self.vae.config.spatial_compression_ratio if self.vae is not None else 32
         F, H, W = (args.num_frames - 1) // tsr + 1, args.height // spr, args.width // spr
         S, B = F * H * W, lat.shape[0]
+        K = pe.shape[1]
+        L._expect("latents", lat, (B, S, cfgd.in_channels))
+        L._expect("prompt_embeds", pe, (B, K, cfgd.caption_channels))
+        L._expect("prompt_attention_mask", pm, (B, K))
+        if ne is not None: L._expect("negative_prompt_embeds", ne, (B, K, cfgd.caption_channels))
+        if nm is not None: L._expect("negative_prompt_attention_mask", nm, (B, K))
+        if decode_noise is not None: L._expect("decode_noise", decode_noise, (B, cfgd.in_channels, F, H, W))
         if args.skip_block_list is not None:                           # permanent iff STG is off (:691-697)
             self.transformer.set_skip_block_list([] if do_stg else args.skip_block_list)
         N = args.num_inference_steps

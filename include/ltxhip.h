@@ -17,8 +17,11 @@
  *   - tensor pointers are DEVICE pointers unless a parameter says "host".
  *   - the caller owns all tensors it passes; the library owns weights + workspaces.
  *   - one handle = one device; a handle is not re-entrant (reference: `&mut self`, single stream).
- *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued on it, nothing blocks
- *     except workspace (re)allocation on a first/larger call.
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued on it.  What blocks: workspace
+ *     (re)allocation on a first/larger call and - unless ltx_warmup() / ltx_plan_load() / ltx_set_autotune(0) was
+ *     used - the one-time measurement of the candidate GEMM plans on the first call of each GEMM shape.
+ *   - results do not depend on the plans chosen (every plan of a shape sums K in the same order), so two processes
+ *     given the same inputs produce the same bits whether or not they share a plan file.
  *   - model dtype: LTX_BF16 is the production path (bf16 storage, f32 accumulate — the reference's
  *     GPU dtype, main.rs:226); LTX_F32 is the parity path (exact f32 MFMA, reference CPU dtype).
  */
@@ -192,6 +195,18 @@ int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
 /* per-stage wall time of the last ltx_pipeline_call on this thread, measured with hipEvents:
  * ms[0] = all DiT forwards, ms[1] = guidance+Euler, ms[2] = VAE decode (+denorm), ms[3] = total */
 int ltx_pipeline_last_timing(float ms[4]);
+
+/* ---- start-up control (no reference counterpart; speed only, never results) ----
+ * ltx_warmup: run one forward (B, F*H*W tokens, K text tokens) and one decode of that latent geometry on scratch buffers,
+ *   so that plan measurement, workspace sizing and code loading happen here and not inside the caller's first call.
+ *   Either handle may be NULL.  Blocks until done.
+ * ltx_set_autotune(0): never measure inside a call - shapes without a cached/loaded plan use the static cost model.
+ * ltx_plan_save / ltx_plan_load: the measured plans of this process as a text file ("M N K conv ntaps T H W plan" per
+ *   line); a loaded file makes a later process start with the same plans and without measuring. */
+int ltx_warmup(ltx_dit* dit, ltx_vae* vae, int B, int F, int H, int W, int K, ltx_stream stream);
+int ltx_set_autotune(int enabled);
+int ltx_plan_save(const char* path);
+int ltx_plan_load(const char* path);
 
 /* ---- optional measurement hooks (bench.py roofline object) ----
  * kinds: 0 linear GEMM, 1 conv3d implicit GEMM, 2 self-attention, 3 cross-attention, 4 row norms.

@@ -926,7 +926,7 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
                   neg_embeds: Optional[Tensor] = None, neg_mask: Optional[Tensor] = None,
                   decode_noise: Optional[Tensor] = None, dtype=torch.float32,
                   sched_cfg: SchedulerCfg = SchedulerCfg(), trajectory: Optional[list] = None,
-                  step_noise: Optional[Tensor] = None) -> Tensor:
+                  step_noise: Optional[Tensor] = None, timestep_cast: Optional[torch.dtype] = None) -> Tensor:
     """LtxPipeline::call (t2v_pipeline.rs:627-1073) with embeddings supplied
     (text encoder out of scope) and the decode noise supplied explicitly (the
     reference draws it from the device RNG, :1055)."""
@@ -950,7 +950,10 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
     L = dit_cfg.num_layers
 
     def fwd(emb, mask, t, slm=None):
-        return dit_forward(dit_p, dit_cfg, lat, emb, torch.full((b,), float(t)), mask, F_, H_, W_,
+        tt = torch.full((b,), float(t))
+        if timestep_cast is not None:     # test aid: the timestep as a `timestep_cast` model sees it (:1051), all else in `dtype`
+            tt = tt.to(timestep_cast).float()
+        return dit_forward(dit_p, dit_cfg, lat, emb, tt, mask, F_, H_, W_,
                            None, coords, slm, skip_perm, dtype)
 
     trajectory_idx: list = []

@@ -213,14 +213,66 @@ def pipeline_case():
               metadata={"source": "oracle/ltx_oracle.py pipeline_call", "args": repr(args)})
 
 
+C1 = dict(height=256, width=384, num_frames=25)           # BASELINE.json configs[0]
+C1_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232 (distilled)
+
+
+def c1_inputs():
+    """Synthetic inputs of BASELINE.md section 3 at C1 geometry; shared by the generator and tests/test_gpu_c1.py."""
+    F, H, W = 4, 8, 12
+    lat = O.pack_latents(O.Pcg32(42, 1442695040888963407).randn((1, 128, F, H, W)))
+    pe = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(42))
+    pm = torch.zeros(1, 128); pm[:, :32] = 1
+    noise = torch.randn(1, 128, F, H, W, generator=torch.Generator().manual_seed(44))
+    g = torch.Generator().manual_seed(45)
+    mean = torch.randn(128, generator=g) * 0.1
+    std = 1.0 + 0.1 * torch.randn(128, generator=g).abs()
+    return lat, pe, pm, noise, mean, std
+
+
+def c1_case():
+    """BASELINE config C1 in FULL: the 2B DiT (28 layers, D = 2048, 32 x 64 heads) and the full VAE decoder with seeded
+    synthetic weights (seeds 31 / 32, re-derived on the GPU box by O.synth_weights), distilled 7 steps + decode at
+    256x384x25 (t2v_pipeline.rs:627-1073, configs.rs:223-240), in f32 - and once more in f32 with the model seeing the
+    timesteps as a bf16 model does (ltx_transformer.rs:1051), the reference for the production bf16 mode.
+    Committed: final latents, the latents after the first step, a strided slice + moments of the video."""
+    import time
+    dcfg, vcfg = O.DitConfig(), O.VaeConfig()
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=31)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    lat, pe, pm, noise, mean, std = c1_inputs()
+    args = O.PipelineArgs(height=C1["height"], width=C1["width"], num_frames=C1["num_frames"], num_inference_steps=7, sigmas=C1_SIGMAS,
+                          guidance_scale=1.0, stg_scale=0.0, decode_timestep=0.05, decode_noise_scale=0.025)
+    out = {"dit_weights_checksum": weights_checksum(dw), "vae_weights_checksum": weights_checksum(vw)}
+    for tag, cast in (("f32", None), ("f32_bf16ts", torch.bfloat16)):
+        traj = []
+        t0 = time.time()
+        video = O.pipeline_call(dw, dcfg, vw, vcfg, mean, std, args, lat, pe, pm, None, None, noise, torch.float32, trajectory=traj,
+                                timestep_cast=cast)
+        dt = time.time() - t0
+        out[f"latents_{tag}"] = traj[-1]
+        out[f"latents_step1_{tag}"] = traj[0]
+        out[f"video_slice_{tag}"] = video[:, :, ::4, ::8, ::8]
+        out[f"video_moments_{tag}"] = torch.tensor([float(video.double().mean()), float(video.double().std()), float(video.double().abs().sum())], dtype=torch.float64)
+        out[f"oracle_seconds_{tag}"] = torch.tensor([dt], dtype=torch.float64)
+        print(f"C1 oracle {tag}: {dt:.1f} s, video mean {float(video.mean()):.2f} std {float(video.std()):.2f}", flush=True)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c1.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py pipeline_call at BASELINE C1 (full 2B DiT + VAE decoder, synthetic weights seeds 31/32)",
+                        "args": repr(args), "video_slice": "[:, :, ::4, ::8, ::8] of the [1,3,25,256,384] post-processed video"})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        c1_case()
+        sys.exit(0)
     ref_scripts()
     for n, s in DIT_CASES.items():
         dit_case(n, s)
     vae_case()
     ops_case()
     pipeline_case()
+    c1_case()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
