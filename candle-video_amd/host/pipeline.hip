@@ -84,6 +84,32 @@ extern "C" int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out
     return LTX_OK;
 }
 
+// the integer stream itself (deterministic_rng.rs:23-35): bit-exact by construction, pinned to the published PCG32 vectors
+extern "C" int ltx_pcg32_u32(uint64_t seed, uint64_t inc, size_t n, uint32_t* out) {
+    if (!out) LTX_FAIL(LTX_ERR_ARG, "ltx_pcg32_u32: null output");
+    Pcg32 r(seed, inc);
+    for (size_t i = 0; i < n; ++i) out[i] = r.next_u32();
+    return LTX_OK;
+}
+
+// ---- device memory for hosts that have no HIP bindings of their own (the Rust shim, rust/hip_backend.rs) ----
+extern "C" int ltx_device_alloc(size_t bytes, int device, void** out) {
+    if (!out) LTX_FAIL(LTX_ERR_ARG, "ltx_device_alloc: null output");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return LTX_OK;
+}
+extern "C" int ltx_device_free(void* p) { if (p) HIP_TRY(hipFree(p)); return LTX_OK; }
+extern "C" int ltx_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, ltx_stream stream) {
+    HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return LTX_OK;
+}
+extern "C" int ltx_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, ltx_stream stream) {
+    HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return LTX_OK;
+}
+extern "C" int ltx_stream_synchronize(ltx_stream stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return LTX_OK; }
+
 // video_coords (t2v_pipeline.rs:798-847): f' = clamp(8f-7, 0, 1000)/frame_rate ; h' = 32h ; w' = 32w
 extern "C" int ltx_build_video_coords(int F, int H, int W, int frame_rate, int ts_ratio, int sp_ratio, float* out) {
     if (!out || F < 1 || H < 1 || W < 1 || frame_rate < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_build_video_coords: bad argument");

@@ -98,6 +98,9 @@ _SIGS = {
     "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
     "ltx_calculate_shift": [_i, _i, _i, _f, _f],
     "ltx_pcg32_randn": [C.c_uint64, C.c_uint64, _sz, _vp],
+    "ltx_pcg32_u32": [C.c_uint64, C.c_uint64, _sz, _vp],
+    "ltx_device_alloc": [_sz, _i, _vp], "ltx_device_free": [_vp], "ltx_memcpy_h2d": [_vp, _vp, _sz, _vp], "ltx_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "ltx_stream_synchronize": [_vp],
     "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
@@ -122,6 +125,7 @@ _SIGS = {
     # include/ltxhip_frames.h
     "ltx_video_to_rgb8": [_vp, _i, _i, _i, _i, _vp, _vp], "ltx_write_png": [C.c_char_p, _vp, _i, _i],
     "ltx_save_frames_png": [_vp, _i, _i, _i, _i, C.c_char_p, _vp, _vp],
+    "ltx_write_gif": [C.c_char_p, _vp, _i, _i, _i, _i, _i], "ltx_save_video_gif": [_vp, _i, _i, _i, _i, C.c_char_p, _vp],
     # include/ltxhip_weights.h
     "ltx_weights_detect_format": [C.c_char_p], "ltx_weights_remap_key": [C.c_char_p, C.c_char_p, _sz],
     "ltx_weights_is_transformer_key": [C.c_char_p], "ltx_weights_is_vae_key": [C.c_char_p],
@@ -577,6 +581,14 @@ def pcg32_randn(seed: int, shape: Sequence[int], inc: int = 1442695040888963407)
     return out.reshape(*shape)
 
 
+def pcg32_u32(seed: int, n: int, inc: int = 1442695040888963407) -> torch.Tensor:
+    """first n outputs of Pcg32::new(seed, inc).next_u32() as int64 (exact)"""
+    import numpy as np
+    out = np.empty(n, dtype=np.uint32)
+    _check(lib.ltx_pcg32_u32(C.c_uint64(seed), C.c_uint64(inc), C.c_size_t(n), C.c_void_p(out.ctypes.data)))
+    return torch.from_numpy(out.astype(np.int64))
+
+
 def build_video_coords(F: int, H: int, W: int, frame_rate: int = 25, ts_ratio: int = 8, sp_ratio: int = 32) -> torch.Tensor:
     out = torch.empty(F * H * W, 3, dtype=torch.float32)
     _check(lib.ltx_build_video_coords(F, H, W, frame_rate, ts_ratio, sp_ratio, C.c_void_p(out.data_ptr())))
@@ -719,6 +731,19 @@ def write_png(path: str, rgb: torch.Tensor):
     """HOST u8 [H,W,3] -> PNG file."""
     t = rgb.detach().to("cpu", torch.uint8).contiguous()
     _check(lib.ltx_write_png(path.encode(), C.c_void_p(t.data_ptr()), t.shape[1], t.shape[0]))
+
+
+def write_gif(path: str, frames: torch.Tensor, delay_cs: int = 4, speed: int = 30):
+    """HOST u8 [N,H,W,3] -> animated GIF (main.rs:683-707: per-frame NeuQuant palette at `speed`, delay, infinite loop)."""
+    t = frames.detach().to("cpu", torch.uint8).contiguous()
+    _check(lib.ltx_write_gif(path.encode(), C.c_void_p(t.data_ptr()), t.shape[0], t.shape[2], t.shape[1], delay_cs, speed))
+
+
+def save_video_gif(video: torch.Tensor, path: str):
+    """The reference's default output: [B,3,F,H,W] f32 (0..255) on the device -> path (video.gif in main.rs:690)."""
+    v = _dev(video, torch.float32)
+    B, _, F, H, W = v.shape
+    _check(lib.ltx_save_video_gif(_ptr(v), B, F, H, W, path.encode(), _stream()))
 
 
 def save_frames_png(video: torch.Tensor, out_dir: str) -> int:

@@ -164,6 +164,8 @@ int ltx_sched_set_timesteps(const float* sigmas_in, int n, float mu, int use_mu,
 float ltx_calculate_shift(int seq_len, int base_seq_len, int max_seq_len, float base_shift, float max_shift);
 /* Pcg32::new(seed, inc).randn(n) (utils/deterministic_rng.rs:11-81) into HOST memory */
 int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out_host);
+/* the first n values of Pcg32::new(seed, inc).next_u32() (deterministic_rng.rs:23-35) into HOST memory: bit-exact */
+int ltx_pcg32_u32(uint64_t seed, uint64_t inc, size_t n, uint32_t* out_host);
 /* video_coords of LtxPipeline::call (t2v_pipeline.rs:798-847) into HOST memory [F*H*W, 3] */
 int ltx_build_video_coords(int F, int H, int W, int frame_rate, int ts_ratio, int sp_ratio, float* out_host);
 
@@ -195,6 +197,15 @@ int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
 /* per-stage wall time of the last ltx_pipeline_call on this thread, measured with hipEvents:
  * ms[0] = all DiT forwards, ms[1] = guidance+Euler, ms[2] = VAE decode (+denorm), ms[3] = total */
 int ltx_pipeline_last_timing(float ms[4]);
+
+/* ---- device memory for hosts without HIP bindings of their own (rust/hip_backend.rs keeps candle tensors on the CPU
+ * device and moves the few MB per step itself; candle has no ROCm backend).  Copies are enqueued on `stream` and are
+ * asynchronous with respect to the host for pinned memory only: call ltx_stream_synchronize before reading a d2h target. */
+int ltx_device_alloc(size_t bytes, int device, void** out);
+int ltx_device_free(void* p);
+int ltx_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, ltx_stream stream);
+int ltx_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, ltx_stream stream);
+int ltx_stream_synchronize(ltx_stream stream);
 
 /* ---- start-up control (no reference counterpart; speed only, never results) ----
  * ltx_warmup: run one forward (B, F*H*W tokens, K text tokens) and one decode of that latent geometry on scratch buffers,

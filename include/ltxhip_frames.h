@@ -16,6 +16,13 @@ int ltx_write_png(const char* path, const uint8_t* rgb, int width, int height);
  * the directory is created if missing).  Returns the number of files written in *n_written (may be NULL). */
 int ltx_save_frames_png(const float* video, int B, int F, int H, int W, const char* dir, int* n_written, ltx_stream stream);
 
+/* The reference's DEFAULT output (main.rs:683-707): an animated GIF - every frame quantised to a local 256-colour palette
+ * (NeuQuant, sampling factor `speed` 1..30; the reference uses 30), LZW-coded, `delay_cs` centiseconds per frame (the
+ * reference: 4), looping forever, no global palette.  rgb_frames: HOST u8 [n_frames, height, width, 3]. */
+int ltx_write_gif(const char* path, const uint8_t* rgb_frames, int n_frames, int width, int height, int delay_cs, int speed);
+/* main.rs:653-707 in one call: convert on the device, copy to the host, write the GIF (speed 30, delay 4; frames in b*F+f order). */
+int ltx_save_video_gif(const float* video, int B, int F, int H, int W, const char* path, ltx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,20 @@ def test_pcg32_and_coords_match_oracle(hip, golden):
     assert torch.equal(hip.pack_latents(b), O.pack_latents(b))
 
 
+def test_pcg32_integer_stream_is_bit_exact(hip, golden):
+    """The u32 stream against (1) the PCG paper's demo vector (pcg32 seed 42, sequence 54), (2) the reference's own
+    scripts/verify_rng.py Pcg32 executed unmodified (tests/golden/ref_rng.safetensors), (3) the oracle; and the
+    Gaussians built on it against the same script (its own bar: 1e-6)."""
+    assert hip.pcg32_u32(42, 6, inc=54).tolist() == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    r = golden("ref_rng.safetensors")
+    assert hip.pcg32_u32(42, 6, inc=54).tolist() == r["u32_seed42_seq54"].tolist()
+    assert torch.equal(hip.pcg32_u32(42, 64), r["u32"])
+    o = O.Pcg32(42, 1442695040888963407)
+    assert [o.next_u32() for _ in range(64)] == r["u32"].tolist()
+    assert (hip.pcg32_randn(42, (257,)) - r["randn"]).abs().max() < 1e-6
+    assert (O.Pcg32(42, 1442695040888963407).randn((257,)) - r["randn"]).abs().max() < 1e-6
+
+
 def test_errors_surface_as_exceptions_without_gpu(hip):
     with pytest.raises(hip.LtxError, match="bad argument"):
         hip.FlowMatchEulerDiscreteScheduler().set_timesteps([], 0.0)

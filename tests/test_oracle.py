@@ -230,3 +230,12 @@ def test_stochastic_sampling_step_formula():
     sched2.set_timesteps(sigmas=[0.5], mu=0.0)
     out2 = sched2.step(v, float(sched2.timesteps[0]), x, nz)
     assert torch.allclose(out2, x - float(sched2.sigmas[0]) * v, atol=1e-6)
+
+
+def test_oracle_pinned_by_three_more_reference_scripts(golden):
+    """scripts/test_unpatchify.py, verify_rng.py, test_rope_rotation.py executed unmodified (tools/gen_fixtures.py ref)."""
+    u = golden("ref_unpatchify.safetensors")
+    assert torch.equal(O.unpatchify(u["x"], 4, 1), u["out"])                         # vae.rs:1626-1654 axis order, exact
+    r = golden("ref_rope_rotation.safetensors")
+    got = O.apply_rotary_emb(r["x"], r["cos"], r["sin"])
+    assert (got - r["out"]).abs().max() < 1e-6 and (got - r["out_diffusers"]).abs().max() < 1e-6

@@ -60,6 +60,41 @@ def ref_scripts():
                   metadata={"source": "reference scripts/gen_latent_norm_ref.py (seed 42), executed unmodified; tensors sliced [:, :, :3, :4, :6]"})
 
 
+def ref_scripts_imported():
+    """Three more of the reference's torch-only scripts, executed UNMODIFIED from /root/reference (runpy, in a temp cwd) and
+    asked for outputs of their own functions:
+      scripts/test_unpatchify.py   - the decoder's permute(0,1,5,2,6,4,7,3) on its index-coded tensor (module globals x, out)
+      scripts/verify_rng.py        - its Pcg32 class: u32 stream and randn for the seed / increment of main.rs:568
+      scripts/test_rope_rotation.py - rust_apply_rotary_emb_linear ("what Rust apply_rotary_emb_linear should do")"""
+    import contextlib, io, runpy
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.getcwd(); os.chdir(td)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                up = runpy.run_path(os.path.join(REF, "scripts", "test_unpatchify.py"), run_name="ref_unpatchify")
+                rng = runpy.run_path(os.path.join(REF, "scripts", "verify_rng.py"), run_name="ref_rng")
+                rope = runpy.run_path(os.path.join(REF, "scripts", "test_rope_rotation.py"), run_name="ref_rope")
+        finally:
+            os.chdir(cwd)
+    save_file({"x": c(up["x"]), "out": c(up["out"])}, os.path.join(GOLD, "ref_unpatchify.safetensors"),
+              metadata={"source": "reference scripts/test_unpatchify.py executed unmodified: its x [1,48,2,4,6] and python_unpatchify(x, 4, 1)"})
+    P = rng["Pcg32"]
+    r = P(42, 1442695040888963407)
+    u32 = torch.tensor([r.next_u32() for _ in range(64)], dtype=torch.int64)
+    r2 = P(42, 54)                                          # the PCG paper's demo seed / sequence
+    u32_demo = torch.tensor([r2.next_u32() for _ in range(6)], dtype=torch.int64)
+    randn = P(42, 1442695040888963407).randn((257,))       # odd count: the dropped second Box-Muller value
+    save_file({"u32": u32, "u32_seed42_seq54": u32_demo, "randn": c(randn.float())}, os.path.join(GOLD, "ref_rng.safetensors"),
+              metadata={"source": "reference scripts/verify_rng.py executed unmodified: its Pcg32(42, 1442695040888963407) u32 stream / randn((257,)); Pcg32(42, 54) first six"})
+    g = torch.Generator().manual_seed(9)
+    # tables as the model builds them: one (cos, sin) per channel PAIR, repeat_interleave 2 (ltx_transformer.rs:436-524)
+    x = torch.randn(1, 24, 96, generator=g)
+    cs = (torch.rand(1, 24, 48, generator=g) * 2 - 1).repeat_interleave(2, -1); sn = (torch.rand(1, 24, 48, generator=g) * 2 - 1).repeat_interleave(2, -1)
+    save_file({"x": x, "cos": cs, "sin": sn, "out": c(rope["rust_apply_rotary_emb_linear"](x, (cs, sn))),
+               "out_diffusers": c(rope["diffusers_apply_rotary_emb"](x, (cs, sn)))}, os.path.join(GOLD, "ref_rope_rotation.safetensors"),
+              metadata={"source": "reference scripts/test_rope_rotation.py executed unmodified: rust_apply_rotary_emb_linear / diffusers_apply_rotary_emb on seeded inputs"})
+
+
 DIT_CASES = {
     # tests/verify_dit_parity.rs:24-39 config (2 layers, 2 heads x 16, dims 32), smaller grid, no mask, rope scale (1,1,1)
     "A": dict(cfg=dict(in_channels=32, out_channels=32, num_attention_heads=2, attention_head_dim=16, cross_attention_dim=32,
@@ -267,7 +302,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":
+        ref_scripts(); ref_scripts_imported()
+        sys.exit(0)
     ref_scripts()
+    ref_scripts_imported()
     for n, s in DIT_CASES.items():
         dit_case(n, s)
     vae_case()
