@@ -126,6 +126,8 @@ _SIGS = {
     "ltx_video_to_rgb8": [_vp, _i, _i, _i, _i, _vp, _vp], "ltx_write_png": [C.c_char_p, _vp, _i, _i],
     "ltx_save_frames_png": [_vp, _i, _i, _i, _i, C.c_char_p, _vp, _vp],
     "ltx_write_gif": [C.c_char_p, _vp, _i, _i, _i, _i, _i], "ltx_save_video_gif": [_vp, _i, _i, _i, _i, C.c_char_p, _vp],
+    # include/ltxhip_presets.h
+    "ltx_preset_count": [], "ltx_preset_name": [_i], "ltx_preset_get": [C.c_char_p, _vp], "ltx_pipeline_params_from_preset": [_vp, _vp],
     # include/ltxhip_weights.h
     "ltx_weights_detect_format": [C.c_char_p], "ltx_weights_remap_key": [C.c_char_p, C.c_char_p, _sz],
     "ltx_weights_is_transformer_key": [C.c_char_p], "ltx_weights_is_vae_key": [C.c_char_p],
@@ -697,6 +699,85 @@ class LtxPipeline:
         _check(lib.ltx_pipeline_last_timing(ms))
         self.last_timing_ms = tuple(ms)
         return lat, video
+
+
+# ------------------------------------------------------------------ version presets (include/ltxhip_presets.h; configs.rs:50-283)
+class PresetC(C.Structure):
+    _fields_ = [("version", C.c_char_p), ("guidance_scale", C.c_float), ("num_inference_steps", C.c_int), ("stg_scale", C.c_float),
+                ("rescaling_scale", C.c_float), ("stochastic_sampling", C.c_int), ("skip_block_list", C.c_int * 8), ("n_skip_blocks", C.c_int),
+                ("timesteps", C.c_float * 16), ("n_timesteps", C.c_int), ("decode_timestep", C.c_float), ("has_decode_timestep", C.c_int),
+                ("decode_noise_scale", C.c_float), ("has_decode_noise_scale", C.c_int), ("transformer", DitConfigC), ("vae", VaeConfigC),
+                ("vae_encoder_block_out_channels", C.c_int * 5), ("vae_encoder_layers_per_block", C.c_int * 5),
+                ("num_train_timesteps", C.c_int), ("shift", C.c_float), ("use_dynamic_shifting", C.c_int), ("base_shift", C.c_float),
+                ("max_shift", C.c_float), ("base_image_seq_len", C.c_int), ("max_image_seq_len", C.c_int), ("shift_terminal", C.c_float),
+                ("has_shift_terminal", C.c_int), ("time_shift_exponential", C.c_int)]
+
+
+@dataclass
+class LTXVFullConfig:
+    """get_config_by_version's result (configs.rs:40-46): inference settings + the three component configs."""
+    version: str
+    guidance_scale: float
+    num_inference_steps: int
+    stg_scale: float
+    rescaling_scale: float
+    stochastic_sampling: bool
+    skip_block_list: List[int]
+    timesteps: Optional[List[float]]
+    decode_timestep: Optional[float]
+    decode_noise_scale: Optional[float]
+    transformer: "LtxVideoTransformer3DModelConfig"
+    vae: "AutoencoderKLLtxVideoConfig"
+    vae_encoder_block_out_channels: List[int]
+    vae_encoder_layers_per_block: List[int]
+    scheduler: Dict[str, object]
+
+    def pipeline_call(self, height: int, width: int, num_frames: int, **over) -> "PipelineCall":
+        """the PipelineCall examples/ltx-video/main.rs:585-646 builds from this preset (ltx_pipeline_params_from_preset)"""
+        kw = dict(height=height, width=width, num_frames=num_frames,
+                  num_inference_steps=len(self.timesteps) if self.timesteps else self.num_inference_steps, sigmas=self.timesteps,
+                  guidance_scale=self.guidance_scale, guidance_rescale=self.rescaling_scale, stg_scale=self.stg_scale,
+                  skip_block_list=list(self.skip_block_list) or None,
+                  decode_timestep=self.decode_timestep if self.decode_timestep is not None else 0.0,
+                  stochastic_sampling=self.stochastic_sampling)
+        kw["decode_noise_scale"] = self.decode_noise_scale if self.decode_noise_scale is not None else kw["decode_timestep"]
+        kw.update(over)
+        return PipelineCall(**kw)
+
+
+def preset_names() -> List[str]:
+    lib.ltx_preset_name.restype = C.c_char_p
+    return [lib.ltx_preset_name(i).decode() for i in range(lib.ltx_preset_count())]
+
+
+def get_config_by_version(version: str) -> LTXVFullConfig:
+    """configs.rs:50-70 (aliases; unknown strings fall back to 0.9.5)."""
+    p = PresetC()
+    _check(lib.ltx_preset_get(version.encode(), C.byref(p)))
+    t, v = p.transformer, p.vae
+    tcfg = LtxVideoTransformer3DModelConfig(in_channels=t.in_channels, out_channels=t.out_channels, patch_size=t.patch_size, patch_size_t=t.patch_size_t,
+                                            num_attention_heads=t.num_attention_heads, attention_head_dim=t.attention_head_dim,
+                                            cross_attention_dim=t.cross_attention_dim, num_layers=t.num_layers, norm_eps=t.norm_eps,
+                                            caption_channels=t.caption_channels)
+    nb = v.n_blocks
+    vcfg = AutoencoderKLLtxVideoConfig(latent_channels=v.latent_channels, out_channels=v.out_channels,
+                                       decoder_block_out_channels=tuple(v.decoder_block_out_channels[:nb]),
+                                       decoder_layers_per_block=tuple(v.decoder_layers_per_block[:nb + 1]),
+                                       decoder_upsample_factor=tuple(v.decoder_upsample_factor[:nb]), patch_size=v.patch_size,
+                                       patch_size_t=v.patch_size_t, timestep_conditioning=bool(v.timestep_conditioning),
+                                       decoder_causal=bool(v.decoder_causal), scaling_factor=v.scaling_factor,
+                                       spatial_compression_ratio=v.spatial_compression_ratio, temporal_compression_ratio=v.temporal_compression_ratio)
+    return LTXVFullConfig(
+        version=p.version.decode(), guidance_scale=p.guidance_scale, num_inference_steps=p.num_inference_steps, stg_scale=p.stg_scale,
+        rescaling_scale=p.rescaling_scale, stochastic_sampling=bool(p.stochastic_sampling), skip_block_list=list(p.skip_block_list[:p.n_skip_blocks]),
+        timesteps=[float(x) for x in p.timesteps[:p.n_timesteps]] if p.n_timesteps else None,
+        decode_timestep=float(p.decode_timestep) if p.has_decode_timestep else None,
+        decode_noise_scale=float(p.decode_noise_scale) if p.has_decode_noise_scale else None,
+        transformer=tcfg, vae=vcfg, vae_encoder_block_out_channels=list(p.vae_encoder_block_out_channels),
+        vae_encoder_layers_per_block=list(p.vae_encoder_layers_per_block),
+        scheduler=dict(num_train_timesteps=p.num_train_timesteps, shift=p.shift, use_dynamic_shifting=bool(p.use_dynamic_shifting),
+                       base_shift=p.base_shift, max_shift=p.max_shift, base_image_seq_len=p.base_image_seq_len, max_image_seq_len=p.max_image_seq_len,
+                       shift_terminal=p.shift_terminal if p.has_shift_terminal else None, time_shift_type="exponential" if p.time_shift_exponential else "linear"))
 
 
 # ------------------------------------------------------------------ start-up control (include/ltxhip.h)

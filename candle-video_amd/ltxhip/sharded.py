@@ -9,8 +9,10 @@ places where `LtxPipeline::call` naturally partitions get one:
     predictions ([B,S,128] f32 = 2.56 MB per rank at 2B/4992 tokens, latency-bound next to a ~25 ms forward) and
     every rank applies the fused guidance + Euler update redundantly, so latents stay replicated without a broadcast.
   * VAE tiles (`vae.rs:2225-2290, 2358-2434`): the reference's tiled decode is a serial loop over independent
-    `decoder.forward` calls.  Leaf tiles are dealt round-robin to the ranks, decoded, all-gathered (padded to the
-    largest tile) and blended/cropped in exactly the reference order on every rank: numerics = the tiled path.
+    `decoder.forward` calls.  With framewise decoding whole TEMPORAL tiles go to ranks in contiguous ranges: spatial
+    blends stay local, one strip of <= 8 frames goes to the next rank for the temporal blend, and only finished
+    frames are all-gathered (each frame travels once).  Spatial-only tiling (four leaves at C2) deals the leaves
+    round-robin and gathers them whole.  Either way blends run in exactly the reference order: numerics = the tiled path.
 
 Guidance-free presets (the distilled headline config) have ONE forward per step and do not shard: those run as
 independent replicas, one video per GPU (`bench.py --gpus N`), with no data-path collective.
@@ -238,14 +240,112 @@ def assemble(tl: Tiling, F: int, H: int, W: int, leaves: Sequence[torch.Tensor],
     return torch.cat(out, 2)[:, :, :num_sample_frames]
 
 
+def temporal_tile_owner(n_tiles: int, team_size: int) -> List[range]:
+    """Contiguous, balanced deal of temporal tiles to team ranks (the first n_tiles % team_size ranks get one more)."""
+    base, extra = divmod(n_tiles, team_size)
+    out, start = [], 0
+    for r in range(team_size):
+        n = base + (1 if r < extra else 0)
+        out.append(range(start, start + n))
+        start += n
+    return out
+
+
+def _decode_temporal_sharded(decode_tile, blend, z: torch.Tensor, tl: Tiling, team: Team) -> torch.Tensor:
+    """Framewise (temporal) tiled decode, vae.rs:2358-2434, with TEMPORAL tiles as the unit of distribution.
+
+    A temporal tile (its spatial leaves, their spatial blend, vae.rs:2225-2290) is decoded and assembled on ONE rank.  The
+    only value that crosses tiles is `blend_t(row[i-1], row[i])`, which reads the last `blend` frames of the previous
+    tile as decoded (not as blended - no chain): ranks own CONTIGUOUS ranges of temporal tiles, so a rank receives one
+    strip of <= blend frames from its predecessor (point to point) and finishes its kept frames locally.  What is
+    gathered is the finished video, each frame once: 458 MB of f32 at C2 instead of the 2.8 GB of whole padded tiles
+    the round-robin leaf deal moved (SURVEY 8e "crop before send").  Bit-identical to the serial loop."""
+    B, _, F, H, W = z.shape
+    tr = tl.temporal_compression_ratio
+    ranges = _temporal_ranges(tl, F)
+    nT = len(ranges)
+    owner = temporal_tile_owner(nT, team.size)
+    mine = owner[team.rank]
+    blend_t = max(tl.tile_sample_min_num_frames - tl.tile_sample_stride_num_frames, 0)
+    stride_t = tl.tile_sample_stride_num_frames
+    num_sample_frames = (F - 1) * tr + 1
+    tiled = _temporal_is_tiled(tl, H, W)
+    row = {}
+    for li in mine:                                                   # vae.rs:2382-2408
+        t0, t1 = ranges[li]
+        if tiled:
+            grid = _spatial_crops(tl, t0, t1, H, W)
+            dec = _assemble_spatial(tl, [[decode_tile(z[:, :, c[0]:c[1], c[2]:c[3], c[4]:c[5]].contiguous()).float() for c in r_] for r_ in grid], H, W, blend)
+        else:
+            dec = decode_tile(z[:, :, t0:t1].contiguous()).float()
+        if li > 0 and dec.shape[2] > 1:
+            dec = dec[:, :, :-1]
+        row[li] = dec
+    # strip exchange: the tail of my last tile goes to the rank that owns the next tile
+    def frames_of(li):                                                # decoded length of temporal tile li (after the drop)
+        n = (ranges[li][1] - ranges[li][0] - 1) * tr + 1
+        return n - 1 if (li > 0 and n > 1) else n
+    prev_tail = None
+    if team.size > 1:
+        ops_ = []
+        first, last = (mine[0], mine[-1]) if len(mine) else (None, None)
+        send_to = next((r for r in range(team.rank + 1, team.size) if len(owner[r])), None) if len(mine) and last < nT - 1 else None
+        recv_from = next((r for r in range(team.rank - 1, -1, -1) if len(owner[r])), None) if len(mine) and first > 0 else None
+        Hs, Ws = H * tl.spatial_compression_ratio, W * tl.spatial_compression_ratio
+        if send_to is not None:
+            e = min(blend_t, row[last].shape[2])
+            tail = row[last][:, :, row[last].shape[2] - e:].contiguous()
+            ops_.append(dist.P2POp(dist.isend, tail, _global_rank(team, send_to), group=team.group))
+        if recv_from is not None:
+            e = min(blend_t, frames_of(first - 1))
+            prev_tail = torch.empty(B, 3, e, Hs, Ws, dtype=torch.float32, device=z.device)
+            ops_.append(dist.P2POp(dist.irecv, prev_tail, _global_rank(team, recv_from), group=team.group))
+        if ops_:
+            for w_ in dist.batch_isend_irecv(ops_):
+                w_.wait()
+    out = []
+    for li in mine:                                                   # vae.rs:2410-2434
+        tile = row[li]
+        if li > 0:
+            a = row[li - 1] if (li - 1) in row else prev_tail        # the blend reads only a's last min(len, blend) frames
+            bl = blend(a, tile, blend_t, 2)
+            out.append(bl[:, :, :min(stride_t, bl.shape[2])])
+        else:
+            out.append(tile[:, :, :min(stride_t + 1, tile.shape[2])])
+    Hs, Ws = H * tl.spatial_compression_ratio, W * tl.spatial_compression_ratio
+    chunk = torch.cat(out, 2) if out else torch.empty(B, 3, 0, Hs, Ws, dtype=torch.float32, device=z.device)
+    if team.size == 1:
+        return chunk[:, :, :num_sample_frames]
+    # kept frames per rank are known everywhere: gather equal-size (padded) chunks, one frame travels once
+    kept = []
+    for r in range(team.size):
+        n = 0
+        for li in owner[r]:
+            n += min(stride_t + 1, frames_of(li)) if li == 0 else min(stride_t, frames_of(li))
+        kept.append(n)
+    mx = max(kept)
+    send = torch.zeros(B, 3, mx, Hs, Ws, dtype=torch.float32, device=z.device)
+    send[:, :, :chunk.shape[2]] = chunk
+    gathered = _all_gather(send, team)
+    return torch.cat([gathered[r][:, :, :kept[r]] for r in range(team.size)], 2)[:, :, :num_sample_frames]
+
+
+def _global_rank(team: Team, team_rank: int) -> int:
+    return dist.get_global_rank(team.group, team_rank) if team.group is not None else team_rank
+
+
 def decode_tile_sharded(decode_tile: Callable[[torch.Tensor], torch.Tensor], blend, z: torch.Tensor, tl: Tiling,
                         team: Team) -> torch.Tensor:
-    """Tiled VAE decode with the leaf tiles dealt round-robin over the team.
+    """Tiled VAE decode split over the team.
 
     decode_tile(z_crop [B,C,t,h,w]) -> f32 [B,3,8t-7,32h,32w] (one `decoder.forward`);
     blend(a, b, extent, dim) -> b blended against a (blend_t/v/h, vae.rs:1927-2006).
-    Every rank returns the full video; the result is bit-identical to the single-rank tiled decode."""
+    Every rank returns the full video; the result is bit-identical to the single-rank tiled decode.
+    Framewise decoding (the 52-leaf case at C2) distributes whole temporal tiles and gathers only finished frames
+    (_decode_temporal_sharded); the spatial-only mode has four leaves at C2, which are dealt round-robin and gathered whole."""
     _, _, F, H, W = z.shape
+    if _mode(tl, F, H, W) == "temporal":
+        return _decode_temporal_sharded(decode_tile, blend, z, tl, team)
     crops = leaf_crops(tl, F, H, W)
     r, tr = tl.spatial_compression_ratio, tl.temporal_compression_ratio
     shapes = [((c[1] - c[0] - 1) * tr + 1, (c[3] - c[2]) * r, (c[5] - c[4]) * r) for c in crops]

@@ -28,7 +28,7 @@ def _declared(header):
 
 def test_library_exports_every_declared_symbol(hip):
     lib = ctypes.CDLL(os.path.join(ROOT, "candle-video_amd", "libltxhip.so"))
-    names = _declared("ltxhip.h") + _declared("ltxhip_ops.h") + _declared("ltxhip_weights.h") + _declared("ltxhip_t5.h") + _declared("ltxhip_frames.h")
+    names = _declared("ltxhip.h") + _declared("ltxhip_ops.h") + _declared("ltxhip_weights.h") + _declared("ltxhip_t5.h") + _declared("ltxhip_frames.h") + _declared("ltxhip_presets.h")
     assert len(names) >= 45
     for n in names:
         assert hasattr(lib, n), f"libltxhip.so does not export {n}"

@@ -135,10 +135,10 @@ def _tile_worker(rank, world, port, framewise, q):
     out = S.decode_tile_sharded(dec, O._blend, z, tl, team)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, out, len(n), len(S.leaf_crops(tl, *z.shape[2:]))))
+    q.put((rank, out, len(n), len(S.leaf_crops(tl, *z.shape[2:])), [tuple(r) for r in S.temporal_tile_owner(len(S._temporal_ranges(tl, z.shape[2])), world)]))
 
 
-@pytest.mark.parametrize("world,framewise", [(2, 0), (2, 1), (3, 1)])
+@pytest.mark.parametrize("world,framewise", [(2, 0), (2, 1), (3, 1), (5, 1)])
 def test_vae_tiles_sharded_match_single_process_tiled_decode(world, framewise):
     O, cfg, w, z, temb = _vae_problem()
     nthreads = torch.get_num_threads()
@@ -149,9 +149,12 @@ def test_vae_tiles_sharded_match_single_process_tiled_decode(world, framewise):
         torch.set_num_threads(nthreads)
     res = _spawn(_tile_worker, world, (framewise,))
     total = 0
-    for rank, out, ndec, nleaf in res:
+    for rank, out, ndec, nleaf, owner in res:
         assert out.shape == want.shape and torch.equal(out, want), f"rank {rank}"
-        assert ndec in (nleaf // world, nleaf // world + 1)
+        if framewise:            # whole temporal tiles per rank (contiguous ranges), 9 spatial leaves each here
+            assert ndec == 9 * len(owner[rank]) and max(len(o) for o in owner) - min(len(o) for o in owner) <= 1
+        else:
+            assert ndec in (nleaf // world, nleaf // world + 1)
         total += ndec
     assert total == res[0][3]                                   # every leaf tile decoded exactly once across the team
 
@@ -168,3 +171,5 @@ def test_leaf_crops_cover_reference_tile_loops():
     assert S.leaf_crops(tl2, 13, 16, 24) == [(0, 13, 0, 16, 0, 24)]
     assert S.guidance_branches(1.0, 0.0) == ["text"] and S.guidance_branches(3.0, 1.0) == ["uncond", "text", "perturbed"]
     assert S.branch_owner(3, 2) == (2, [[0, 1], [2]]) and S.branch_owner(2, 3) == (1, [[0], [1], []])
+    assert [list(r) for r in S.temporal_tile_owner(13, 8)] == [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10], [11], [12]]
+    assert [list(r) for r in S.temporal_tile_owner(2, 3)] == [[0], [1], []]
