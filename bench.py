@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — end-to-end LTX-Video-2B hot path on MI355X (BASELINE.json metric).
+"""bench.py - end-to-end LTX-Video hot path on MI355X (BASELINE.json metric).
 
-A "step" = one full pass of the hot path over one batch of synthetic input: the distilled
-0.9.8-2B preset's 7 denoise steps (one DiT forward + Euler step each) + denormalize/noise-mix +
-3D-VAE decode + postprocess, producing one 512x768x97 video (configs[1] of BASELINE.json).
-`value` = frames/sec over the whole job; inputs (latents, embeddings, weights) are resident in
-HBM before the timed region.  Multi-GPU: the distilled preset has one forward per step, so the
-denoise loop does not shard ("replicas only") — every rank generates its own video,
-no data-path collective, scaling = weak.
+A "step" = one full pass of the hot path over one batch of synthetic input: the preset's denoise steps (DiT forwards +
+guidance/Euler update each) + denormalize / noise mix + 3D-VAE decode + postprocess, producing one video.
+`value` = frames/sec over the whole job with inputs (latents, embeddings, weights) resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2] [--no-cpu-baseline]
+Workloads (--config; the default c2 is the one BASELINE.json's metric is quoted on, BASELINE.json configs[1]):
+  c1  0.9.8-2B-distilled 256x384x25, 7 steps                   replicas (one video per GPU)
+  c2  0.9.8-2B-distilled 512x768x97, 7 steps, untiled decode   replicas, scaling weak          <- headline
+  c3  0.9.5 (CFG 3.0 + STG 1.0 + rescale 0.7, 40 steps, skip block 19; configs.rs:167-184) 512x768x97:
+      1 GPU: three forwards per step in sequence; N >= 3: teams of three ranks, one guidance branch each, one all-gather of
+      the f32 predictions per step (ltxhip/sharded.py); value = teams x frames / time
+  c4  c2 with the reference's TILED framewise decode (vae.rs:2225-2434; 52 decoder calls), one video per TEAM of all N ranks:
+      denoise replicated, temporal tiles split over the team (strip exchange + one gather of finished frames); scaling strong
+  c5  0.9.8-13B-distilled 704x1216x161, 7 steps (head_dim 128, 48 layers; skip block 42)
+Multi-GPU: the distilled presets run ONE forward per step, so their denoise loop does not shard ("replicas only",
+SURVEY 8e): every rank generates its own video, no data-path collective, scaling weak.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1..c5] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-"""
+`--gpus N` without a torchrun environment starts the N ranks itself (child process, before any GPU call)."""
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (os.path.join(ROOT, "candle-video_amd"), os.path.join(ROOT, "oracle")):
+for _p in (os.path.join(ROOT, "candle-video_amd"),):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -29,11 +39,22 @@ import torch  # noqa: E402
 
 CONFIGS = {
     # BASELINE.json configs[1]: LTX-Video-0.9.8-2B-distilled bf16, 512x768, 97 frames
-    "c2": dict(height=512, width=768, num_frames=97, name="LTX-Video-0.9.8-2B-distilled 512x768x97, 7 steps (configs.rs:223-240), untiled VAE decode"),
+    "c2": dict(preset="0.9.8-2b-distilled", height=512, width=768, num_frames=97, mode="replicas",
+               name="LTX-Video-0.9.8-2B-distilled 512x768x97, 7 steps (configs.rs:223-240), untiled VAE decode"),
     # BASELINE.json configs[0]: 256x384, 25 frames (the reference's CPU-runnable case)
-    "c1": dict(height=256, width=384, num_frames=25, name="LTX-Video-0.9.8-2B-distilled 256x384x25, 7 steps"),
+    "c1": dict(preset="0.9.8-2b-distilled", height=256, width=384, num_frames=25, mode="replicas",
+               name="LTX-Video-0.9.8-2B-distilled 256x384x25, 7 steps"),
+    # BASELINE.json configs[2]: 0.9.5, 40-step flow matching with CFG + STG
+    "c3": dict(preset="0.9.5", height=512, width=768, num_frames=97, mode="branches",
+               name="LTX-Video-0.9.5 512x768x97, 40 steps, CFG 3.0 + STG 1.0 (skip block 19) + rescale 0.7 (configs.rs:167-184)"),
+    # BASELINE.json configs[3]: C2 with the tiled framewise decode split over the node
+    "c4": dict(preset="0.9.8-2b-distilled", height=512, width=768, num_frames=97, mode="tiles",
+               name="LTX-Video-0.9.8-2B-distilled 512x768x97, 7 steps, TILED framewise VAE decode (vae.rs:2225-2434) split over the team"),
+    # BASELINE.json configs[4]: 13B
+    "c5": dict(preset="0.9.8-13b-distilled", height=704, width=1216, num_frames=161, mode="replicas",
+               name="LTX-Video-0.9.8-13B-distilled 704x1216x161, 7 steps, skip block 42 (configs.rs:264-282), untiled VAE decode"),
 }
-DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232
+DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232 (the CPU baseline's C1 run)
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -79,37 +100,63 @@ def synth_on_device(shapes, dev, seed):
     return out
 
 
-def cpu_baseline(cfg):
-    """The oracle (a port of the reference's CPU path: f32, un-fused, materialised attention scores,
-    conv3d as per-frame sums of conv2d) timed on this box's host cores on a bounded sample of the SAME
-    workload (10-20 s of CPU work), scaled to frames/sec: DiT forwards with 1 and 3 of the 28 layers at the full token
-    count (fixed part + 28 x per-layer time, x7 steps) and a VAE decode of a latent crop (scaled by conv FLOPs)."""
+def cpu_baseline(cfg, fl_job):
+    """The oracle (a port of the reference's CPU path: f32, un-fused, materialised attention scores, conv3d as per-frame
+    sums of conv2d) timed on this box's host cores, two ways:
+      * MEASURED: BASELINE config C1 in full and end to end - the 28-layer 2B DiT x 7 distilled steps + the full VAE decode
+        at 256x384x25 (12.8 TFLOP; the run tests/golden/oracle_c1.safetensors comes from), ~20-40 s;
+      * for the workload `value` is quoted on: the same oracle on a bounded SAMPLE of it (1- and 3-layer forwards at the
+        full token count + a VAE latent crop scaled by conv FLOPs, ~12 s) - an estimate, labelled as one.
+    `value` is the estimate for the benchmarked workload (same unit as the headline); the measured C1 rate stands beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ltx_oracle as O
     # 16 threads: torch's small-conv2d / bmm paths get SLOWER with hundreds of threads (measured: the VAE crop
     # took 488 s with 256 threads vs ~1 s with 8); `cores` reports what was actually used.
     ncores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
+    # ---- measured: C1 end to end
+    dcfg, vcfg = O.DitConfig(), O.VaeConfig()
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=31)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    F1, H1, W1 = 4, 8, 12
+    lat = O.pack_latents(O.Pcg32(42, 1442695040888963407).randn((1, 128, F1, H1, W1)))
+    pe = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(42)); pm = torch.zeros(1, 128); pm[:, :32] = 1
+    noise = torch.randn(1, 128, F1, H1, W1, generator=torch.Generator().manual_seed(44))
+    args = O.PipelineArgs(height=256, width=384, num_frames=25, num_inference_steps=7, sigmas=DISTILLED_SIGMAS, guidance_scale=1.0, stg_scale=0.0,
+                          decode_timestep=0.05, decode_noise_scale=0.025)
+    O.dit_forward({k: v for k, v in dw.items()}, dcfg, lat[:, :8], pe[:, :8], torch.tensor([1000.0]), pm[:, :8], 1, 2, 4, None, O.build_video_coords(1, 1, 2, 4))   # thread pool / allocator warm-up
+    t0 = time.time()
+    video = O.pipeline_call(dw, dcfg, vw, vcfg, torch.zeros(128), torch.ones(128), args, lat, pe, pm, None, None, noise, torch.float32)
+    t_c1 = time.time() - t0
+    assert torch.isfinite(video).all()
+    fl_c1 = 7 * dit_flops(F1 * H1 * W1) + vae_flops(F1, H1, W1)
+    c1 = {"workload": CONFIGS["c1"]["name"] + " + VAE decode, full run", "seconds": t_c1, "frames_per_sec": 25.0 / t_c1, "tflop": fl_c1 / 1e12,
+          "cpu_tflops": fl_c1 / t_c1 / 1e12}
+    del dw
+    if cfg["preset"] != "0.9.8-2b-distilled" or cfg["mode"] != "replicas" or cfg["num_frames"] == 25:
+        # c1 itself: the measured run IS the baseline; other workloads: scaled by algorithmic FLOPs at the measured CPU rate
+        total = fl_job / (fl_c1 / t_c1)
+        return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "c1_measured": c1,
+                "sample": f"oracle f32 on host: C1 run in full ({t_c1:.1f} s, {fl_c1 / t_c1 / 1e12:.2f} TFLOP/s); this workload's {fl_job / 1e12:.0f} TFLOP "
+                          f"at that rate = {total:.0f} s per video" + (" (measured, not scaled)" if cfg["num_frames"] == 25 else " (estimate)")}
+    # ---- estimate for C2 from a bounded sample of C2 itself
     F, H, W = (cfg["num_frames"] - 1) // 8 + 1, cfg["height"] // 32, cfg["width"] // 32
     S = F * H * W
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, S, 128, generator=g); enc = torch.randn(1, 128, 4096, generator=g)
     mask = torch.zeros(1, 128); mask[:, :32] = 1
     coords = O.build_video_coords(1, F, H, W)
-    # DiT forward = fixed part (projections, embeddings, RoPE) + 28 x layer: time a 1-layer and a 3-layer model
     t_n = {}
-    for nl in (0, 1, 3):                       # 0 = untimed warm-up of the thread pool / allocator with the 1-layer model
-        dcfg = O.DitConfig(num_layers=max(nl, 1))
-        dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=1)
+    for nl in (1, 3):                          # DiT forward = fixed part + 28 x layer: time a 1-layer and a 3-layer model
+        d2 = O.DitConfig(num_layers=nl)
+        w2 = O.synth_weights(O.dit_weight_shapes(d2), seed=1)
         t0 = time.time()
-        O.dit_forward(dw, dcfg, x, enc, torch.tensor([1000.0]), mask, F, H, W, None, coords)
-        if nl:
-            t_n[nl] = time.time() - t0
-        del dw
+        O.dit_forward(w2, d2, x, enc, torch.tensor([1000.0]), mask, F, H, W, None, coords)
+        t_n[nl] = time.time() - t0
+        del w2
     t_layer = max((t_n[3] - t_n[1]) / 2.0, 1e-6)
     t_fixed = max(t_n[1] - t_layer, 0.0)
     t_fwd = t_fixed + 28 * t_layer
-    vcfg = O.VaeConfig()
-    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=2)
     cf, chh, cww = 2, 3, 4
     z = torch.randn(1, 128, cf, chh, cww, generator=g)
     t0 = time.time()
@@ -117,17 +164,27 @@ def cpu_baseline(cfg):
     t_crop = time.time() - t0
     t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
     total = 7 * t_fwd + t_vae
-    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port",
-            "sample": f"oracle f32 on host ({t_n[1] + t_n[3] + t_crop:.1f}s of CPU work): DiT forwards with 1 and 3 of 28 layers at S={S} "
-                      f"({t_n[1]:.2f}s, {t_n[3]:.2f}s -> {t_fixed:.2f}s + 28 x {t_layer:.2f}s per forward, x7 steps) + VAE decode of a "
-                      f"{cf}x{chh}x{cww} latent crop ({t_crop:.2f}s, scaled by conv FLOPs to {F}x{H}x{W}); estimated {total:.1f}s per video"}
+    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "c1_measured": c1,
+            "sample": f"ESTIMATE for this workload from a bounded sample of it ({t_n[1] + t_n[3] + t_crop:.1f} s of CPU work): oracle f32 DiT forwards with 1 and 3 of 28 "
+                      f"layers at S={S} ({t_n[1]:.2f} s, {t_n[3]:.2f} s -> {t_fixed:.2f} s + 28 x {t_layer:.2f} s per forward, x7 steps) + VAE decode of a {cf}x{chh}x{cww} "
+                      f"latent crop ({t_crop:.2f} s, scaled by conv FLOPs to {F}x{H}x{W}) = {total:.0f} s per video; MEASURED beside it: C1 in full, {t_c1:.1f} s "
+                      f"= {25.0 / t_c1:.3f} frames/s"}
 
 
-def rank_plan(world, rank):
-    """Replicas-only sharding (one forward per step in the distilled preset, so the denoise
-    loop does not partition): every rank owns an independent video; seeds differ per rank."""
-    return {"latent_seed": 42 + rank, "dit_weight_seed": 1 + rank, "vae_weight_seed": 100 + rank, "videos_per_step": 1,
-            "total_videos_per_step": world}
+def rank_plan(world, rank, mode="replicas"):
+    """Who makes which video.  replicas: every rank its own (seeds differ per rank; SURVEY 8e: one forward per step does
+    not partition).  branches: teams of three consecutive ranks share one video (one guidance branch each).  tiles: the
+    whole world is one team (denoise replicated, decode tiles split)."""
+    if mode == "branches":
+        team = 3 if world >= 3 else 1
+        teams = max(world // team, 1)
+        return {"team_size": team, "team": rank // team, "videos_per_step": 1, "total_videos_per_step": teams,
+                "latent_seed": 42 + rank // team, "dit_weight_seed": 1, "vae_weight_seed": 100, "idle": rank >= teams * team}
+    if mode == "tiles":
+        return {"team_size": world, "team": 0, "videos_per_step": 1, "total_videos_per_step": 1, "latent_seed": 42, "dit_weight_seed": 1,
+                "vae_weight_seed": 100, "idle": False}
+    return {"team_size": 1, "team": rank, "latent_seed": 42 + rank, "dit_weight_seed": 1 + rank, "vae_weight_seed": 100 + rank, "videos_per_step": 1,
+            "total_videos_per_step": world, "idle": False}
 
 
 def reduce_elapsed(elapsed, dist, device):
@@ -139,8 +196,8 @@ def reduce_elapsed(elapsed, dist, device):
     return float(t.item())
 
 
-def job_fps(world, steps, frames, elapsed):
-    return world * steps * frames / elapsed
+def job_fps(videos_per_step, steps, frames, elapsed):
+    return videos_per_step * steps * frames / elapsed
 
 
 def pmc_traffic_bytes(cls):
@@ -160,6 +217,16 @@ def pmc_traffic_bytes(cls):
     return best if best else (None, None)
 
 
+def spawn_ranks(n, argv):
+    """`--gpus N` outside torchrun: start the N ranks as a CHILD (torch.distributed.run) before this process touches the
+    GPU, and leave with its exit code (never exec after GPU initialisation)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,9 +237,13 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing pass")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -183,37 +254,49 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import ltxhip
-    import ltx_oracle as O
+    from ltxhip import schema, sharded
 
     cfg = CONFIGS[a.config]
+    pre = ltxhip.get_config_by_version(cfg["preset"])
     F, H, W = (cfg["num_frames"] - 1) // 8 + 1, cfg["height"] // 32, cfg["width"] // 32
     S = F * H * W
-    dcfg = O.DitConfig()
-    plan = rank_plan(world, rank)
-    dit = ltxhip.LtxVideoTransformer3DModel(ltxhip.LtxVideoTransformer3DModelConfig(), synth_on_device(O.dit_weight_shapes(dcfg), dev, plan["dit_weight_seed"]), torch.bfloat16, local)
-    vw = {"decoder." + k: v for k, v in synth_on_device(O.vae_decoder_weight_shapes(O.VaeConfig()), dev, plan["vae_weight_seed"]).items()}
-    vae = ltxhip.AutoencoderKLLtxVideo(ltxhip.AutoencoderKLLtxVideoConfig(), vw, torch.bfloat16, local)
+    plan = rank_plan(world, rank, cfg["mode"])
+    dit = ltxhip.LtxVideoTransformer3DModel(pre.transformer, synth_on_device(schema.dit_weight_shapes(pre.transformer), dev, plan["dit_weight_seed"]), torch.bfloat16, local)
+    vw = {"decoder." + k: v for k, v in synth_on_device(schema.vae_decoder_weight_shapes(pre.vae), dev, plan["vae_weight_seed"]).items()}
+    vae = ltxhip.AutoencoderKLLtxVideo(pre.vae, vw, torch.bfloat16, local)
     del vw
     torch.cuda.empty_cache()
-    pipe = ltxhip.LtxPipeline(dit, vae)
-    # synthetic inputs per BASELINE.md §3: PCG32 latents seed 42, embeddings N(0,1) seed 42, mask 32 ones, noise seed 44
+    if cfg["mode"] == "tiles":                                     # the reference's tiled framewise decode (main.rs --vae-tiling)
+        vae.use_tiling = vae.use_framewise_decoding = True
+    # synthetic inputs per BASELINE.md section 3: PCG32 latents seed 42, embeddings N(0,1) seeds 42/43, masks 32/8 ones, noise seed 44
     lat = ltxhip.pack_latents(ltxhip.pcg32_randn(plan["latent_seed"], (1, 128, F, H, W))).to(dev)
-    g = torch.Generator().manual_seed(42)
-    pe = torch.randn(1, 128, 4096, generator=g).to(dev)
+    pe = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(42)).to(dev)
     pm = torch.zeros(1, 128); pm[:, :32] = 1; pm = pm.to(dev)
+    ne = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(43)).to(dev)
+    nm = torch.zeros(1, 128); nm[:, :8] = 1; nm = nm.to(dev)
     noise = torch.randn(1, 128, F, H, W, generator=torch.Generator().manual_seed(44)).to(dev)
-    call = ltxhip.PipelineCall(height=cfg["height"], width=cfg["width"], num_frames=cfg["num_frames"], num_inference_steps=7,
-                               sigmas=DISTILLED_SIGMAS, guidance_scale=1.0, stg_scale=0.0, skip_block_list=[], postprocess=True)
+    call = pre.pipeline_call(cfg["height"], cfg["width"], cfg["num_frames"], postprocess=True)
+    n_steps = call.num_inference_steps
+    fwd_per_step = (1 if call.guidance_scale > 1.0 else 0) + 1 + (1 if call.stg_scale > 0.0 else 0)
+    cfg_args = (ne, nm) if call.guidance_scale > 1.0 else (None, None)
 
-    def step():
-        return pipe.call(call, lat, pe, pm, decode_noise=noise)
+    team = sharded.Team()
+    if dist is not None and plan["team_size"] > 1:
+        team = sharded.make_teams(plan["team_size"])
+    if plan["team_size"] > 1:
+        pipe = sharded.ShardedLtxPipeline(dit, vae, team)
+        step = lambda: pipe.call(call, lat, pe, pm, cfg_args[0], cfg_args[1], decode_noise=noise)
+    else:
+        pipe = ltxhip.LtxPipeline(dit, vae)
+        step = lambda: pipe.call(call, lat, pe, pm, cfg_args[0], cfg_args[1], decode_noise=noise)
 
-    # Initialisation, not a warm-up step: the first call of every GEMM shape measures the candidate plans (tile / kernel)
-    # and caches the winner, and the models size their workspaces.  Done once here so that the W warm-up steps and the K
-    # timed steps below all run the steady-state path even when the driver passes --warmup 0.
-    step()
-    for _ in range(a.warmup):
+    # Initialisation, not a warm-up step: plan measurement, workspace sizing and code loading happen here (ltx_warmup), so
+    # that the W warm-up steps and the K timed steps all run the steady-state path even when the driver passes --warmup 0.
+    ltxhip.warmup(dit, vae if cfg["mode"] != "tiles" else None, 1, F, H, W, 128)
+    if not plan["idle"]:
         step()
+        for _ in range(a.warmup):
+            step()
 
     def barrier():
         if dist is not None:
@@ -223,33 +306,45 @@ def main():
     barrier()
     t0 = time.perf_counter()
     dit_ms = vae_ms = 0.0
+    video = None
     for _ in range(a.steps):
+        if plan["idle"]:
+            continue
         _, video = step()
-        dit_ms += pipe.last_timing_ms[0]; vae_ms += pipe.last_timing_ms[2]
+        if plan["team_size"] == 1:
+            dit_ms += pipe.last_timing_ms[0]; vae_ms += pipe.last_timing_ms[2]
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = reduce_elapsed(elapsed, dist, dev)
-    assert torch.isfinite(video).all()
+    assert plan["idle"] or torch.isfinite(video).all()
 
     out = None
     if rank == 0:
-        fps = job_fps(world, a.steps, cfg["num_frames"], elapsed)
-        fl_dit, fl_vae = dit_flops(S), vae_flops(F, H, W)
+        fps = job_fps(plan["total_videos_per_step"], a.steps, cfg["num_frames"], elapsed)
+        D = pre.transformer.num_attention_heads * pre.transformer.attention_head_dim
+        fl_dit = dit_flops(S, D=D, L=pre.transformer.num_layers - (len(call.skip_block_list or []) if call.stg_scale <= 0 else 0))
+        fl_vae = vae_flops(F, H, W)
+        fl_job = n_steps * fwd_per_step * fl_dit + fl_vae
+        par = {"replicas": f"replicas x{world} (no data-path collective)",
+               "branches": f"{plan['total_videos_per_step']} team(s) of {plan['team_size']}: one guidance branch per rank, all-gather of f32 predictions per step" if plan["team_size"] > 1 else "1 GPU: guidance branches in sequence",
+               "tiles": f"one team of {world}: denoise replicated, temporal VAE tiles split (strip exchange + gather of finished frames)" if world > 1 else "1 GPU: tiled framewise decode, 52 decoder calls"}[cfg["mode"]]
         out = {"metric": "frames/sec end-to-end LTX-Video-2B 512x768x97; DiT step ms; VAE decode ms", "value": fps, "unit": "frames/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * elapsed / a.steps,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": cfg["name"], "latent_grid": [F, H, W], "tokens": S, "text_tokens": 128,
-                          "denoise_steps": 7, "parallelism": f"replicas x{world} (no data-path collective)"},
-               "dit_step_ms": dit_ms / (7 * a.steps), "vae_decode_ms": vae_ms / a.steps,
-               "dit_tflops": fl_dit / (dit_ms / (7 * a.steps) * 1e-3) / 1e12, "vae_tflops": fl_vae / (vae_ms / a.steps * 1e-3) / 1e12,
-               "algorithmic_tflop_per_video": (7 * fl_dit + fl_vae) / 1e12}
-        if not a.no_prof:
+               "higher_is_better": True, "scaling": "strong" if cfg["mode"] == "tiles" else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": cfg["name"], "preset": pre.version, "latent_grid": [F, H, W], "tokens": S, "text_tokens": 128,
+                          "denoise_steps": n_steps, "forwards_per_step": fwd_per_step, "parallelism": par},
+               "algorithmic_tflop_per_video": fl_job / 1e12, "job_tflops": fl_job * plan["total_videos_per_step"] * a.steps / elapsed / 1e12}
+        if plan["team_size"] == 1:
+            out.update({"dit_step_ms": dit_ms / (n_steps * a.steps), "vae_decode_ms": vae_ms / a.steps,
+                        "dit_tflops": fwd_per_step * fl_dit / (dit_ms / (n_steps * a.steps) * 1e-3) / 1e12, "vae_tflops": fl_vae / (vae_ms / a.steps * 1e-3) / 1e12})
+        if not a.no_prof and plan["team_size"] == 1:
             # separate, untimed pass with hipEvents around every launch of the heavy kernel classes (on their stream)
             ltxhip.prof_enable(True)
             step()
+            attn_name = "attn_q64_kernel (self attention, 64 queries per wave)" if pre.transformer.attention_head_dim == 64 else "attn_bf16_kernel<128> (self attention)"
             kinds = {"gemm_big_kernel/gemm_p8_kernel<bf16> (Linear GEMMs, tile per shape)": 0,
-                     "gemm_big_kernel/gemm_p8_kernel<bf16,conv> (conv3d implicit GEMM)": 1, "attn_pipe64_kernel (self attention)": 2,
-                     "attn_bf16_kernel<64> (cross attention)": 3, "rownorm_kernel<bf16>": 4}
+                     "gemm_big_kernel/gemm_p8_kernel/conv_halo_kernel<bf16,conv> (conv3d implicit GEMM)": 1, attn_name: 2,
+                     "attn_cross64_kernel (cross attention)": 3, "rownorm_kernel<bf16>": 4}
             per = {}
             for name, k in kinds.items():
                 ms, work, cnt = ltxhip.prof_report(k)
@@ -263,13 +358,15 @@ def main():
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: HBM + Infinity Cache)",
                                "traffic_source": tsrc, "avg_launch_ms": per[dom]["avg_ms"],
                                "launches_per_video": per[dom]["launches"]}
+            out["roofline_self_attention"] = {"kernel": attn_name, "bound": "mfma", "achieved": per[attn_name]["TFLOP/s"], "peak": PEAK_BF16_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": per[attn_name]["TFLOP/s"] / PEAK_BF16_TFLOPS, "avg_launch_ms": per[attn_name]["avg_ms"],
+                                              "launches_per_video": per[attn_name]["launches"]}
             out["kernels"] = per
-            Fh, Hh, Wh = F, H, W
-            out["gemm_plans"] = {"qkv": ltxhip.ops.gemm_plan(S, 6144, 2048), "attn_out/q2/out2": ltxhip.ops.gemm_plan(S, 2048, 2048),
-                                 "ff1": ltxhip.ops.gemm_plan(S, 8192, 2048), "ff2": ltxhip.ops.gemm_plan(S, 2048, 8192),
-                                 "vae_mid_1024": ltxhip.ops.gemm_plan(Fh * Hh * Wh, 1024, 1024, 1, 27, Fh, Hh, Wh)}
+            out["gemm_plans"] = {"qkv": ltxhip.ops.gemm_plan(S, 3 * D, D), "attn_out/q2/out2": ltxhip.ops.gemm_plan(S, D, D),
+                                 "ff1": ltxhip.ops.gemm_plan(S, 4 * D, D), "ff2": ltxhip.ops.gemm_plan(S, D, 4 * D),
+                                 "vae_mid_1024": ltxhip.ops.gemm_plan(F * H * W, 1024, 1024, 1, 27, F, H, W)}
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, fl_job)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -41,3 +41,22 @@ def test_two_rank_replica_plan_and_timing():
         assert elapsed == 2.0                      # MAX over ranks
         assert seeds == [42, 43] and total == 2    # disjoint work, no overlap
         assert abs(fps - 2 * 3 * 97 / 2.0) < 1e-9  # whole-job aggregate
+
+
+def test_rank_plans_for_sharded_workloads():
+    """bench.py --config c3 (teams of three guidance-branch ranks) and c4 (the world as one tile team): who owns which
+    video, how many videos a step makes, which ranks idle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    p = [bench.rank_plan(8, r, "branches") for r in range(8)]
+    assert [x["team"] for x in p[:6]] == [0, 0, 0, 1, 1, 1] and all(x["team_size"] == 3 and x["total_videos_per_step"] == 2 for x in p)
+    assert [x["idle"] for x in p] == [False] * 6 + [True] * 2 and p[0]["latent_seed"] != p[3]["latent_seed"] and p[0]["latent_seed"] == p[2]["latent_seed"]
+    assert p[0]["dit_weight_seed"] == p[5]["dit_weight_seed"]                     # a team shares one model
+    one = bench.rank_plan(1, 0, "branches")
+    assert one["team_size"] == 1 and one["total_videos_per_step"] == 1 and not one["idle"]
+    t = [bench.rank_plan(4, r, "tiles") for r in range(4)]
+    assert all(x["team_size"] == 4 and x["total_videos_per_step"] == 1 and x["latent_seed"] == 42 and not x["idle"] for x in t)
+    assert set(bench.CONFIGS) == {"c1", "c2", "c3", "c4", "c5"} and bench.CONFIGS["c2"]["num_frames"] == 97
+    # algorithmic FLOPs of SURVEY 8d: 22.35 TFLOP per C2 forward, 48.4 per decode, 204.8 per video
+    assert abs(bench.dit_flops(4992) / 1e12 - 22.35) < 0.05 and abs(bench.vae_flops(13, 16, 24) / 1e12 - 48.4) < 0.1
