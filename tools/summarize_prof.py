@@ -5,7 +5,10 @@ Only the LAST video period of the profiled run is summarised: periods are delimi
 VAE decode (decode of video n-1 + denoise loop of video n = one video's worth of launches), so warm-up work (first-call
 GEMM plan measurement, workspace allocation) never enters the numbers.
 
-usage: summarize_prof.py <stats_dir> <out_prefix> [--pmc FETCH_SIZE=<dir> --pmc WRITE_SIZE=<dir>]"""
+usage: summarize_prof.py <stats_dir> <out_prefix> [--pmc FETCH_SIZE=<dir> --pmc WRITE_SIZE=<dir>] [--sq <dir>]
+  --sq <dir>: a pass with SQ / GRBM counters (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY,
+  SQ_WAIT_ANY, GRBM_GUI_ACTIVE ...): per kernel class, the per-launch average of every counter and the derived MFMA utilisation
+  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the clock = GRBM_GUI_ACTIVE / 8 / launch duration."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -36,7 +39,7 @@ def classify(n):
         return "conv3d implicit GEMM" if "Lb1" in n else "linear GEMM"
     if "attn_cross64_kernel" in n:
         return "attention (cross / generic)"
-    if "attn_pipe64_kernel" in n:
+    if "attn_pipe64_kernel" in n or "attn_q64_kernel" in n:
         return "attention (self, q-prescaled)"
     if "attn_bf16_kernel" in n:
         return "attention (self, q-prescaled)" if len(a) > 1 and a[1] == "true" else "attention (cross / generic)"
@@ -57,9 +60,12 @@ def main():
     stats_dir, out = sys.argv[1], sys.argv[2]
     pmc = {}
     a = sys.argv[3:]
+    sq_dir = None
     for i, x in enumerate(a):
         if x == "--pmc":
             k, d = a[i + 1].split("="); pmc[k] = d
+        if x == "--sq":
+            sq_dir = a[i + 1]
     f = glob.glob(os.path.join(stats_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     win, ok = last_video(rows, "Kernel_Name")
@@ -88,6 +94,36 @@ def main():
             c = classify(r["Kernel_Name"]); acc[c][0] += float(r["Counter_Value"]); acc[c][1] += 1
         # FETCH_SIZE / WRITE_SIZE are reported in KiB (MI355X_MICROARCH.md, HBM/rocprofv3 section); gfx950: double FETCH_SIZE
         summary.setdefault("pmc", {})[name] = {k: {"per_launch_MB_raw": v[0] * 1024 / max(v[1], 1) / 1e6, "launches": v[1]} for k, v in acc.items()}
+    if sq_dir:
+        fs = glob.glob(os.path.join(sq_dir, "**", "*counter_collection.csv"), recursive=True)
+        if fs:
+            rows_sq = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
+            # one row per (dispatch, counter): window by dispatch order using the delimiter kernel
+            disp = {}
+            for r in rows_sq:
+                disp.setdefault(int(r["Dispatch_Id"]), {"Kernel_Name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+                if "Start_Timestamp" in r and r.get("Start_Timestamp"):
+                    disp[int(r["Dispatch_Id"])]["dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            dl = [dict(v, Dispatch_Id=k) for k, v in sorted(disp.items())]
+            win_sq, _ = last_video(dl, "Kernel_Name")
+            acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+            for r in win_sq:
+                c = classify(r["Kernel_Name"]); cnt[c] += 1
+                for k, v in r.items():
+                    if k not in ("Kernel_Name", "Dispatch_Id"):
+                        acc[c][k] += v
+            sq = {}
+            for c in acc:
+                d = {k: v / cnt[c] for k, v in acc[c].items()}
+                d["launches"] = cnt[c]
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+                    d["mfma_busy_frac_of_real_cycles"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                if d.get("dur_ns", 0) > 0 and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+                    d["clock_GHz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["dur_ns"]
+                    if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+                        d["mfma_busy_frac_of_2.4GHz_peak"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (d["dur_ns"] * 2.4)
+                sq[c] = d
+            summary["sq"] = sq
     open(out + ".json", "w").write(json.dumps(summary, indent=1))
     md = (f"# rocprofv3 --kernel-trace summary ({os.path.basename(out)}) — {summary['window']}\n\n"
           f"kernel busy time {tot/1e6:.1f} ms over a wall span of {span/1e6:.1f} ms, {len(win)} launches\n\n" + "\n".join(lines) +
@@ -97,6 +133,14 @@ def main():
         md += "\n## PMC (raw counter value x 1024 B, per launch; FETCH_SIZE must be doubled on gfx950)\n\n"
         for name, d in summary["pmc"].items():
             md += f"### {name}\n\n" + "\n".join(f"- {k}: {v['per_launch_MB_raw']:.1f} MB/launch over {v['launches']} launches" for k, v in sorted(d.items(), key=lambda kv: -kv[1]['per_launch_MB_raw'])) + "\n\n"
+    if "sq" in summary:
+        md += "\n## SQ / GRBM counters per launch (separate pass) and MFMA utilisation\n\n"
+        for c, d in sorted(summary["sq"].items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["launches"]):
+            if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0:
+                continue
+            md += (f"- {c} ({d['launches']} launches): MFMA busy {100 * d.get('mfma_busy_frac_of_real_cycles', 0):.1f} % of real SIMD cycles"
+                   + (f", {100 * d['mfma_busy_frac_of_2.4GHz_peak']:.1f} % of the 2.4 GHz peak, clock {d['clock_GHz']:.2f} GHz" if "clock_GHz" in d else "")
+                   + "; " + ", ".join(f"{k} {v:.3g}" for k, v in sorted(d.items()) if k.startswith(("SQ_", "GRBM_"))) + "\n")
     open(out + ".md", "w").write(md)
     print(md)
 
