@@ -187,7 +187,8 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     void* tok = nullptr;
     ltx_prof_begin(g.conv ? LTX_PROF_CONV : LTX_PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * (g.conv ? g.ntaps : 1), s, &tok);
     int rc;
-    if (ltx_gemm_big_eligible(g, dtype)) rc = ltx_launch_gemm_big(g, epi, s);
+    if (ltx_gemm_asm_eligible(g, dtype, epi)) rc = ltx_launch_gemm_asm(g, epi, s);
+    else if (ltx_gemm_big_eligible(g, dtype)) rc = ltx_launch_gemm_big(g, epi, s);
     else if (dtype == LTX_DT_BF16) rc = g.conv ? launch_t<bf16_t, true>(g, epi, s) : launch_t<bf16_t, false>(g, epi, s);
     else rc = g.conv ? launch_t<float, true>(g, epi, s) : launch_t<float, false>(g, epi, s);
     ltx_prof_end(tok, s);

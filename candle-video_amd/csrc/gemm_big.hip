@@ -733,6 +733,10 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
 
 // tuning/diagnostic aid: name of the plan cached for a shape ("" if none)
 const char* ltx_gemm_plan_name(int M, int N, int K, int conv, int ntaps, int T, int H, int W) {
+    if (!conv) {                                                   // shapes the asm family serves (by shape, not by plan)
+        GemmArgs g; g.M = M; g.N = N; g.K = K; g.lda = K;
+        if (ltx_gemm_asm_eligible(g, LTX_DT_BF16, EPI_BIAS)) return ltx_gemm_asm_tile_name(ltx_gemm_asm_pick_tile(M, N));
+    }
     PlanKey key; memset(&key, 0, sizeof(key));
     key.M = M; key.N = N; key.K = K; key.conv = conv;
     if (conv) { key.ntaps = ntaps; key.T = T; key.H = H; key.W = W; }

@@ -51,6 +51,12 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
 // large-tile LDS-DMA bf16 variant (gemm_big.hip); ltx_launch_gemm dispatches to it when eligible
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype);
 int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
+int ltx_gemm_split_factor(const GemmArgs& g);   // gemm_big.hip: K-ranges a small-output shape is cut into (shape only)
+// gemm_asm.hip: one-wave-per-SIMD kernels with a generated asm K loop; eligibility is a function of the shape only
+bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi);
+int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s);
+int ltx_gemm_asm_pick_tile(int M, int N);
+const char* ltx_gemm_asm_tile_name(int i);
 int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table
 int ltx_gemm_p8_choice(const GemmArgs& g);  // gemm_p8.hip: phase-interleaved 256-row kernel; returns BN (256/128) or 0
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s);

@@ -1,0 +1,44 @@
+"""GPU suite: the opt-in one-wave-per-SIMD GEMM (csrc/gemm_asm.hip, LTX_GEMM_ASM=1) against the shipped gemm_big tiles.
+
+Both accumulate bf16 products in f32 in ascending k; the MFMA shapes differ (32x32x16 vs 16x16x32).  The matrix core's
+accumulation is a k-ordered chain, so the two families are bit-identical - which is also why every gemm_big / gemm_p8
+/ conv_halo plan of a shape gives the same bits (tests/test_gpu_determinism.py).  The bar here is exact equality."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    assert torch.cuda.is_available()
+    return ltxhip
+
+
+@pytest.mark.parametrize("tile", ["asm256x256", "asm320x256", "asm160x256"])
+@pytest.mark.parametrize("M,N,K,epi", [(4992, 2048, 2048, 0), (4992, 6144, 2048, 1), (3001, 4104, 192, 0), (4992, 2048, 8192, 3)])
+def test_asm_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == 3 else None
+    old = {k: os.environ.get(k) for k in ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE")}
+    try:
+        os.environ.pop("LTX_GEMM_ASM", None); os.environ.pop("LTX_GEMM_ASM_TILE", None)
+        ref = hip.ops.linear(x, w, b, epi=epi, resid=resid)
+        os.environ["LTX_GEMM_ASM"] = "1"; os.environ["LTX_GEMM_ASM_TILE"] = tile
+        got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    ref32 = (x.float() @ w.float().t() + b.float())
+    if epi == 0: assert (got.float() - ref32).norm() / ref32.norm() < 3e-3      # and it is a GEMM, not two equal wrongs
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))

@@ -67,7 +67,7 @@ def _branch_worker(rank, world, port, team_size, q):
     out = S.denoise_branch_sharded(fwd, gstep, lat.clone(), S.guidance_branches(gs, stg), list(sched.sigmas), ts, team)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, out, sorted(set(calls)), len(calls), team.index, team.rank, team.size))
+    q.put((rank, out.numpy(), sorted(set(calls)), len(calls), team.index, team.rank, team.size))
 
 
 def _spawn(target, world, extra):
@@ -77,7 +77,8 @@ def _spawn(target, world, extra):
     procs = [ctx.Process(target=target, args=(r, world, port) + extra + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    # tensors travel as numpy arrays (pickled by value): a torch tensor in a Queue is an fd the exited worker no longer serves
+    res = sorted(((lambda t: (t[0], torch.from_numpy(t[1])) + tuple(t[2:]))(q.get(timeout=300)) for _ in procs), key=lambda x: x[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -135,7 +136,7 @@ def _tile_worker(rank, world, port, framewise, q):
     out = S.decode_tile_sharded(dec, O._blend, z, tl, team)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, out, len(n), len(S.leaf_crops(tl, *z.shape[2:])), [tuple(r) for r in S.temporal_tile_owner(len(S._temporal_ranges(tl, z.shape[2])), world)]))
+    q.put((rank, out.numpy(), len(n), len(S.leaf_crops(tl, *z.shape[2:])), [tuple(r) for r in S.temporal_tile_owner(len(S._temporal_ranges(tl, z.shape[2])), world)]))
 
 
 @pytest.mark.parametrize("world,framewise", [(2, 0), (2, 1), (3, 1), (5, 1)])

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Variant builder / runner for the generated K loop of csrc/gemm_asm.hip (same scheme as tools/attn_q64_tune.py).
+  build NAME [key=value ...]   -> tools/variants/libltxhip_NAME.so
+  run [NAME ...]               (GPU box) TF/s of each variant on the square and DiT shapes, forced tile asm256x256 unless TILE=..."""
+import json, math, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "candle-video_amd"); VAR = os.path.join(ROOT, "tools", "variants"); HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def build(name, opts):
+    os.makedirs(VAR, exist_ok=True)
+    bdir = os.path.join(PKG, "build", "var"); os.makedirs(bdir, exist_ok=True)
+    inc = os.path.join(bdir, f"gemm_loop_{name}.inc")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_asm.py"), "--out", inc] + opts, check=True)
+    obj = os.path.join(bdir, f"gemm_asm_{name}.o")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f'-DGEMM_ASM_LOOP_INC="{inc}"', "-x", "hip", "-c",
+                    os.path.join(PKG, "csrc", "gemm_asm.hip"), "-o", obj], check=True)
+    objs = []
+    for sub in ("csrc", "host"):
+        d = os.path.join(PKG, "build", sub)
+        objs += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".o") and not f.startswith("gemm_asm")]
+    out = os.path.join(VAR, f"libltxhip_{name}.so")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [obj, "-lz"], check=True)
+    print("built", out)
+
+
+def measure():
+    sys.path.insert(0, PKG); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch, ltxhip
+    from microbench import timeit
+    res = {}
+    tile = os.environ.get("TILE", "asm256x256")
+    os.environ["LTX_GEMM_ASM_TILE"] = tile
+    os.environ["LTX_GEMM_ASM"] = "0" if tile == "big" else "1"
+    for name, M, N, K in [("sq8192", 8192, 8192, 8192), ("sq4096", 4096, 4096, 4096), ("qkv", 4992, 6144, 2048), ("ff2", 4992, 2048, 8192), ("k16k", 4096, 4096, 16384)]:
+        x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
+        fn = lambda: ltxhip.ops.linear(x, w, None)
+        t = min(timeit(fn, iters=10, warm=2) for _ in range(3))
+        res[name] = round(2 * M * N * K / t / 1e9, 1)
+    # cycles per K-step from the slope over K at fixed 4096 x 4096 (256 tiles = one per CU), assuming 2.0 GHz
+    res["us_per_kstep"] = round((2 * 4096 * 4096 * 16384 / res["k16k"] / 1e6 - 2 * 4096 ** 3 / res["sq4096"] / 1e6) / (256 - 64), 4)
+    print(json.dumps(res), flush=True)
+
+
+def run(names):
+    libs = sorted(f for f in os.listdir(VAR) if f.startswith("libltxhip_") and f.endswith(".so"))
+    if names: libs = [f"libltxhip_{n}.so" for n in names]
+    for lib in libs:
+        shutil.copyfile(os.path.join(VAR, lib), os.path.join(PKG, "libltxhip.so"))
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "measure"], capture_output=True, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        print(lib[len("libltxhip_"):-3], line[-1] if line else ("FAILED " + p.stderr[-300:]), flush=True)
+
+
+if __name__ == "__main__":
+    {"build": lambda: build(sys.argv[2], sys.argv[3:]), "measure": measure, "run": lambda: run(sys.argv[2:])}[sys.argv[1]]()
