@@ -34,6 +34,24 @@ extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int k
     return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_timestep_embedding(const float* timesteps_host, int n, int vae_flavour, float multiplier, int dtype, void* out, ltx_stream stream) {
+    if (!timesteps_host || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_op_timestep_embedding: null argument");
+    if (n < 1 || n > 8) LTX_FAIL(LTX_ERR_ARG, "ltx_op_timestep_embedding: batch must be 1..8");
+    float tab[128]; ltx_sinusoid_table(vae_flavour, tab);
+    float* dtab = nullptr;
+    HIP_TRY(hipMalloc((void**)&dtab, sizeof(tab)));
+    int rc = LTX_OK;
+    if (hipMemcpy(dtab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) rc = LTX_ERR_HIP;
+    if (rc == LTX_OK) {
+        TimeVec tv; tv.n = n;
+        for (int i = 0; i < n; ++i) tv.t[i] = timesteps_host[i];
+        rc = ltx_launch_sinusoid(out, dtc(dtype), tv, dtab, 128, dtc(dtype) == LTX_DT_BF16, multiplier, (hipStream_t)stream);
+        if (rc == LTX_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = LTX_ERR_HIP;
+    }
+    (void)hipFree(dtab);
+    return rc;
+}
+
 extern "C" int ltx_op_qknorm_rope(void* x, int64_t rows, int D, int ld, const void* weight, float eps,
                                   const float* cos, const float* sin, int dtype, ltx_stream stream) {
     if (!x || !weight) LTX_FAIL(LTX_ERR_ARG, "ltx_op_qknorm_rope: null tensor");

@@ -14,13 +14,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define LTX_WAVE 64
 
-// ---- error plumbing (thread-local last error, C-ABI returns int codes) ----
-enum { LTX_OK = 0, LTX_ERR_ARG = 1, LTX_ERR_HIP = 2, LTX_ERR_MISSING_WEIGHT = 3, LTX_ERR_UNSUPPORTED = 4 };
-void ltx_set_error(const std::string& s);
-#define LTX_FAIL(code, msg) do { ltx_set_error(std::string(msg)); return (code); } while (0)
+#include "errors.h"
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     ltx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return LTX_ERR_HIP; } } while (0)
-#define LTX_TRY(expr) do { int _rc = (expr); if (_rc != LTX_OK) return _rc; } while (0)
 #define LTX_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
 
 // ---- element traits: T in {float, bf16_t}; a "chunk" is 16 bytes ----

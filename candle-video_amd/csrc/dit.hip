@@ -127,11 +127,7 @@ int build(ltx_dit* m, const ltx_weight* weights, size_t n_weights) {
         HIP_TRY(hipMemcpy(m->rope_freqs, fr.data(), sizeof(float) * steps, hipMemcpyHostToDevice));
         // inv_freq_i = 1 / 10000^(i/128)  (ltx_transformer.rs:288-290)
         std::vector<float> inv(128);
-        for (int i = 0; i < 128; ++i) {
-            float ex = (float)i / 128.0f;
-            float pw = (float)std::pow(10000.0, (double)ex);
-            inv[i] = 1.0f / pw;
-        }
+        ltx_sinusoid_table(0, inv.data());
         HIP_TRY(hipMalloc((void**)&m->inv_freq, sizeof(float) * 128)); m->owned.push_back(m->inv_freq);
         HIP_TRY(hipMemcpy(m->inv_freq, inv.data(), sizeof(float) * 128, hipMemcpyHostToDevice));
     }
@@ -139,12 +135,6 @@ int build(ltx_dit* m, const ltx_weight* weights, size_t n_weights) {
 }
 
 }  // namespace
-
-extern "C" void ltx_dit_config_default(ltx_dit_config* c) {
-    c->in_channels = 128; c->out_channels = 128; c->patch_size = 1; c->patch_size_t = 1;
-    c->num_attention_heads = 32; c->attention_head_dim = 64; c->cross_attention_dim = 2048;
-    c->num_layers = 28; c->norm_eps = 1e-6f; c->caption_channels = 4096;
-}
 
 extern "C" int ltx_dit_create(const ltx_dit_config* cfg, const ltx_weight* weights, size_t n_weights,
                               ltx_dtype model_dtype, int device, ltx_dit** out) {

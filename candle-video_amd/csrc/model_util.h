@@ -48,6 +48,17 @@ int ltx_load_linear(const WeightMap& wm, const std::string& prefix, int in, int 
 // stage a source tensor on the device in its own dtype (returns temp pointer to free, or the original device ptr)
 int ltx_stage_src(const ltx_weight* w, const void** dev_src, void** temp_to_free);
 
+// Frequency tables of the two get_timestep_embedding flavours, with the reference's f32 roundings:
+//   DiT (ltx_transformer.rs:288-290): 1 / 10000^(i/128);   VAE (vae.rs:172-198): exp(-ln(1e4) / 128 * i)
+inline void ltx_sinusoid_table(int vae_flavour, float tab[128]) {
+    if (!vae_flavour) {
+        for (int i = 0; i < 128; ++i) { const float ex = (float)i / 128.0f; const float pw = (float)std::pow(10000.0, (double)ex); tab[i] = 1.0f / pw; }
+    } else {
+        const float coef = (float)(-std::log(10000.0) / 128.0);
+        for (int i = 0; i < 128; ++i) { const float x = (float)i * coef; tab[i] = (float)std::exp((double)x); }
+    }
+}
+
 // y[M,N] = epi(x[M,K] @ W^T + b)
 int ltx_linear(const LinearW& l, const void* x, int lda, void* y, int ldc, int M, int dtype, int epi, hipStream_t s,
                const void* resid = nullptr, int ldr = 0, const float* gate = nullptr, int gate_stride = 0, int rows_per_batch = 1);

@@ -195,8 +195,7 @@ int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
     // sinusoid table exp(-ln(1e4) * i / 128) with the reference's f32 roundings (vae.rs:172-198)
     {
         std::vector<float> tab(128);
-        const float coef = (float)(-std::log(10000.0) / 128.0);
-        for (int i = 0; i < 128; ++i) { float x = (float)i * coef; tab[i] = (float)std::exp((double)x); }
+        ltx_sinusoid_table(1, tab.data());
         HIP_TRY(hipMalloc((void**)&v->vtab, sizeof(float) * 128)); v->owned.push_back(v->vtab);
         HIP_TRY(hipMemcpy(v->vtab, tab.data(), sizeof(float) * 128, hipMemcpyHostToDevice));
     }
@@ -449,20 +448,6 @@ int decode_cl(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeV
 }
 
 }  // namespace
-
-extern "C" void ltx_vae_config_default(ltx_vae_config* c) {
-    c->latent_channels = 128; c->out_channels = 3; c->n_blocks = 3;
-    int boc[4] = {256, 512, 1024, 0}; int lpb[5] = {5, 5, 5, 5, 0}; int upf[4] = {2, 2, 2, 0};
-    for (int i = 0; i < 4; ++i) { c->decoder_block_out_channels[i] = boc[i]; c->decoder_upsample_factor[i] = upf[i]; }
-    for (int i = 0; i < 5; ++i) c->decoder_layers_per_block[i] = lpb[i];
-    c->patch_size = 4; c->patch_size_t = 1; c->timestep_conditioning = 1; c->decoder_causal = 0;
-    c->scaling_factor = 1.0f; c->spatial_compression_ratio = 32; c->temporal_compression_ratio = 8;
-}
-extern "C" void ltx_tiling_default(ltx_tiling* t) {
-    t->use_tiling = 1; t->use_framewise_decoding = 1;
-    t->tile_sample_min_height = 512; t->tile_sample_min_width = 512; t->tile_sample_min_num_frames = 16;
-    t->tile_sample_stride_height = 384; t->tile_sample_stride_width = 384; t->tile_sample_stride_num_frames = 8;
-}
 
 extern "C" int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t n_weights,
                               ltx_dtype model_dtype, int device, ltx_vae** out) {

@@ -7,16 +7,6 @@
 #include <vector>
 #include "../csrc/model_util.h"
 
-extern "C" void ltx_pipeline_params_default(ltx_pipeline_params* p) {
-    std::memset(p, 0, sizeof(*p));
-    p->height = 512; p->width = 768; p->num_frames = 97; p->frame_rate = 25;   // main.rs:627
-    p->num_inference_steps = 7;                                                  // configs.rs:227
-    p->guidance_scale = 1.0f; p->guidance_rescale = 0.0f; p->stg_scale = 0.0f;
-    p->decode_timestep = 0.05f; p->decode_noise_scale = 0.025f;                  // configs.rs:233-234
-    p->shift_terminal = 0.1f; p->use_shift_terminal = 1;                         // configs.rs:101-121
-    p->postprocess = 1;
-}
-
 // calculate_shift (t2v_pipeline.rs:159-169), f32 arithmetic
 extern "C" float ltx_calculate_shift(int seq_len, int base_seq_len, int max_seq_len, float base_shift, float max_shift) {
     float m = (max_shift - base_shift) / (float)(max_seq_len - base_seq_len);

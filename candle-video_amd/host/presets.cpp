@@ -3,7 +3,7 @@
 #include <string>
 
 #include "../../include/ltxhip_presets.h"
-#include "../csrc/common.h"
+#include "../csrc/errors.h"
 
 namespace {
 struct Alias { const char* name; int preset; };

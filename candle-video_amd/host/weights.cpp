@@ -17,7 +17,7 @@
 #include <vector>
 
 #include "../../include/ltxhip_weights.h"
-#include "../csrc/common.h"
+#include "../csrc/errors.h"
 
 namespace {
 
@@ -323,6 +323,7 @@ int resolve(const std::string& path, std::vector<std::string>* files) {
     return LTX_OK;
 }
 
+#ifndef LTX_HOST_ONLY          /* the sanitizer build (make asan) has no device library to create models in */
 struct Loaded {
     std::vector<ltx_safetensors*> files;
     std::vector<std::string> names;          // stable storage for ltx_weight.name
@@ -378,6 +379,7 @@ int gather(const char* path, int unified, int component, Loaded* L) {
     if (L->weights.empty()) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, std::string("no ") + (component ? "VAE" : "transformer") + " tensors found in '" + path + "'");
     return LTX_OK;
 }
+#endif
 }  // namespace
 
 extern "C" int ltx_weights_resolve(const char* path, char* out, size_t cap, size_t* n_files) {
@@ -394,6 +396,7 @@ extern "C" int ltx_weights_resolve(const char* path, char* out, size_t cap, size
     return LTX_OK;
 }
 
+#ifndef LTX_HOST_ONLY
 extern "C" int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* path, int unified,
                                          ltx_dtype model_dtype, int device, ltx_dit** out) {
     Loaded L;
@@ -406,3 +409,4 @@ extern "C" int ltx_vae_create_from_files(const ltx_vae_config* cfg, const char* 
     LTX_TRY(gather(path, unified, 1, &L));
     return ltx_vae_create(cfg, L.weights.data(), L.weights.size(), model_dtype, device, out);
 }
+#endif

@@ -112,6 +112,7 @@ _SIGS = {
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
     "ltx_op_rope_table": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ltx_op_timestep_embedding": [_vp, _i, _i, _f, _i, _vp, _vp],
     "ltx_op_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "ltx_op_attention_prescaled": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ltx_op_conv3d": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -873,6 +874,14 @@ class ops:
         _check(lib.ltx_op_qknorm_rope(_ptr(x), C.c_int64(rows), D, D, _ptr(weight), C.c_float(eps), _ptr(cos), _ptr(sin),
                                       _dt(x.dtype), _stream()))
         return x
+
+    @staticmethod
+    def timestep_embedding(timesteps, vae_flavour=False, multiplier=1.0, dtype=torch.float32, device="cuda"):
+        """get_timestep_embedding(dim 256, [cos | sin]): the DiT's (ltx_transformer.rs:271-309) or the VAE's (vae.rs:172-198)"""
+        ts = [float(t) for t in timesteps]
+        out = torch.empty(len(ts), 256, dtype=dtype, device=device)
+        _check(lib.ltx_op_timestep_embedding(_floats(ts), len(ts), int(bool(vae_flavour)), C.c_float(multiplier), _dt(dtype), _ptr(out), _stream()))
+        return out
 
     @staticmethod
     def rope_table(B, F, H, W, D, coords=None, rope_scale=None, device="cuda"):

@@ -35,6 +35,12 @@ int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float 
 int ltx_op_qknorm_rope(void* x, int64_t rows, int D, int ld, const void* weight, float eps,
                        const float* cos, const float* sin, int dtype, ltx_stream stream);
 
+/* get_timestep_embedding, dim 256, order [cos | sin]: flavour 0 = the DiT's (ltx_transformer.rs:271-309, frequencies
+ * 1/10000^(i/128)), 1 = the VAE's (vae.rs:172-198, exp(-ln(1e4) i / 128), timestep first multiplied by `multiplier` =
+ * timestep_scale_multiplier, :1668-1676).  In bf16 the timestep is rounded to bf16 first (:1051).  timesteps: HOST [n], n <= 8;
+ * out DEVICE [n,256] of `dtype`.  Blocks until done (it stages its 128-entry table itself). */
+int ltx_op_timestep_embedding(const float* timesteps_host, int n, int vae_flavour, float multiplier, int dtype, void* out, ltx_stream stream);
+
 /* LtxVideoRotaryPosEmbed::forward (ltx_transformer.rs:436-524): half-width tables [B*F*H*W, D/2];
  * coords f32 [B*S,3] or NULL (then the (f,h,w) grid scaled by rope_scale*patch/base or raw). */
 int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F, int H, int W, int D,

@@ -526,3 +526,22 @@ def test_real_shape_plans_are_bit_identical(hip, monkeypatch):
     assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
     monkeypatch.setenv("LTX_GEMM_WIDE_EPI", "0")
     assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
+
+
+@pytest.mark.parametrize("vae_flavour,mult", [(False, 1.0), (True, 1000.0)])
+def test_timestep_embedding_kernel_vs_oracle(hip, vae_flavour, mult):
+    """§8 a6 / a23 standalone: the sinusoid kernel against get_timestep_embedding (ltx_transformer.rs:271-309) and the
+    VAE's variant (vae.rs:172-198, timestep x timestep_scale_multiplier first).  f32: angles reach 1000 rad, where one
+    f32 ulp of the angle is 6e-5, so the bar is 2e-4 absolute on values in [-1, 1] (the reference's own embedding test
+    uses MSE < 1e-5); bf16: the timestep is rounded to bf16 first (:1051) and the result rounded once."""
+    ts = [1000.0, 979.0, 500.0, 99.0, 0.05, 0.0] if not vae_flavour else [0.05, 0.025, 1.0, 0.0]
+    t = torch.tensor(ts)
+    want = O.vae_timestep_embedding(t * mult) if vae_flavour else O.get_timestep_embedding(t)
+    got = hip.ops.timestep_embedding(ts, vae_flavour, mult).cpu()
+    assert got.shape == (len(ts), 256)
+    assert (got - want).abs().max() <= 2e-4, (got - want).abs().max()
+    assert ((got - want) ** 2).mean() < 1e-9
+    tb = t.bfloat16()
+    want_b = (O.vae_timestep_embedding((tb * torch.tensor(mult).bfloat16()).float()) if vae_flavour else O.get_timestep_embedding(tb.float())).bfloat16()
+    got_b = hip.ops.timestep_embedding(ts, vae_flavour, mult, dtype=torch.bfloat16).cpu()
+    assert (got_b.float() - want_b.float()).abs().max() <= 2 ** -7       # one bf16 ulp at 1.0
