@@ -25,6 +25,9 @@
 #ifndef HALO_LOADERS
 #define HALO_LOADERS 4
 #endif
+#ifndef HALO_ABL          // timing ablations (wrong results; tools/conv_variants.py): 1 = one A fragment read per k half, 2 = one W fragment read, 4 = no LDS-DMA in the loop
+#define HALO_ABL 0
+#endif
 
 namespace {
 
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         constexpr int hw = decltype(hw_tag)::value;
         constexpr int ih = hw / 3, iw = hw % 3;                     // dh = ih - 1, dw = iw - 1
         // next step's weight tile; next group's halo image, one piece round per step
-        if (hw < 8) issue_b(grp, hw + 1, buf ^ 1); else if (grp + 1 < G) issue_b(grp + 1, 0, buf ^ 1);
+        if (!(HALO_ABL & 4)) { if (hw < 8) issue_b(grp, hw + 1, buf ^ 1); else if (grp + 1 < G) issue_b(grp + 1, 0, buf ^ 1); }
         constexpr int RPS = (AJ + 8) / 9;                           // halo piece rounds per step
-        if (grp + 1 < G) {
+        if (!(HALO_ABL & 4) && grp + 1 < G) {
 #pragma unroll
             for (int rr = 0; rr < RPS; ++rr) if (hw * RPS + rr < AJ) issue_a(grp + 1, hw * RPS + rr);
         }
@@ -158,10 +161,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         for (int kb = 0; kb < 2; ++kb) {
             Chunk16 af[FM], wf[FN];
 #pragma unroll
-            for (int f = 0; f < FN; ++f) wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_h(wn * WN + f * 16 + frow, kb * 4 + fq));
+            for (int f = 0; f < FN; ++f) {
+                if ((HALO_ABL & 2) && f > 0) { wf[f].u = wf[0].u + (u32x4){(uint32_t)f, 0u, 0u, 0u}; continue; }
+                wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_h(wn * WN + f * 16 + frow, kb * 4 + fq));
+            }
             af[0].u = *reinterpret_cast<const u32x4*>(As + rowbase[0] + colpart[iw][kb] + ih * HW * ROWB);
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
+                if ((HALO_ABL & 1) && fm + 1 < FM) af[fm + 1].u = af[0].u + (u32x4){(uint32_t)fm, 0u, 0u, 0u};
+                else
                 if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + rowbase[fm + 1] + colpart[iw][kb] + ih * HW * ROWB);
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
