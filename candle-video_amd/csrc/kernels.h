@@ -118,6 +118,8 @@ bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
 struct TimeVec { float t[8]; int n; };
 // out[b][0:half] = cos(t_b*tab), out[b][half:] = sin(t_b*tab); t rounded to T first when round_t
+// ggml blocks (device) -> dense tensor (gguf_dequant.hip)
+int ltx_launch_gguf_dequant(const void* blocks_dev, int ggml_type, int64_t numel, void* dst, int dst_dtype, hipStream_t s);
 int ltx_launch_sinusoid(void* out, int dtype, const TimeVec& tv, const float* tab, int half, int round_t, float tmul, hipStream_t s);
 int ltx_launch_silu(const void* x, void* y, int64_t n, int dtype, hipStream_t s);
 int ltx_launch_cast(const void* x, int xdt, void* y, int ydt, int64_t n, hipStream_t s);

@@ -7,6 +7,8 @@
 #include <vector>
 #include "model_util.h"
 #include "../../include/ltxhip_t5.h"
+#include "../../include/ltxhip_weights.h"
+#include <cstring>
 
 struct ltx_t5 {
     ltx_t5_config cfg;
@@ -17,8 +19,8 @@ struct ltx_t5 {
     struct Layer { LinearW qkv, o, wi, wo; void *ln0 = nullptr, *ln1 = nullptr; };
     std::vector<Layer> layers;
     void* final_ln = nullptr;
-    DevBuf ids, h, n, qkv, att, ff, act, bias;
-    ~ltx_t5() { for (void* p : owned) (void)hipFree(p); ids.release(); h.release(); n.release(); qkv.release(); att.release(); ff.release(); act.release(); bias.release(); }
+    DevBuf ids, h, n, qkv, att, ff, act, bias, kmask;
+    ~ltx_t5() { for (void* p : owned) (void)hipFree(p); ids.release(); h.release(); n.release(); qkv.release(); att.release(); ff.release(); act.release(); bias.release(); kmask.release(); }
 };
 
 namespace {
@@ -62,9 +64,10 @@ __global__ void t5_gate_kernel(const T* ff, T* act, int64_t rows, int dff) {
     }
 }
 
-// exact-f32 attention with a per-head [S,S] bias: block = (64 queries, head, batch), one query per lane, K/V tiles in LDS
+// exact-f32 attention with a per-head [S,S] bias (+ an additive per-key mask [B,S] or null: the quantised encoder's
+// (1 - mask) * -1e9, quantized_t5_encoder.rs:624-634): block = (64 queries, head, batch), one query per lane, K/V tiles in LDS
 template <typename T, int HD>
-__global__ __launch_bounds__(64) void t5_attn_kernel(const T* qkv, const float* bias, T* out, int S, int H) {
+__global__ __launch_bounds__(64) void t5_attn_kernel(const T* qkv, const float* bias, const float* kmask, T* out, int S, int H) {
     constexpr int TK = 32;
     __shared__ float Ks[TK][HD + 1];
     __shared__ float Vs[TK][HD + 1];
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(64) void t5_attn_kernel(const T* qkv, const float* 
 #pragma unroll
     for (int d = 0; d < HD; ++d) { q[d] = (float)base[(int64_t)qi * ld + d]; o[d] = 0.f; }
     const float* brow = bias + ((int64_t)head * S + qi) * S;
+    const float* mrow = kmask ? kmask + (int64_t)b * S : nullptr;
     float m = -INFINITY, l = 0.f;
     for (int k0 = 0; k0 < S; k0 += TK) {
         __syncthreads();
@@ -93,7 +97,8 @@ __global__ __launch_bounds__(64) void t5_attn_kernel(const T* qkv, const float* 
             float acc = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) acc += q[d] * Ks[j][d];
-            const float x = acc + brow[k0 + j];                      // no 1/sqrt(d) in T5
+            float x = acc + brow[k0 + j];                            // no 1/sqrt(d) in T5
+            if (mrow) x += mrow[k0 + j];                             // (scores + position_bias) + mask, the reference's order
             const float mn = fmaxf(m, x);
             const float alpha = __expf(m - mn), p = __expf(x - mn);
             m = mn; l = l * alpha + p;
@@ -127,13 +132,13 @@ int own_fused(ltx_t5* m, const WeightMap& wm, const std::vector<std::string>& na
 }
 
 template <typename T>
-int run_attn(const ltx_t5* m, const void* qkv, const float* bias, void* out, int B, int S, hipStream_t s) {
+int run_attn(const ltx_t5* m, const void* qkv, const float* bias, const float* kmask, void* out, int B, int S, hipStream_t s) {
     dim3 grid((unsigned)cdiv(S, 64), (unsigned)m->cfg.num_heads, (unsigned)B), block(64);
     switch (m->cfg.d_kv) {
-        case 32: hipLaunchKernelGGL((t5_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
-        case 64: hipLaunchKernelGGL((t5_attn_kernel<T, 64>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
-        case 8: hipLaunchKernelGGL((t5_attn_kernel<T, 8>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
-        case 16: hipLaunchKernelGGL((t5_attn_kernel<T, 16>), grid, block, 0, s, (const T*)qkv, bias, (T*)out, S, m->cfg.num_heads); break;
+        case 32: hipLaunchKernelGGL((t5_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qkv, bias, kmask, (T*)out, S, m->cfg.num_heads); break;
+        case 64: hipLaunchKernelGGL((t5_attn_kernel<T, 64>), grid, block, 0, s, (const T*)qkv, bias, kmask, (T*)out, S, m->cfg.num_heads); break;
+        case 8: hipLaunchKernelGGL((t5_attn_kernel<T, 8>), grid, block, 0, s, (const T*)qkv, bias, kmask, (T*)out, S, m->cfg.num_heads); break;
+        case 16: hipLaunchKernelGGL((t5_attn_kernel<T, 16>), grid, block, 0, s, (const T*)qkv, bias, kmask, (T*)out, S, m->cfg.num_heads); break;
         default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "t5: d_kv must be 8, 16, 32 or 64");
     }
     LTX_CHECK_LAUNCH();
@@ -183,6 +188,61 @@ extern "C" int ltx_t5_create(const ltx_t5_config* cfg, const ltx_weight* weights
 extern "C" void ltx_t5_destroy(ltx_t5* m) { delete m; }
 
 extern "C" int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S, ltx_dtype out_dtype, void* out, ltx_stream stream) {
+    return ltx_t5_forward_masked(m, input_ids, nullptr, B, S, out_dtype, out, stream);
+}
+
+// QuantizedT5EncoderModel::load_with_config (quantized_t5_encoder.rs:575-603): every tensor is dequantised to f32 on the device
+// (QTensor::dequantize), handed to ltx_t5_create under the Hugging Face name of the same weight, then released.
+extern "C" int ltx_t5_create_from_gguf(const ltx_t5_config* cfg, const char* gguf_path, ltx_dtype model_dtype, int device, ltx_t5** out) {
+    if (!cfg || !gguf_path || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create_from_gguf: null argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    ltx_gguf* g = nullptr;
+    LTX_TRY(ltx_gguf_open(gguf_path, &g));
+    struct Guard { ltx_gguf* g; std::vector<void*> tmp; ~Guard() { for (void* p : tmp) (void)hipFree(p); ltx_gguf_close(g); } } guard{g, {}};
+    const int D = cfg->d_model, inner = cfg->num_heads * cfg->d_kv;
+    std::vector<std::string> names; std::vector<ltx_weight> ws;
+    names.reserve(16 + 12 * (size_t)cfg->num_layers); ws.reserve(names.capacity());
+    auto add = [&](const std::string& gguf_name, const std::string& hf_name, int64_t d0, int64_t d1) -> int {
+        const int idx = ltx_gguf_find(g, gguf_name.c_str());
+        if (idx < 0) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "GGUF tensor '" + gguf_name + "' not found in '" + gguf_path + "'");
+        const char* nm; int type, nd; const int64_t* shp; const void* data; size_t nbytes;
+        LTX_TRY(ltx_gguf_tensor(g, (size_t)idx, &nm, &type, &nd, &shp, &data, &nbytes));
+        int64_t numel = 1; for (int i = 0; i < nd; ++i) numel *= shp[i];
+        const bool ok = d1 ? (nd == 2 && shp[0] == d0 && shp[1] == d1) : (numel == d0);
+        if (!ok) LTX_FAIL(LTX_ERR_ARG, "GGUF tensor '" + gguf_name + "': unexpected shape");
+        void* dev = nullptr;
+        HIP_TRY(hipMalloc(&dev, (size_t)numel * sizeof(float)));
+        guard.tmp.push_back(dev);
+        LTX_TRY(ltx_gguf_dequantize(type, data, 0, numel, LTX_F32, dev, nullptr));
+        names.push_back(hf_name);
+        ltx_weight w; memset(&w, 0, sizeof(w));
+        w.data = dev; w.dtype = LTX_F32; w.ndim = d1 ? 2 : 1; w.shape[0] = d0; w.shape[1] = d1; w.on_device = 1;
+        ws.push_back(w);
+        return LTX_OK;
+    };
+    LTX_TRY(add("token_embd.weight", "shared.weight", cfg->vocab_size, D));
+    LTX_TRY(add("enc.blk.0.attn_rel_b.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", cfg->relative_attention_num_buckets, cfg->num_heads));
+    for (int i = 0; i < cfg->num_layers; ++i) {
+        const std::string gp = "enc.blk." + std::to_string(i) + ".", hp = "encoder.block." + std::to_string(i) + ".layer.";
+        LTX_TRY(add(gp + "attn_q.weight", hp + "0.SelfAttention.q.weight", inner, D));
+        LTX_TRY(add(gp + "attn_k.weight", hp + "0.SelfAttention.k.weight", inner, D));
+        LTX_TRY(add(gp + "attn_v.weight", hp + "0.SelfAttention.v.weight", inner, D));
+        LTX_TRY(add(gp + "attn_o.weight", hp + "0.SelfAttention.o.weight", D, inner));
+        LTX_TRY(add(gp + "attn_norm.weight", hp + "0.layer_norm.weight", D, 0));
+        LTX_TRY(add(gp + "ffn_gate.weight", hp + "1.DenseReluDense.wi_0.weight", cfg->d_ff, D));      // gelu_new(gate(x)) * up(x), :437-449
+        LTX_TRY(add(gp + "ffn_up.weight", hp + "1.DenseReluDense.wi_1.weight", cfg->d_ff, D));
+        LTX_TRY(add(gp + "ffn_down.weight", hp + "1.DenseReluDense.wo.weight", D, cfg->d_ff));
+        LTX_TRY(add(gp + "ffn_norm.weight", hp + "1.layer_norm.weight", D, 0));
+    }
+    LTX_TRY(add("enc.output_norm.weight", "encoder.final_layer_norm.weight", D, 0));
+    for (size_t i = 0; i < ws.size(); ++i) ws[i].name = names[i].c_str();
+    HIP_TRY(hipDeviceSynchronize());
+    return ltx_t5_create(cfg, ws.data(), ws.size(), model_dtype, device, out);
+}
+
+extern "C" int ltx_t5_forward_masked(ltx_t5* m, const int32_t* input_ids, const float* attention_mask, int B, int S,
+                                     ltx_dtype out_dtype, void* out, ltx_stream stream) {
     if (!m || !input_ids || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_forward: null argument");
     if (B < 1 || S < 1 || S > 512) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_forward: need B >= 1 and 1 <= S <= 512");
     HIP_TRY(hipSetDevice(m->device));
@@ -195,6 +255,16 @@ extern "C" int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S,
     LTX_TRY(m->ff.ensure(M * 2 * c.d_ff * esz)); LTX_TRY(m->act.ensure(M * c.d_ff * esz));
     LTX_TRY(m->bias.ensure((size_t)H * S * S * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(m->ids.p, input_ids, M * sizeof(int), hipMemcpyHostToDevice, s));
+    const float* kmask = nullptr;
+    std::vector<float> kb;
+    if (attention_mask) {                                            // (1 - mask) * -1e9 in f32, as the reference builds it (:624-634)
+        kb.resize((size_t)M);
+        for (int64_t i = 0; i < M; ++i) kb[(size_t)i] = (1.0f - attention_mask[i]) * -1e9f;
+        LTX_TRY(m->kmask.ensure(M * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(m->kmask.p, kb.data(), M * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                            // kb is a stack-lifetime staging buffer
+        kmask = m->kmask.as<float>();
+    }
     const int blocks = (int)((M * D + 255) / 256 > 4096 ? 4096 : (M * D + 255) / 256);
     if (dt == LTX_DT_BF16) hipLaunchKernelGGL((t5_embed_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, m->ids.as<int>(), (const bf16_t*)m->embed, m->h.as<bf16_t>(), M, D, c.vocab_size);
     else hipLaunchKernelGGL((t5_embed_kernel<float>), dim3(blocks), dim3(256), 0, s, m->ids.as<int>(), (const float*)m->embed, m->h.as<float>(), M, D, c.vocab_size);
@@ -208,8 +278,8 @@ extern "C" int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S,
         rn.x = m->h.p; rn.y = m->n.p; rn.weight = L.ln0;
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         LTX_TRY(ltx_linear(L.qkv, m->n.p, D, m->qkv.p, 3 * inner, (int)M, dt, EPI_BIAS, s));
-        if (dt == LTX_DT_BF16) LTX_TRY(run_attn<bf16_t>(m, m->qkv.p, m->bias.as<float>(), m->att.p, B, S, s));
-        else LTX_TRY(run_attn<float>(m, m->qkv.p, m->bias.as<float>(), m->att.p, B, S, s));
+        if (dt == LTX_DT_BF16) LTX_TRY(run_attn<bf16_t>(m, m->qkv.p, m->bias.as<float>(), kmask, m->att.p, B, S, s));
+        else LTX_TRY(run_attn<float>(m, m->qkv.p, m->bias.as<float>(), kmask, m->att.p, B, S, s));
         LTX_TRY(ltx_linear(L.o, m->att.p, inner, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
         rn.x = m->h.p; rn.y = m->n.p; rn.weight = L.ln1;
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));

@@ -123,6 +123,10 @@ _SIGS = {
     # include/ltxhip_t5.h
     "ltx_t5_config_default": [_vp], "ltx_t5_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_t5_destroy": [_vp],
     "ltx_t5_forward": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "ltx_t5_create_from_gguf": [_vp, C.c_char_p, _i, _i, _vp], "ltx_t5_forward_masked": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "ltx_gguf_open": [C.c_char_p, _vp], "ltx_gguf_close": [_vp], "ltx_gguf_count": [_vp], "ltx_gguf_find": [_vp, C.c_char_p],
+    "ltx_gguf_tensor": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp], "ltx_gguf_type_info": [_i, _vp, _vp],
+    "ltx_gguf_dequantize": [_i, _vp, _i, _i64, _i, _vp, _vp],
     # include/ltxhip_frames.h
     "ltx_video_to_rgb8": [_vp, _i, _i, _i, _i, _vp, _vp], "ltx_write_png": [C.c_char_p, _vp, _i, _i],
     "ltx_save_frames_png": [_vp, _i, _i, _i, _i, C.c_char_p, _vp, _vp],
@@ -154,6 +158,8 @@ lib.ltx_name_mapper_create.restype = C.c_void_p
 lib.ltx_name_mapper_destroy.restype = None
 lib.ltx_safetensors_close.restype = None
 lib.ltx_safetensors_count.restype = C.c_size_t
+lib.ltx_gguf_close.restype = None
+lib.ltx_gguf_count.restype = C.c_size_t
 
 
 def _dt(t: torch.dtype) -> int:
@@ -325,14 +331,23 @@ class T5EncoderConfig:                           # text_encoder.rs:66-113; defau
 class T5TextEncoder:
     """impl VTextEncoder (text_encoder.rs:597-606) over ltx_t5_*: forward(input_ids) -> [B,S,d_model] in the model dtype."""
 
-    def __init__(self, config: T5EncoderConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16, device: int = 0):
+    def __init__(self, config: T5EncoderConfig, weights: Optional[Dict[str, torch.Tensor]], dtype: torch.dtype = torch.bfloat16, device: int = 0,
+                 gguf_path: Optional[str] = None):
         self.config, self.dtype = config, dtype
         c = T5ConfigC(config.vocab_size, config.d_model, config.d_kv, config.d_ff, config.num_layers, config.num_heads,
                       config.relative_attention_num_buckets, config.relative_attention_max_distance, config.layer_norm_epsilon)
-        arr, keep = _make_weights(weights)
         self._h = C.c_void_p()
+        if gguf_path is not None:
+            _check(lib.ltx_t5_create_from_gguf(C.byref(c), os.fsencode(gguf_path), _dt(dtype), device, C.byref(self._h)))
+            return
+        arr, keep = _make_weights(weights)
         _check(lib.ltx_t5_create(C.byref(c), arr, C.c_size_t(len(weights)), _dt(dtype), device, C.byref(self._h)))
         del keep
+
+    @classmethod
+    def from_gguf(cls, gguf_path: str, config: Optional[T5EncoderConfig] = None, dtype: torch.dtype = torch.float32, device: int = 0):
+        """QuantizedT5EncoderModel::load_with_config (quantized_t5_encoder.rs:575-603): the reference's default text encoder"""
+        return cls(config or T5EncoderConfig(), None, dtype, device, gguf_path=gguf_path)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -340,15 +355,57 @@ class T5TextEncoder:
             lib.ltx_t5_destroy(h)
             self._h = None
 
-    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """forward(input_ids) (text_encoder.rs:600-605) / forward(input_ids, Some(mask)) (quantized_t5_encoder.rs:608-650)"""
         ids = input_ids.detach().to("cpu", torch.int32).contiguous()
         if ids.dim() != 2:
             raise LtxError("input_ids must be [B, S]")
         B, S = ids.shape
         out = torch.empty(B, S, self.config.d_model, dtype=self.dtype, device=torch.device("cuda", torch.cuda.current_device()))
-        _check(lib.ltx_t5_forward(self._h, C.c_void_p(ids.data_ptr()), B, S, _dt(self.dtype), _ptr(out), _stream()))
+        if attention_mask is not None:
+            am = attention_mask.detach().to("cpu", torch.float32).contiguous()
+            if tuple(am.shape) != (B, S):
+                raise LtxError("attention_mask must be [B, S]")
+            _check(lib.ltx_t5_forward_masked(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(am.data_ptr()), B, S, _dt(self.dtype), _ptr(out), _stream()))
+        else:
+            _check(lib.ltx_t5_forward(self._h, C.c_void_p(ids.data_ptr()), B, S, _dt(self.dtype), _ptr(out), _stream()))
         torch.cuda.current_stream().synchronize()       # the ids were read from host memory asynchronously
         return out
+
+
+# ------------------------------------------------------------------ GGUF (include/ltxhip_weights.h)
+GGML_TYPES = {"F32": 0, "F16": 1, "Q4_0": 2, "Q5_0": 6, "Q8_0": 8, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14, "BF16": 30}
+
+
+def gguf_type_info(ggml_type: int):
+    be, bb = C.c_int(), C.c_int()
+    _check(lib.ltx_gguf_type_info(ggml_type, C.byref(be), C.byref(bb)))
+    return be.value, bb.value
+
+
+def gguf_tensors(path: str):
+    """[(name, ggml_type, shape outermost-first, raw bytes)] of a GGUF file, in file order (host-side parser, no GPU needed)"""
+    h = C.c_void_p()
+    _check(lib.ltx_gguf_open(os.fsencode(path), C.byref(h)))
+    try:
+        out = []
+        for i in range(lib.ltx_gguf_count(h)):
+            nm, ty, nd, shp, data, nb = C.c_char_p(), C.c_int(), C.c_int(), C.POINTER(C.c_int64)(), C.c_void_p(), C.c_size_t()
+            rc = lib.ltx_gguf_tensor(h, i, C.byref(nm), C.byref(ty), C.byref(nd), C.byref(shp), C.byref(data), C.byref(nb))
+            raw = C.string_at(data, nb.value) if rc == 0 else None
+            out.append((nm.value.decode(), ty.value, tuple(shp[k] for k in range(nd.value)), raw))
+        return out
+    finally:
+        lib.ltx_gguf_close(h)
+
+
+def gguf_dequantize(ggml_type: int, blocks: bytes, numel: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """QTensor::dequantize on the device: raw ggml blocks (host bytes) -> dense [numel] tensor"""
+    out = torch.empty(numel, dtype=dtype, device=torch.device("cuda", torch.cuda.current_device()))
+    buf = C.create_string_buffer(blocks, len(blocks))
+    _check(lib.ltx_gguf_dequantize(ggml_type, buf, 0, numel, _dt(dtype), _ptr(out), _stream()))
+    torch.cuda.current_stream().synchronize()
+    return out
 
 
 # ------------------------------------------------------------------ VAE

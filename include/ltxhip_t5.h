@@ -1,4 +1,5 @@
-/* ltxhip_t5.h — T5 v1.1 text encoder (the step before the denoise path).
+/* ltxhip_t5.h — T5 v1.1 text encoder (the step before the denoise path), from safetensors (bf16 / f32)
+ * or, as the reference does by default, from a GGUF-quantised file (see ltx_t5_create_from_gguf below).
  *
  * Replaces `T5TextEncoderWrapper` as a `VTextEncoder` (reference: src/models/ltx_video/text_encoder.rs:315-345, 597-606),
  * i.e. `candle_transformers::models::t5::T5EncoderModel` built from `T5EncoderConfig::to_candle_t5_config` (:222-249):
@@ -31,6 +32,19 @@ void ltx_t5_destroy(ltx_t5* m);
  * out [B,S,d_model] out_dtype (device).  The caller pads ids with 0 and builds the mask itself (VTokenizer::encode_batch,
  * :612-640); like the reference, the encoder does not mask padded positions. */
 int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S, ltx_dtype out_dtype, void* out, ltx_stream stream);
+
+/* The reference's DEFAULT text encoder, `QuantizedT5EncoderModel` (quantized_t5_encoder.rs:558-679; main.rs:441-444): the same
+ * network with its weights read from a GGUF file - token_embd.weight, enc.blk.N.{attn_q,attn_k,attn_v,attn_o,attn_norm,
+ * ffn_gate (wi_0), ffn_up (wi_1), ffn_down (wo), ffn_norm}.weight, enc.blk.0.attn_rel_b.weight [buckets, heads],
+ * enc.output_norm.weight - every tensor dequantised to f32 before use (QLinear::forward, :53-72), and WITH an attention
+ * mask: scores + position_bias + (1 - mask) * -1e9 over the keys (:624-634, 218-220).
+ *   ltx_t5_create_from_gguf : load_with_config (:575-603); model_dtype F32 = the reference's arithmetic, BF16 rounds the
+ *                             dequantised weights once;
+ *   ltx_t5_forward_masked   : forward(input_ids, Some(mask)) - attention_mask HOST f32 [B,S] (1 keep, 0 pad) or NULL (no mask,
+ *                             then it is ltx_t5_forward). */
+int ltx_t5_create_from_gguf(const ltx_t5_config* cfg, const char* gguf_path, ltx_dtype model_dtype, int device, ltx_t5** out);
+int ltx_t5_forward_masked(ltx_t5* m, const int32_t* input_ids, const float* attention_mask, int B, int S,
+                          ltx_dtype out_dtype, void* out, ltx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,25 @@ int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* path, int u
 int ltx_vae_create_from_files(const ltx_vae_config* cfg, const char* path, int unified,
                               ltx_dtype model_dtype, int device, ltx_vae** out);
 
+/* ---- GGUF (the container of the reference's DEFAULT text encoder: examples/ltx-video/main.rs:261-296 picks
+ * t5-v1_1-xxl-encoder-Q8_0.gguf / -Q5_K_M.gguf unless --use-bf16-t5; quantized_t5_encoder.rs:570-600 reads it through
+ * candle's `VarBuilder::from_gguf`, which is not in the checkout: the published GGUF v2 / v3 layout and ggml block formats are
+ * restated).  One mmap'ed file; tensors in file order; shapes reported OUTERMOST FIRST (as candle reports them: a linear
+ * weight is [out, in]); `data` points into the mapping. */
+typedef struct ltx_gguf ltx_gguf;
+int ltx_gguf_open(const char* path, ltx_gguf** out);
+void ltx_gguf_close(ltx_gguf* g);
+size_t ltx_gguf_count(const ltx_gguf* g);
+int ltx_gguf_tensor(const ltx_gguf* g, size_t i, const char** name, int* ggml_type, int* ndim, const int64_t** shape,
+                    const void** data, size_t* nbytes);           /* LTX_ERR_UNSUPPORTED (fields still filled) for a type not read */
+int ltx_gguf_find(const ltx_gguf* g, const char* name);            /* index or -1 */
+/* elements and bytes per block of a ggml type; read: F32 (0), F16 (1), BF16 (30), Q4_0 (2), Q5_0 (6), Q8_0 (8), Q4_K (12),
+ * Q5_K (13), Q6_K (14).  Others: LTX_ERR_UNSUPPORTED. */
+int ltx_gguf_type_info(int ggml_type, int* block_elems, int* block_bytes);
+/* QTensor::dequantize on the device: `numel` elements of ggml blocks (HOST or DEVICE memory) -> dense dst (DEVICE) of dst_dtype,
+ * ggml's reference f32 arithmetic (each product / difference rounded separately), then one rounding to bf16 if asked. */
+int ltx_gguf_dequantize(int ggml_type, const void* blocks, int on_device, int64_t numel, ltx_dtype dst_dtype, void* dst, ltx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1093,9 +1093,13 @@ def t5_layer_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
     return (x.float() * torch.rsqrt(v + eps)).to(x.dtype) * w.to(x.dtype)
 
 
-def t5_encoder_forward(p: Dict[str, Tensor], cfg: T5Config, input_ids: Tensor, dtype=torch.float32) -> Tensor:
-    """T5EncoderModel.forward(input_ids) -> last hidden state [B, S, d_model]; no attention mask (reference behaviour)."""
+def t5_encoder_forward(p: Dict[str, Tensor], cfg: T5Config, input_ids: Tensor, dtype=torch.float32,
+                       attention_mask: Optional[Tensor] = None) -> Tensor:
+    """T5EncoderModel.forward(input_ids) -> last hidden state [B, S, d_model]; no attention mask (the bf16 wrapper's
+    behaviour, text_encoder.rs:600-605).  attention_mask [B, S] (1 keep, 0 pad): QuantizedT5EncoderModel::forward's extended
+    mask (quantized_t5_encoder.rs:624-634): (scores + position_bias) + (1 - mask) * -1e9 over the keys (:218-220)."""
     B, S = input_ids.shape
+    mask_bias = None if attention_mask is None else ((1.0 - attention_mask.float()) * -1e9).reshape(B, 1, 1, S)
     H, dk = cfg.num_heads, cfg.d_kv
     w = lambda k: p[k].to(dtype)
     h = w("shared.weight")[input_ids]
@@ -1108,6 +1112,7 @@ def t5_encoder_forward(p: Dict[str, Tensor], cfg: T5Config, input_ids: Tensor, d
         k = (n @ w(pre + "0.SelfAttention.k.weight").T).reshape(B, S, H, dk).transpose(1, 2)
         v = (n @ w(pre + "0.SelfAttention.v.weight").T).reshape(B, S, H, dk).transpose(1, 2)
         sc = q.float() @ k.float().transpose(-1, -2) + bias[None]            # T5 does not scale by 1/sqrt(d_kv)
+        if mask_bias is not None: sc = sc + mask_bias
         a = torch.softmax(sc, -1).to(dtype) @ v
         h = h + a.transpose(1, 2).reshape(B, S, H * dk) @ w(pre + "0.SelfAttention.o.weight").T
         n = t5_layer_norm(h, w(pre + "1.layer_norm.weight"), cfg.layer_norm_epsilon)

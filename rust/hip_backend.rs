@@ -24,7 +24,7 @@ use std::ptr;
 use candle_core::{bail, DType, Device, Result, Tensor};
 use ltxhip_sys as sys;
 
-use super::t2v_pipeline::{TransformerConfig, VaeConfig, VaeLtxVideo, VideoTransformer3D};
+use super::t2v_pipeline::{TextEncoder as VTextEncoder, TransformerConfig, VaeConfig, VaeLtxVideo, VideoTransformer3D};
 
 fn check(rc: c_int) -> Result<()> {
     if rc == 0 {
@@ -398,6 +398,68 @@ impl VaeLtxVideo for HipVae {
         check(unsafe { sys::ltx_memcpy_d2h(host.as_mut_ptr() as *mut c_void, v_d, n_out * 4, ptr::null_mut()) })?;
         check(unsafe { sys::ltx_stream_synchronize(ptr::null_mut()) })?;
         Tensor::from_vec(host, (b, 3, fo, ho, wo), latents.device())
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Text encoder
+// ------------------------------------------------------------------------------------------------------------------
+
+/// Replaces `QuantizedT5EncoderModel` (quantized_t5_encoder.rs:558-679, the DEFAULT of examples/ltx-video/main.rs:441-444)
+/// and, through `VTextEncoder`, `T5TextEncoderWrapper` (text_encoder.rs:596-606).
+pub struct HipT5 {
+    handle: *mut sys::ltx_t5,
+    dtype: DType,
+    d_model: usize,
+    out: DeviceBuf,
+}
+
+impl HipT5 {
+    /// `QuantizedT5EncoderModel::load(gguf_path, device)`: T5-XXL from a GGUF file, every tensor dequantised on the GPU.
+    /// `DType::F32` is the reference's arithmetic (QLinear dequantises to f32); `BF16` rounds the dequantised weights once.
+    pub fn load(gguf_path: &Path, dtype: DType, device: c_int) -> Result<Self> {
+        let mut cfg = std::mem::MaybeUninit::<sys::ltx_t5_config>::uninit();
+        unsafe { sys::ltx_t5_config_default(cfg.as_mut_ptr()) };
+        Self::load_with_config(gguf_path, unsafe { cfg.assume_init() }, dtype, device)
+    }
+
+    pub fn load_with_config(gguf_path: &Path, cfg: sys::ltx_t5_config, dtype: DType, device: c_int) -> Result<Self> {
+        let path = CString::new(gguf_path.to_string_lossy().as_bytes()).map_err(candle_core::Error::wrap)?;
+        let mut handle = ptr::null_mut();
+        check(unsafe { sys::ltx_t5_create_from_gguf(&cfg, path.as_ptr(), model_dtype(dtype)?, device, &mut handle) })?;
+        Ok(Self { handle, dtype, d_model: cfg.d_model as usize, out: DeviceBuf::new(device) })
+    }
+
+    /// `forward(input_ids [B,S] u32, Some(mask [B,S]))` (:608-650) -> [B,S,d_model] f32 on `Device::Cpu`.
+    pub fn forward_masked(&mut self, input_ids: &Tensor, attention_mask: Option<&Tensor>) -> Result<Tensor> {
+        let (b, s) = input_ids.dims2()?;
+        let ids: Vec<i32> = input_ids.to_device(&Device::Cpu)?.to_dtype(DType::U32)?.flatten_all()?.to_vec1::<u32>()?.into_iter().map(|x| x as i32).collect();
+        let mask = match attention_mask { Some(m) => Some(host_f32(m)?), None => None };
+        let n = b * s * self.d_model;
+        let dev = self.out.ensure(n * 4)?;
+        check(unsafe {
+            sys::ltx_t5_forward_masked(self.handle, ids.as_ptr(), mask.as_ref().map_or(ptr::null(), |m| m.as_ptr()), b as c_int, s as c_int,
+                                       sys::LTX_F32, dev, ptr::null_mut())
+        })?;
+        let mut host = vec![0f32; n];
+        check(unsafe { sys::ltx_memcpy_d2h(host.as_mut_ptr() as *mut c_void, dev, n * 4, ptr::null_mut()) })?;
+        check(unsafe { sys::ltx_stream_synchronize(ptr::null_mut()) })?;
+        Tensor::from_vec(host, (b, s, self.d_model), &Device::Cpu)
+    }
+}
+
+impl Drop for HipT5 {
+    fn drop(&mut self) {
+        unsafe { sys::ltx_t5_destroy(self.handle) };
+    }
+}
+
+impl VTextEncoder for HipT5 {
+    fn dtype(&self) -> DType {
+        self.dtype
+    }
+    fn forward(&mut self, input_ids: &Tensor) -> Result<Tensor> {
+        self.forward_masked(input_ids, None)
     }
 }
 

@@ -73,6 +73,21 @@ pub struct ltx_tiling {
     pub tile_sample_stride_num_frames: c_int,
 }
 
+/// `ltx_t5_config`: T5EncoderConfig (text_encoder.rs:66-113 / quantized_t5_encoder.rs:20-47); default = t5_xxl().
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ltx_t5_config {
+    pub vocab_size: c_int,
+    pub d_model: c_int,
+    pub d_kv: c_int,
+    pub d_ff: c_int,
+    pub num_layers: c_int,
+    pub num_heads: c_int,
+    pub relative_attention_num_buckets: c_int,
+    pub relative_attention_max_distance: c_int,
+    pub layer_norm_epsilon: c_float,
+}
+
 /// `ltx_pipeline_params`: arguments of LtxPipeline::call (t2v_pipeline.rs:627-1073).
 #[repr(C)]
 pub struct ltx_pipeline_params {
@@ -104,15 +119,19 @@ pub const LAYOUT_LTX_DIT_CONFIG: (usize, usize) = (40, 4);
 pub const LAYOUT_LTX_VAE_CONFIG: (usize, usize) = (92, 4);
 pub const LAYOUT_LTX_TILING: (usize, usize) = (32, 4);
 pub const LAYOUT_LTX_PIPELINE_PARAMS: (usize, usize) = (112, 8);
+pub const LAYOUT_LTX_T5_CONFIG: (usize, usize) = (36, 4);
 const _: () = assert!(size_of::<ltx_weight>() == LAYOUT_LTX_WEIGHT.0 && align_of::<ltx_weight>() == LAYOUT_LTX_WEIGHT.1);
 const _: () = assert!(size_of::<ltx_dit_config>() == LAYOUT_LTX_DIT_CONFIG.0 && align_of::<ltx_dit_config>() == LAYOUT_LTX_DIT_CONFIG.1);
 const _: () = assert!(size_of::<ltx_vae_config>() == LAYOUT_LTX_VAE_CONFIG.0 && align_of::<ltx_vae_config>() == LAYOUT_LTX_VAE_CONFIG.1);
 const _: () = assert!(size_of::<ltx_tiling>() == LAYOUT_LTX_TILING.0 && align_of::<ltx_tiling>() == LAYOUT_LTX_TILING.1);
 const _: () = assert!(size_of::<ltx_pipeline_params>() == LAYOUT_LTX_PIPELINE_PARAMS.0 && align_of::<ltx_pipeline_params>() == LAYOUT_LTX_PIPELINE_PARAMS.1);
 
+const _: () = assert!(size_of::<ltx_t5_config>() == LAYOUT_LTX_T5_CONFIG.0 && align_of::<ltx_t5_config>() == LAYOUT_LTX_T5_CONFIG.1);
+
 /// opaque handles
 pub enum ltx_dit {}
 pub enum ltx_vae {}
+pub enum ltx_t5 {}
 /// hipStream_t; null = default stream
 pub type ltx_stream = *mut c_void;
 
@@ -159,6 +178,15 @@ extern "C" {
     pub fn ltx_set_autotune(enabled: c_int) -> c_int;
     pub fn ltx_plan_save(path: *const c_char) -> c_int;
     pub fn ltx_plan_load(path: *const c_char) -> c_int;
+
+    // text encoder (include/ltxhip_t5.h): T5TextEncoderWrapper (safetensors, bf16) and QuantizedT5EncoderModel (GGUF, masked)
+    pub fn ltx_t5_config_default(c: *mut ltx_t5_config);
+    pub fn ltx_t5_create(cfg: *const ltx_t5_config, weights: *const ltx_weight, n_weights: usize, model_dtype: c_int, device: c_int, out: *mut *mut ltx_t5) -> c_int;
+    pub fn ltx_t5_create_from_gguf(cfg: *const ltx_t5_config, gguf_path: *const c_char, model_dtype: c_int, device: c_int, out: *mut *mut ltx_t5) -> c_int;
+    pub fn ltx_t5_destroy(m: *mut ltx_t5);
+    pub fn ltx_t5_forward(m: *mut ltx_t5, input_ids: *const i32, b: c_int, s: c_int, out_dtype: c_int, out: *mut c_void, stream: ltx_stream) -> c_int;
+    pub fn ltx_t5_forward_masked(m: *mut ltx_t5, input_ids: *const i32, attention_mask: *const c_float, b: c_int, s: c_int, out_dtype: c_int,
+                                 out: *mut c_void, stream: ltx_stream) -> c_int;
 
     // host-side scalar restatements
     pub fn ltx_pcg32_randn(seed: u64, inc: u64, n: usize, out_host: *mut c_float) -> c_int;

@@ -105,6 +105,56 @@ int main(int argc, char** argv) {
     write_file(dir + "/ckpt/model.safetensors.index.json", "{\"weight_map\":{\"w\":");
     (void)ltx_weights_resolve((dir + "/ckpt").c_str(), buf, sizeof buf, &nfiles);
     CHECK(ltx_weights_detect_format((dir + "/good.safetensors").c_str()) == 1 && ltx_weights_detect_format((dir + "/ckpt").c_str()) == 0);
+    // ---- GGUF container (quantized_t5_encoder.rs:575-603 reads it through candle): a good file, then every kind of damage
+    {
+        auto u32 = [](uint32_t v) { return std::string((const char*)&v, 4); };
+        auto u64 = [](uint64_t v) { return std::string((const char*)&v, 8); };
+        auto str = [&](const std::string& x) { return u64(x.size()) + x; };
+        std::string kv = str("general.alignment") + u32(4) + u32(32) + str("tokens") + u32(9) + u32(8) + u64(2) + str("a") + str("bc") + str("f") + u32(6) + u32(0x3f800000);
+        std::string infos = str("w") + u32(2) + u64(32) + u64(3) + u32(8) + u64(0) + str("n") + u32(1) + u64(4) + u32(0) + u64(128);
+        std::string headv = u32(0x46554747) + u32(3) + u64(2) + u64(3) + kv + infos;
+        headv += std::string((32 - headv.size() % 32) % 32, '\0');
+        const std::string data = std::string(3 * 34, '\x02') + std::string(128 - 3 * 34, '\0') + std::string(16, '\x03');
+        const std::string good = headv + data;
+        write_file(dir + "/good.gguf", good);
+        ltx_gguf* g = nullptr;
+        CHECK(ltx_gguf_open((dir + "/good.gguf").c_str(), &g) == 0 && ltx_gguf_count(g) == 2 && ltx_gguf_find(g, "n") == 1 && ltx_gguf_find(g, "zz") == -1);
+        for (size_t i = 0; i < 2; ++i) {
+            const char* nm; int ty, nd; const int64_t* shp; const void* dat; size_t nb;
+            CHECK(ltx_gguf_tensor(g, i, &nm, &ty, &nd, &shp, &dat, &nb) == 0);
+            unsigned acc = 0; for (size_t j = 0; j < nb; ++j) acc += ((const unsigned char*)dat)[j];
+            CHECK(acc == (i == 0 ? 2u * 102u : 3u * 16u) && shp[0] == (i == 0 ? 3 : 4));
+        }
+        { const char* nm; int ty, nd; const int64_t* shp; const void* dat; size_t nb; CHECK(ltx_gguf_tensor(g, 9, &nm, &ty, &nd, &shp, &dat, &nb) != 0); }
+        ltx_gguf_close(g);
+        int n_ok = 0;
+        for (size_t cut = 0; cut < good.size(); cut += 3) {              // every truncation must be refused or fully readable
+            write_file(dir + "/cut.gguf", good.substr(0, cut));
+            ltx_gguf* h = nullptr;
+            if (ltx_gguf_open((dir + "/cut.gguf").c_str(), &h) == 0) {
+                ++n_ok;
+                for (size_t i = 0; i < ltx_gguf_count(h); ++i) {
+                    const char* nm; int ty, nd; const int64_t* shp; const void* dat; size_t nb;
+                    if (ltx_gguf_tensor(h, i, &nm, &ty, &nd, &shp, &dat, &nb) == 0) { volatile unsigned acc = 0; for (size_t j = 0; j < nb; ++j) acc += ((const unsigned char*)dat)[j]; }
+                }
+                ltx_gguf_close(h);
+            }
+        }
+        CHECK(n_ok == 0);                                                 // the last tensor ends at the last byte: no prefix is a valid file
+        for (size_t pos = 8; pos < headv.size(); pos += 1) {              // every single-byte corruption of the header
+            std::string b = good; b[pos] = (char)(b[pos] ^ 0xA5);
+            write_file(dir + "/flip.gguf", b);
+            ltx_gguf* h = nullptr;
+            if (ltx_gguf_open((dir + "/flip.gguf").c_str(), &h) == 0) {
+                for (size_t i = 0; i < ltx_gguf_count(h); ++i) {
+                    const char* nm; int ty, nd; const int64_t* shp; const void* dat; size_t nb;
+                    if (ltx_gguf_tensor(h, i, &nm, &ty, &nd, &shp, &dat, &nb) == 0) { volatile unsigned acc = 0; for (size_t j = 0; j < nb; ++j) acc += ((const unsigned char*)dat)[j]; }
+                }
+                ltx_gguf_close(h);
+            }
+        }
+        int be, bb; CHECK(ltx_gguf_type_info(13, &be, &bb) == 0 && be == 256 && bb == 176 && ltx_gguf_type_info(11, &be, &bb) != 0);
+    }
     // ---- presets (configs.rs:50-283)
     CHECK(ltx_preset_count() == 6);
     for (int i = 0; i < ltx_preset_count(); ++i) {

@@ -40,14 +40,14 @@ def test_rust_layout_constants_and_field_order_match_the_c_headers(c_layout):
     src = open(os.path.join(ROOT, "rust", "ltxhip-sys", "src", "lib.rs")).read()
     consts = dict(re.findall(r"pub const LAYOUT_(\w+): \(usize, usize\) = \((\d+), (\d+)\);", src) and
                   [(m[0], (int(m[1]), int(m[2]))) for m in re.findall(r"pub const LAYOUT_(\w+): \(usize, usize\) = \((\d+), (\d+)\);", src)])
-    assert len(consts) == 5
+    assert len(consts) == 6
     for key, (size, align) in consts.items():
         c = c_layout[key.lower()]
         assert (size, align) == (c["size"], c["align"]), (key, size, align, c)
         # the constant is tied to the Rust struct by a compile-time assertion
         assert re.search(r"size_of::<%s>\(\) == LAYOUT_%s\.0" % (key.lower(), key), src), key
     # field ORDER of every #[repr(C)] struct equals the header's (types are all 4- or 8-byte scalars / arrays of them)
-    for name in ("ltx_weight", "ltx_dit_config", "ltx_vae_config", "ltx_tiling", "ltx_pipeline_params"):
+    for name in ("ltx_weight", "ltx_dit_config", "ltx_vae_config", "ltx_tiling", "ltx_pipeline_params", "ltx_t5_config"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, src, re.S).group(1)
         rust_fields = re.findall(r"pub (\w+):", body)
         assert rust_fields == list(c_layout[name]["fields"].keys()), (name, rust_fields)
