@@ -296,11 +296,43 @@ def c1_case():
                         "args": repr(args), "video_slice": "[:, :, ::4, ::8, ::8] of the [1,3,25,256,384] post-processed video"})
 
 
+def c3_case():
+    """BASELINE config C3's PRESET at C1's geometry: LTX-Video 0.9.5 (configs.rs:163-184: 40 steps on the linspace schedule
+    with the resolution-dependent shift, CFG 3.0 + STG 1.0 through skip block 19, rescale 0.7, no decode timestep / noise)
+    on the full 2B DiT and VAE decoder (weights of c1_case), 256x384x25: 120 real-width forwards through the guidance
+    path (t2v_pipeline.rs:878-964), which the toy pipeline fixture only walks with 2-layer models.  f32.
+    Committed: final latents, the latents after steps 1 and 20, a strided slice + moments of the video."""
+    import time
+    dcfg, vcfg = O.DitConfig(), O.VaeConfig()
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=31)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    lat, pe, pm, noise, mean, std = c1_inputs()
+    ne = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(43))
+    nm = torch.zeros(1, 128); nm[:, :8] = 1
+    args = O.PipelineArgs(height=C1["height"], width=C1["width"], num_frames=C1["num_frames"], num_inference_steps=40, sigmas=None,
+                          guidance_scale=3.0, guidance_rescale=0.7, stg_scale=1.0, skip_block_list=[19], decode_timestep=0.0, decode_noise_scale=0.0)
+    traj = []
+    t0 = time.time()
+    video = O.pipeline_call(dw, dcfg, vw, vcfg, mean, std, args, lat, pe, pm, ne, nm, noise, torch.float32, trajectory=traj)
+    dt = time.time() - t0
+    out = {"dit_weights_checksum": weights_checksum(dw), "vae_weights_checksum": weights_checksum(vw), "latents": traj[-1], "latents_step1": traj[0],
+           "latents_step20": traj[19], "video_slice": video[:, :, ::4, ::8, ::8],
+           "video_moments": torch.tensor([float(video.double().mean()), float(video.double().std()), float(video.double().abs().sum())], dtype=torch.float64),
+           "oracle_seconds": torch.tensor([dt], dtype=torch.float64)}
+    print(f"C3-preset oracle: {dt:.1f} s, {len(traj)} steps, video mean {float(video.mean()):.2f} std {float(video.std()):.2f}", flush=True)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c3.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py pipeline_call, 0.9.5 preset (CFG 3.0 + STG 1.0 skip block 19, rescale 0.7, 40 steps) at C1 geometry, synthetic weights seeds 31/32",
+                        "args": repr(args), "video_slice": "[:, :, ::4, ::8, ::8] of the [1,3,25,256,384] post-processed video"})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c3":
+        c3_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":
         ref_scripts(); ref_scripts_imported()
@@ -313,5 +345,6 @@ if __name__ == "__main__":
     ops_case()
     pipeline_case()
     c1_case()
+    c3_case()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
