@@ -296,6 +296,40 @@ def c1_case():
                         "args": repr(args), "video_slice": "[:, :, ::4, ::8, ::8] of the [1,3,25,256,384] post-processed video"})
 
 
+def c2_case():
+    """THE headline config in full: BASELINE C2 = 0.9.8-2B-distilled at 512x768x97 (S = 4992), 7 distilled steps + the
+    untiled 48-TFLOP decode, full 2B DiT + VAE (weights of c1_case), synthetic inputs of BASELINE.md section 3 - in f32 and
+    once more with the model seeing bf16-rounded timesteps (ltx_transformer.rs:1051).  About 10 minutes of host time per
+    run.  Committed: every 8th token of the final latents + their moments, a strided slice + moments of the video."""
+    import time
+    dcfg, vcfg = O.DitConfig(), O.VaeConfig()
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=31)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    F, H, W = 13, 16, 24
+    lat = O.pack_latents(O.Pcg32(42, 1442695040888963407).randn((1, 128, F, H, W)))
+    _, pe, pm, _, mean, std = c1_inputs()
+    noise = torch.randn(1, 128, F, H, W, generator=torch.Generator().manual_seed(44))
+    args = O.PipelineArgs(height=512, width=768, num_frames=97, num_inference_steps=7, sigmas=C1_SIGMAS,
+                          guidance_scale=1.0, stg_scale=0.0, decode_timestep=0.05, decode_noise_scale=0.025)
+    out = {"dit_weights_checksum": weights_checksum(dw), "vae_weights_checksum": weights_checksum(vw)}
+    for tag, cast in (("f32", None), ("f32_bf16ts", torch.bfloat16)):
+        traj = []
+        t0 = time.time()
+        video = O.pipeline_call(dw, dcfg, vw, vcfg, mean, std, args, lat, pe, pm, None, None, noise, torch.float32, trajectory=traj, timestep_cast=cast)
+        dt = time.time() - t0
+        l = traj[-1]
+        out[f"latents_sub_{tag}"] = l[:, ::8]
+        out[f"latents_moments_{tag}"] = torch.tensor([float(l.double().sum()), float(l.double().abs().sum()), float(l.double().pow(2).sum())], dtype=torch.float64)
+        out[f"video_slice_{tag}"] = video[:, :, ::8, ::16, ::16]
+        out[f"video_moments_{tag}"] = torch.tensor([float(video.double().mean()), float(video.double().std()), float(video.double().abs().sum())], dtype=torch.float64)
+        out[f"oracle_seconds_{tag}"] = torch.tensor([dt], dtype=torch.float64)
+        print(f"C2 oracle {tag}: {dt:.1f} s, video mean {float(video.mean()):.2f} std {float(video.std()):.2f}", flush=True)
+        del video, traj
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c2.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py pipeline_call at BASELINE C2 (512x768x97, S = 4992, full 2B DiT + VAE decoder, synthetic weights seeds 31/32)",
+                        "args": repr(args), "latents_sub": "[:, ::8] of the final [1,4992,128] latents", "video_slice": "[:, :, ::8, ::16, ::16] of the [1,3,97,512,768] post-processed video"})
+
+
 def c3_case():
     """BASELINE config C3's PRESET at C1's geometry: LTX-Video 0.9.5 (configs.rs:163-184: 40 steps on the linspace schedule
     with the resolution-dependent shift, CFG 3.0 + STG 1.0 through skip block 19, rescale 0.7, no decode timestep / noise)
@@ -325,14 +359,47 @@ def c3_case():
                         "args": repr(args), "video_slice": "[:, :, ::4, ::8, ::8] of the [1,3,25,256,384] post-processed video"})
 
 
+def c4_case():
+    """BASELINE config C4's decode at FULL size: the full VAE decoder (weights of c1_case) on a C2-geometry latent
+    [1,128,13,16,24] -> [1,3,97,512,768], once untiled (vae.rs:2101-2136 direct path, 48.4 TFLOP) and once with the
+    reference's tiled framewise decode at its default tile parameters (vae.rs:2225-2290, 2358-2434: 2 x 2 spatial x 13
+    temporal tiles, blends), f32, decode timestep 0.05.  Committed: a strided slice + moments of each video."""
+    import time
+    vcfg = O.VaeConfig()
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    z = torch.randn(1, 128, 13, 16, 24, generator=torch.Generator().manual_seed(46))
+    temb = torch.full((1,), 0.05, dtype=torch.float32)
+    out = {"vae_weights_checksum": weights_checksum(vw),       # the latents are re-derived from the seed by the test
+           "latents_checksum": torch.tensor([float(z.double().sum()), float(z.double().abs().sum())], dtype=torch.float64)}
+    for tag, tiling, framewise in (("untiled", False, False), ("tiled", True, True)):
+        t0 = time.time()
+        v = O.vae_decode(vw, vcfg, z, temb, torch.float32, tiling, framewise)
+        dt = time.time() - t0
+        out[f"video_slice_{tag}"] = v[:, :, ::8, ::16, ::16]
+        out[f"video_edge_{tag}"] = v[:, :, :, 376:392:2, 376:392:2]            # across the spatial tile seam (stride 384) on every frame
+        out[f"video_moments_{tag}"] = torch.tensor([float(v.double().mean()), float(v.double().std()), float(v.double().abs().sum())], dtype=torch.float64)
+        out[f"oracle_seconds_{tag}"] = torch.tensor([dt], dtype=torch.float64)
+        print(f"C4 oracle {tag}: {dt:.1f} s, video {tuple(v.shape)} mean {float(v.mean()):.4f} std {float(v.std()):.4f}", flush=True)
+        del v
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c4.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py vae_decode at C2 latent geometry, untiled and tiled+framewise (reference tile parameters), synthetic weights seed 32",
+                        "video_slice": "[:, :, ::8, ::16, ::16]; video_edge: [:, :, :, 376:392:2, 376:392:2] of the [1,3,97,512,768] video (before postprocess)"})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c2":
+        c2_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c3":
         c3_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c4":
+        c4_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":
         ref_scripts(); ref_scripts_imported()
@@ -346,5 +413,7 @@ if __name__ == "__main__":
     pipeline_case()
     c1_case()
     c3_case()
+    c4_case()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    # c2_case() (the headline config in full, ~20 minutes of host time) is generated on request only: gen_fixtures.py c2
     print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
