@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
 
     // DMA source offsets: piece j of this wave fills LDS rows 8 * (4 j + wave) .. + 7; lane -> (row lane >> 3, physical chunk
     // lane & 7), logical chunk = physical ^ ((row >> 1) & 7).  Rows past M / N repeat the last one (never stored).
+#ifndef GEMM_ASM_REG          // 1: register-staged operands (buffer loads to VGPRs two K-steps ahead + ds_write_b128), 256 x 256 tile only
+#define GEMM_ASM_REG 0
+#endif
+    constexpr bool REGSTAGE = GEMM_ASM_REG && BM == 256 && BN == 256;
     const int lr = lane >> 3, pc = lane & 7;
     u32x16 dma0; u32x2 dma1 = {0x80000000u, 0x80000000u};
     uint32_t off[AI + BI];
@@ -69,13 +73,13 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
     for (int j = 0; j < AI; ++j) {
         const int row = 8 * (j * 4 + wave) + lr;
         int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
-        off[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+        off[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)(REGSTAGE ? pc : (pc ^ ((row >> 1) & 7))) * 8u) * 2u;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int row = 8 * (j * 4 + wave) + lr;
         int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
-        off[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+        off[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)(REGSTAGE ? pc : (pc ^ ((row >> 1) & 7))) * 8u) * 2u;
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma0[j] = j < AI + BI ? off[j] : 0x80000000u;
@@ -92,6 +96,11 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
             rbase[st * 4 + ks] = smem_base + st * STAGE + BM * 128 + (wn * WN + r) * 128 + ch;      // W rows (MFMA A operand)
             rbase[8 + st * 4 + ks] = smem_base + st * STAGE + (wm * WM + r) * 128 + ch;             // activation rows (B operand)
         }
+    if constexpr (REGSTAGE) {        // LDS write address of this lane's 16 bytes of piece 0 (pieces add 4096 j, W adds BM * 128), stage 0 / 1
+        const int row0 = 8 * wave + lr;
+        dma1[0] = smem_base + (uint32_t)(row0 * 128 + ((pc ^ ((row0 >> 1) & 7)) << 4));
+        dma1[1] = dma1[0] + (uint32_t)STAGE;
+    }
     const uint64_t ap = (uint64_t)(uintptr_t)g.A, wp = (uint64_t)(uintptr_t)g.W;
     const u32x4 ra = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ap), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ap >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
     const u32x4 rw = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};

@@ -13,7 +13,8 @@ def build(name, opts):
     inc = os.path.join(bdir, f"gemm_loop_{name}.inc")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_asm.py"), "--out", inc] + opts, check=True)
     obj = os.path.join(bdir, f"gemm_asm_{name}.o")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f'-DGEMM_ASM_LOOP_INC="{inc}"', "-x", "hip", "-c",
+    extra = ["-DGEMM_ASM_REG=1"] if "stage=reg" in opts else []
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f'-DGEMM_ASM_LOOP_INC="{inc}"'] + extra + ["-x", "hip", "-c",
                     os.path.join(PKG, "csrc", "gemm_asm.hip"), "-o", obj], check=True)
     objs = []
     for sub in ("csrc", "host"):
@@ -37,6 +38,11 @@ def measure():
         fn = lambda: ltxhip.ops.linear(x, w, None)
         t = min(timeit(fn, iters=10, warm=2) for _ in range(3))
         res[name] = round(2 * M * N * K / t / 1e9, 1)
+    if tile != "big":                      # bit-identity against gemm_big on a ragged shape (M, N not multiples of the tile, short K)
+        x = torch.randn(3001, 320, device="cuda").bfloat16(); w = (torch.randn(4104, 320, device="cuda") / 18).bfloat16(); b = torch.randn(4104, device="cuda").bfloat16()
+        y = ltxhip.ops.linear(x, w, b)
+        os.environ["LTX_GEMM_ASM"] = "0"; ref = ltxhip.ops.linear(x, w, b); os.environ["LTX_GEMM_ASM"] = "1"
+        res["equal_big"] = bool(torch.equal(y.view(torch.int16), ref.view(torch.int16))); res["max_diff"] = float((y.float() - ref.float()).abs().max())
     # cycles per K-step from the slope over K at fixed 4096 x 4096 (256 tiles = one per CU), assuming 2.0 GHz
     res["us_per_kstep"] = round((2 * 4096 * 4096 * 16384 / res["k16k"] / 1e6 - 2 * 4096 ** 3 / res["sq4096"] / 1e6) / (256 - 64), 4)
     print(json.dumps(res), flush=True)

@@ -108,6 +108,120 @@ def gen(BM, BN, WGM, WGN, opt=None):
         emit("s_add_u32 %[ak], %[ak], 128")
         emit("s_add_u32 %[bk], %[bk], 128")
 
+    REG = str(opt.get("stage", "dma")) == "reg"
+    if REG: assert NT <= 16 and AI + BI == 16, "register staging: 128 staging registers = two K-steps of 16 pieces"
+
+    def RS(r, p): return 112 + 64 * r + 4 * p
+
+    def gload(r, p):
+        """piece p of a K-step into register set r (coalesced 128-byte rows, no swizzle: that is applied by the LDS write)"""
+        if "nodma" in abl: return None
+        if p < AI: return f"buffer_load_dwordx4 v[{RS(r, p)}:{RS(r, p) + 3}], v{88 + p}, %[ra], %[asoff] offen"
+        return f"buffer_load_dwordx4 v[{RS(r, p)}:{RS(r, p) + 3}], v{88 + p}, %[rw], %[bsoff] offen"
+
+    def lwrite(stage, r, p):
+        if "nodma" in abl or "nowrite" in abl: return None
+        imm = p * 4096 if p < AI else BM * 128 + (p - AI) * 4096
+        return f"ds_write_b128 v{104 + stage}, v[{RS(r, p)}:{RS(r, p) + 3}] offset:{imm}"
+
+    def kstep_reg(stage, wr):
+        """K-step reading LDS `stage`; register set `wr` (the NEXT K-step's operands, loaded one K-step ago) goes to LDS stage ^ 1,
+        set wr ^ 1 receives the operands of the K-step after that.  Per sixteen-deep step: the next step's 8 fragment reads
+        in the first gaps, then global loads and LDS writes; the step boundary waits with a COUNTED lgkmcnt for the reads
+        only (LDS operations retire in order: the writes issued after them stay in flight); the K-step ends with
+        lgkmcnt(0) + barrier and NO vmcnt wait."""
+        ld = wr ^ 1
+        emit("s_cmp_le_u32 %[cnt], 2")
+        emit("s_cselect_b32 %[asoff], 0x80000000, %[ak]")
+        emit("s_cselect_b32 %[bsoff], 0x80000000, %[bk]")
+        lper = [int(x) for x in str(opt.get("reg_loads", "4,4,4,4")).split(",")]
+        wper = [int(x) for x in str(opt.get("reg_writes", "6,5,5,0")).split(",")]
+        assert sum(lper) == 16 and sum(wper) == 16
+        counted = int(opt.get("lgkm_counted", 1))
+        lp = wp = 0                                    # pieces loaded / written so far in this K-step
+        pending_w = 0                                  # LDS writes issued after the last fragment read
+        for s16 in range(4):
+            cur, nxt = s16 & 1, (s16 & 1) ^ 1
+            emit(f"s_waitcnt lgkmcnt({min(pending_w, 15) if counted else 0})")
+            pending_w = 0
+            slots = [[] for _ in range(NT)]
+            if s16 < 3:
+                rd = reads(stage, s16 + 1, nxt)
+                for i, r in enumerate(rd): slots[min(i, NT - 1)].append(r)
+                free = list(range(len(rd), NT)) or [NT - 1]
+            else:
+                half = NT // 2
+                slots[half - 1] += ["s_waitcnt lgkmcnt(0)"] + ([] if "nobar" in abl else ["s_barrier"])
+                rd = reads(stage ^ 1, 0, nxt)
+                for i, r in enumerate(rd): slots[min(half + i // 2, NT - 1)].append(r)
+                free = list(range(0, half - 1)) or [0]
+            seq = []                                   # loads and writes of this step, alternating
+            nl, nw = lper[s16], wper[s16]
+            for i in range(max(nl, nw)):
+                if i < nl: seq.append("L")
+                if i < nw: seq.append("W")
+            for i, kind in enumerate(seq):
+                g = free[(i * len(free)) // len(seq)]
+                if kind == "L":
+                    l = gload(ld, lp); lp += 1
+                    if l: slots[g].append(l)
+                else:
+                    w = lwrite(stage ^ 1, wr, wp)
+                    if w:
+                        q = lp if "nodma" not in abl else 0
+                        slots[g].append(f"s_waitcnt vmcnt({15 - wp + q})")          # load `wp` of the older batch has landed
+                        slots[g].append(w); pending_w += 1
+                    wp += 1
+            i = 0
+            for nb in range(NB):
+                for mb in range(MB):
+                    if "nomfma" not in abl:
+                        emit(f"v_mfma_f32_32x32x16_bf16 {acc(nb, mb)}, {wfrag(cur, nb)}, {afrag(cur, mb)}, {acc(nb, mb)}")
+                    for ins in slots[i]: emit(ins)
+                    i += 1
+        assert lp == 16 and wp == 16
+        emit("s_add_u32 %[ak], %[ak], 128")
+        emit("s_add_u32 %[bk], %[bk], 128")
+
+    if REG:
+        emit("s_nop 15")
+        emit("s_mov_b32 %[asoff], %[ak]")
+        emit("s_mov_b32 %[bsoff], %[bk]")
+        for p in range(16):
+            l = gload(1, p)
+            if l: emit(l)
+        emit("s_add_u32 %[asoff], %[ak], 128")
+        emit("s_add_u32 %[bsoff], %[bk], 128")
+        for p in range(16):
+            l = gload(0, p)
+            if l: emit(l)
+        emit("s_add_u32 %[ak], %[ak], 256")               # the K position of the loads issued inside K-step 0
+        emit("s_add_u32 %[bk], %[bk], 256")
+        for t in range(NT):
+            for r in range(16): emit(f"v_accvgpr_write_b32 a{16 * t + r}, 0")
+        emit("s_waitcnt vmcnt(16)")
+        for p in range(16):
+            w = lwrite(0, 1, p)
+            if w: emit(w)
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_barrier")
+        for ins in reads(0, 0, 0): emit(ins)
+        emit("1:")
+        kstep_reg(0, 0)
+        emit("s_add_i32 %[cnt], %[cnt], -1")
+        emit("s_cmp_eq_u32 %[cnt], 0")
+        emit("s_cbranch_scc1 2f")
+        kstep_reg(1, 1)
+        emit("s_add_i32 %[cnt], %[cnt], -1")
+        emit("s_cmp_eq_u32 %[cnt], 0")
+        emit("s_cbranch_scc0 1b")
+        emit("2:")
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_nop 15")
+        emit("s_nop 15")
+        return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, REG=True)
+
     # ---- prologue: first K-step's operands, zeroed accumulators under their flight, first fragments
     emit("s_nop 15")
     emit("s_mov_b32 %[asoff], %[ak]")
@@ -154,6 +268,7 @@ def c_function(name, BM, BN, WGM, WGN, opt=None):
         sig += ", f32x32& cv0, f32x32& cv1"
         outs += ', "={v[112:143]}"(cv0), "={v[144:175]}"(cv1)'
     clob = [f'"v{i}"' for i in range(0, 72)] + ['"scc"', '"memory"']
+    if d.get("REG"): clob = [f'"v{i}"' for i in range(0, 72)] + [f'"v{i}"' for i in range(112, 240)] + ['"scc"', '"memory"']
     return f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  {len(lines)} instructions: tile {BM} x {BN}, waves {WGM} x {WGN}.
 __device__ __forceinline__ void gemm_asm_loop_{name}({sig}, const u32x16& rbase, const u32x16& dma0, const u32x2& dma1,
         const u32x4& ra, const u32x4& rw, int cnt, uint32_t ak, uint32_t bk, uint32_t ldsw) {{
@@ -178,7 +293,9 @@ def main():
             k, v = a.split("="); opt[k] = v
     with open(out, "w") as f:
         for name, (BM, BN, WGM, WGN) in TILES.items():
-            f.write(c_function(name.replace("x", "_"), BM, BN, WGM, WGN, opt))
+            o = dict(opt)
+            if str(o.get("stage", "dma")) == "reg" and (BM // 32 + BN // 32 != 16 or (BM // WGM // 32) * (BN // WGN // 32) > 16): o["stage"] = "dma"
+            f.write(c_function(name.replace("x", "_"), BM, BN, WGM, WGN, o))
             f.write("\n")
     print("wrote", out, opt)
 
