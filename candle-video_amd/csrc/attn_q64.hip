@@ -27,7 +27,14 @@
 //     first tile's maximum by ~127 in log2 units).  Overflow leaves inf/NaN in l or O^T, which is checked once per
 //     block; the block then computes the exact row maxima over all keys (plain loads, no pipeline) and runs again
 //     with those: a slow, always-correct path that ordinary activations never take.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "kernels.h"
 
@@ -147,9 +154,19 @@ __device__ __forceinline__ void store_o64(const f32x16 (&acc_o)[2], float inv, b
     }
 }
 
-// One workgroup: queries [q_first, q_first + 128*QB) of (batch b, head).  QB = 32-query column blocks per wave.
+// Slab of one key-range part of a split 256-query block (persistent kernel below): per wave 16 fragment groups of O^T
+// (a[4g:4g+3] of the generated loop = acc_o[g >> 3][(g >> 2) & 1][4 * (g & 3) ..]) and one group (own l of q0, of q1, -m of
+// q0, of q1), each group 64 lanes x 16 B.  Written with write-through (sc1) 16-byte stores and read back by the merging
+// workgroup with sc1 loads behind the arrival ticket (MI355X guide, hand-off table row 1: no fences).
+constexpr int SLAB_GROUPS = 17, SLAB_WAVE_F = SLAB_GROUPS * 256, SLAB_F = 4 * SLAB_WAVE_F;     // floats
+__device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld16_sc1(const float* p) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); return v; }
+
+// One workgroup: queries [q_first, q_first + 128*QB) of (batch b, head) against the keys [k_row0, k_row0 + Sk).
+// QB = 32-query column blocks per wave.  slab == nullptr: the keys are all keys, the result is normalised and stored;
+// slab != nullptr (QB = 2): a key-range part - un-normalised O^T, l and -m go to the slab (merge: attn_q64_merge).
 template <int QB>
-__device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char* smem, int b, int head, int q_first) {
+__device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char* smem, int b, int head, int q_first, int k_row0, int Sk, float* slab) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int q0 = q_first + wave * 32 * QB;
@@ -157,10 +174,10 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * 64;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * 64;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * 64;
-    const int nt = (a.Sk + BKV - 1) / BKV;
-    const bool ragged = (a.Sk % BKV) != 0;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + ((int64_t)b * a.Sk + k_row0) * a.ldk + head * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + ((int64_t)b * a.Sk + k_row0) * a.ldv + head * 64;
+    const int nt = (Sk + BKV - 1) / BKV;
+    const bool ragged = (Sk % BKV) != 0;
 
     // Q^T operand fragments (B operand: k = d, col = query); rows past Sq repeat the last one (never stored)
     bf16x8 qf[QB][4];
@@ -179,8 +196,8 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
     __amdgpu_buffer_rsrc_t rk_rsrc, rv_rsrc;
     uint32_t k_voff[PW], v_voff[PW];
     {
-        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + 128u;
-        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
+        const uint32_t k_bytes = (uint32_t)(Sk - 1) * (uint32_t)a.ldk * 2u + 128u;
+        const uint32_t v_bytes = (uint32_t)(Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
         rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
         rv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
 #pragma unroll
@@ -194,7 +211,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
     u32x4 rk_words, rv_words;
     {
         const uint64_t kp = (uint64_t)(uintptr_t)K, vp = (uint64_t)(uintptr_t)V;
-        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + 128u, v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
+        const uint32_t k_bytes = (uint32_t)(Sk - 1) * (uint32_t)a.ldk * 2u + 128u, v_bytes = (uint32_t)(Sk - 1) * (uint32_t)a.ldv * 2u + 128u;
         rk_words = (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kp >> 32)) & 0xffffu,
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)k_bytes), 0x00020000u};
         rv_words = (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vp >> 32)) & 0xffffu,
@@ -284,7 +301,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= a.Sk) s[qb][kb][i] = -INFINITY;
+                    if (key >= Sk) s[qb][kb][i] = -INFINITY;
                 }
     };
     auto qk_mfma = [&](f32x16& s, const bf16x8& k, const bf16x8& q, const f32x16& init, auto first_tag) {
@@ -562,11 +579,16 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
             ooff[qb] = qr < a.Sq ? (uint32_t)qr * (uint32_t)a.ldo * 2u + 16u * h : 0x80000000u;     // rows past Sq: out of range, dropped
         }
         const uint64_t qp = (uint64_t)(uintptr_t)Q;
-        const uint64_t op = (uint64_t)(uintptr_t)(reinterpret_cast<bf16_t*>(a.o) + (int64_t)b * a.Sq * a.ldo + head * 64);
+        uint64_t op = (uint64_t)(uintptr_t)(reinterpret_cast<bf16_t*>(a.o) + (int64_t)b * a.Sq * a.ldo + head * 64);
+        uint32_t o_bytes = (uint32_t)(a.Sq - 1) * (uint32_t)a.ldo * 2u + 128u;
+        if (slab) {                                         // part: this wave's 17 KiB of the slab, lane-linear 16-byte groups
+            op = (uint64_t)(uintptr_t)(slab + wave * SLAB_WAVE_F); o_bytes = SLAB_WAVE_F * 4u;
+            ooff[0] = (uint32_t)lane * 16u; ooff[1] = 0u;
+        }
         const u32x4 rq_words = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qp >> 32)) & 0xffffu,
                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a.Sq - 1) * (uint32_t)a.ldq * 2u + 128u)), 0x00020000u};
         const u32x4 ro_words = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)op), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(op >> 32)) & 0xffffu,
-                                (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a.Sq - 1) * (uint32_t)a.ldo * 2u + 128u)), 0x00020000u};
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)o_bytes), 0x00020000u};
         const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
         const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
         const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
@@ -581,7 +603,12 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
         bool bad = false;
         if constexpr (QB == 2) {
             f32x8 la;
+#if Q64_STAMP
             q64_full_qb2(la, ones_u, kbase_u, tr_u, dma_u, qoff, ooff, sel, rk_words, rv_words, rq_words, ro_words, nt_u, kstep, vstep, ldsw Q64_STF);
+#else
+            if (slab) q64_part_qb2(la, ones_u, kbase_u, tr_u, dma_u, qoff, ooff, sel, rk_words, rv_words, rq_words, ro_words, nt_u, kstep, vstep, ldsw);
+            else q64_full_qb2(la, ones_u, kbase_u, tr_u, dma_u, qoff, ooff, sel, rk_words, rv_words, rq_words, ro_words, nt_u, kstep, vstep, ldsw);
+#endif
             const float l0 = (lane & 16) ? la[1] : la[0], l1 = (lane & 16) ? la[5] : la[4];
             bad = !(l0 < 0x1p100f) || !(l1 < 0x1p100f);
         } else {
@@ -618,7 +645,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) mx[qb] = -INFINITY;
             for (int kb = 0; kb < 2 * nt; ++kb) {
-                int key = kb * 32 + r; if (key > a.Sk - 1) key = a.Sk - 1;     // rows past Sk repeat the last key: harmless for a maximum
+                int key = kb * 32 + r; if (key > Sk - 1) key = Sk - 1;     // rows past Sk repeat the last key: harmless for a maximum
                 bf16x8 kk[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) kk[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * a.ldk + 16 * ks + 8 * h);
@@ -669,6 +696,16 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
+    if (slab) {                                             // key-range part: the generated part epilogue's slab image
+        float* sw = slab + wave * SLAB_WAVE_F + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 8 * QB; ++g) {
+            const f32x16& o = acc_o[g >> 3][(g >> 2) & 1];
+            st16_sc1(sw + g * 256, (f32x4){o[4 * (g & 3)], o[4 * (g & 3) + 1], o[4 * (g & 3) + 2], o[4 * (g & 3) + 3]});
+        }
+        st16_sc1(sw + 16 * 256, (f32x4){own_l(0), QB == 2 ? own_l(QB - 1) : 0.f, -m_fix[0], -m_fix[QB - 1]});
+        return;
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float inv = 1.0f / own_l(qb);
@@ -697,23 +734,337 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnArgs a, int 
     int head, qb;
     if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / n); qb = j % n; }
     else { head = L / n; qb = L - head * n; }
-    if (big) attn_q64_block<2>(a, smem, b, head, qb * 256);
-    else attn_q64_block<1>(a, smem, b, head, nbig * 256 + qb * 128);
+    if (big) attn_q64_block<2>(a, smem, b, head, qb * 256, 0, a.Sk, nullptr);
+    else attn_q64_block<1>(a, smem, b, head, nbig * 256 + qb * 128, 0, a.Sk, nullptr);
+}
+
+// ---- persistent form: one workgroup per CU walks a static list of items ---------------------------------------------
+// The one-block-per-(head, 256 queries) grid above runs 2.44 rounds of work in 2 + 0.70 rounds at S = 4992 (the last
+// round as 128-query blocks at 70 % of a big block's time each).  Here the host cuts the work evenly: every CU gets
+// whole blocks plus ONE key range ("part") of a block that is shared with one or two other CUs; the parts of a block
+// leave un-normalised (O^T, l, m) in slabs and the workgroup that draws the last arrival ticket merges them
+// (O = sum_p 2^(m_p - M) O_p in part order: the result does not depend on who merges).  No workgroup ever waits for another.
+struct Q64Item { int b, head, q_first, kind, k_row0, Sk, slab0, part, nparts, cnt; };   // kind: QB (2 = 256 queries, 1 = 128)
+
+// the merging workgroup: all parts of the block are in their slabs (ticket), this wave's 64 queries
+__device__ __forceinline__ void attn_q64_merge(const AttnArgs& a, const Q64Item& it, const float* slabs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const float* base = slabs + (int64_t)it.slab0 * SLAB_F + wave * SLAB_WAVE_F + lane * 4;
+    constexpr int MAXP = 8;
+    float negm[2][MAXP], lp[2][MAXP];
+    float negM[2] = {INFINITY, INFINITY};
+    for (int p = 0; p < it.nparts; ++p) {
+        f32x4 t = ld16_sc1(base + (int64_t)p * SLAB_F + 16 * 256);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t));
+        lp[0][p] = t[0]; lp[1][p] = t[1]; negm[0][p] = t[2]; negm[1][p] = t[3];
+        negM[0] = fminf(negM[0], t[2]); negM[1] = fminf(negM[1], t[3]);
+    }
+    f32x16 acc[2][2];
+    float L[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[qb][d][i] = 0.f;
+    for (int p = 0; p < it.nparts; ++p) {
+        const float f0 = __builtin_amdgcn_exp2f(negM[0] - negm[0][p]), f1 = __builtin_amdgcn_exp2f(negM[1] - negm[1][p]);   // 2^(m_p - M) <= 1
+        L[0] += f0 * lp[0][p]; L[1] += f1 * lp[1][p];
+        const float* sp = base + (int64_t)p * SLAB_F;
+        f32x4 g[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = ld16_sc1(sp + i * 256);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),
+                     "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]), "+v"(g[13]), "+v"(g[14]), "+v"(g[15]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float f = i < 8 ? f0 : f1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i >> 3][(i >> 2) & 1][4 * (i & 3) + j] += f * g[i][j];
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = it.q_first + wave * 64 + 32 * qb + r;
+        if (qr < a.Sq) {
+            bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)it.b * a.Sq + qr) * a.ldo + it.head * 64;
+            store_o64(acc[qb], 1.0f / L[qb], O, h, a.wide_o != 0);
+        }
+    }
+}
+
+#ifndef Q64_TRACE
+#define Q64_TRACE 0            // 1 (diagnostic builds): s_memrealtime stamps per item of the persistent kernel (ltx_dbg_q64_trace)
+#endif
+#if Q64_TRACE
+__device__ unsigned long long q64_trace[512 * 8 * 4];   // [workgroup][item][start, block done, published, merged] in 10 ns ticks
+#define Q64_TR(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && i - i0 < 8) q64_trace[(blockIdx.x * 8 + (i - i0)) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Q64_TR(slot) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256, 1) void attn_q64_persist_kernel(const AttnArgs a, const Q64Item* __restrict__ items, const int* __restrict__ first,
+                                                                   float* slabs, unsigned* cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * TILE_BYTES + 16];
+    volatile unsigned* last_flag = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF + 4);
+    const int i0 = first[blockIdx.x], i1 = first[blockIdx.x + 1];
+    for (int i = i0; i < i1; ++i) {
+        const Q64Item it = items[i];
+        if (i > i0) __syncthreads();                        // every wave is done with the ring (and the flags) of the previous item
+        Q64_TR(0);
+        if (it.kind == 2) {
+            float* slab = it.nparts > 1 ? slabs + (int64_t)(it.slab0 + it.part) * SLAB_F : nullptr;
+            attn_q64_block<2>(a, smem, it.b, it.head, it.q_first, it.k_row0, it.Sk, slab);
+            Q64_TR(1);
+            if (slab) {
+                // publish: every storing wave drains its sc1 stores, the workgroup meets, ONE lane draws the ticket
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const unsigned ticket = __hip_atomic_fetch_add(cnt + it.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned last = ticket == (unsigned)it.nparts - 1u;
+                    if (last) __hip_atomic_store(cnt + it.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // handed back at zero
+                    *last_flag = last;
+                }
+                __syncthreads();
+                Q64_TR(2);
+                if (*last_flag) attn_q64_merge(a, it, slabs);
+#if Q64_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                Q64_TR(3);
+            }
+        } else {
+            attn_q64_block<1>(a, smem, it.b, it.head, it.q_first, it.k_row0, it.Sk, nullptr);
+            Q64_TR(1);
+        }
+    }
 }
 
 }  // namespace
+#if Q64_TRACE
+extern "C" int ltx_dbg_q64_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(q64_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
+// ---- host side of the persistent form: the static item lists ----------------------------------------------------------
+namespace {
+struct Q64Plan { Q64Item* items = nullptr; int* first = nullptr; int grid = 0, nslab = 0, ncnt = 0; };
+struct Q64Ws { float* slabs = nullptr; size_t slab_f = 0; unsigned* cnt = nullptr; size_t ncnt = 0; };
+std::map<std::tuple<int, int, int, int, int, int>, Q64Plan> g_q64_plans;     // (device, B, heads, Sq, Sk, xcd order)
+std::map<std::pair<int, hipStream_t>, Q64Ws> g_q64_ws;
+std::mutex g_q64_mu;
+
+constexpr int Q64_SMALL_PCT = 70;        // a 128-query block's key tile costs 70 % of a 256-query block's (measured)
+constexpr int Q64_MIN_PART = 8;          // key tiles: shorter parts are not worth a publish + merge (a block has at most 4 parts)
+constexpr int Q64_PART_OVH = 8;          // what a part costs beyond its tiles, in key tiles of a 256-query block (prologue, slab publish, merge duty)
+
+// Cuts the blocks of the (batch, head) pairs `bh` over `ncu` workgroups.  Every workgroup's list: its parts first (the
+// merges then happen early, off the tail of the launch), then its whole blocks.
+void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int Sk, int ncu, std::vector<std::vector<Q64Item>>& lists,
+                        int& nslab, int& ncnt) {
+    const int nt = Sk / 64;
+    struct Blk { int b, head, q_first; };
+    std::vector<Blk> bigs, smalls;
+    const int nfull = Sq / 256, rest = Sq - nfull * 256;
+    // head-major: the blocks in flight at any time belong to few heads (their K/V stay in the XCD's L2); the tape (the
+    // tail of this list) is cut from the last head(s)
+    for (const auto& p : bh) {
+        for (int i = 0; i < nfull + (rest > 128 ? 1 : 0); ++i) bigs.push_back({p.first, p.second, i * 256});
+        if (rest > 0 && rest <= 128) smalls.push_back({p.first, p.second, nfull * 256});
+    }
+    const int64_t big_cost = (int64_t)nt * 100, small_cost = (int64_t)nt * Q64_SMALL_PCT;
+    const int64_t total = big_cost * (int64_t)bigs.size() + small_cost * (int64_t)smalls.size();
+    const int64_t target = (total + ncu - 1) / ncu;
+    std::vector<int64_t> load(ncu, 0);
+    std::vector<std::vector<Q64Item>> whole(ncu);
+    for (size_t i = 0; i < smalls.size(); ++i) {
+        const int c = (int)(i % ncu);
+        whole[c].push_back({smalls[i].b, smalls[i].head, smalls[i].q_first, 1, 0, Sk, 0, 0, 1, 0});
+        load[c] += small_cost;
+    }
+    size_t nb = 0;                                          // whole bigs: as many as fit under the target, dealt round by round
+    for (bool any = true; any;) {
+        any = false;
+        for (int c = 0; c < ncu && nb < bigs.size(); ++c)
+            if (load[c] + big_cost <= target) {
+                whole[c].push_back({bigs[nb].b, bigs[nb].head, bigs[nb].q_first, 2, 0, Sk, 0, 0, 1, 0});
+                load[c] += big_cost; ++nb; any = true;
+            }
+    }
+    // the tape: the remaining bigs.  Every workgroup takes at most ONE part (a part costs a prologue and a slab publish on top
+    // of its tiles: Q64_PART_OVH), every block is covered by 1..4 workgroups.  The smallest makespan T for which that works
+    // is found by bisection; for a given T a workgroup can take cap = (T - load) / 100 - overhead tiles, and the blocks are
+    // covered greedily: the roomiest workgroup left, completed by the tightest one that still closes the block.
+    const int ntape = (int)(bigs.size() - nb);
+    struct Cut { int cu, t0, t1; };
+    std::vector<std::vector<Cut>> cuts(ntape);
+    auto cover = [&](int64_t T, bool commit) {
+        std::vector<std::pair<int, int>> caps;             // (cap tiles, cu), ascending
+        for (int c = 0; c < ncu; ++c) {
+            int64_t cap = (T - load[c]) / 100 - Q64_PART_OVH;
+            if (cap >= nt) cap = nt; else if (cap < Q64_MIN_PART) continue;
+            caps.push_back({(int)cap, c});
+        }
+        std::sort(caps.begin(), caps.end());
+        std::vector<char> used(caps.size(), 0);
+        int hi = (int)caps.size() - 1;
+        for (int k = 0; k < ntape; ++k) {
+            std::vector<std::pair<int, int>> team;           // (cap, cu)
+            int sum = 0;
+            while (sum < nt && (int)team.size() < 4) {
+                while (hi >= 0 && used[hi]) --hi;
+                if (hi < 0) return false;
+                // the tightest unused workgroup that closes the block, else the roomiest
+                const int need = nt - sum;
+                int pick = -1;
+                if (!team.empty()) {
+                    auto it = std::lower_bound(caps.begin(), caps.end(), std::make_pair(need, -1));
+                    for (int j = (int)(it - caps.begin()); j < (int)caps.size(); ++j) if (!used[j]) { pick = j; break; }
+                }
+                if (pick < 0) pick = hi;
+                used[pick] = 1; team.push_back(caps[pick]); sum += caps[pick].first;
+            }
+            if (sum < nt) return false;
+            if (!commit) continue;
+            // cut the block in proportion to the caps (every part <= its cap, >= Q64_MIN_PART by construction of caps unless scaled below)
+            std::sort(team.begin(), team.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.second < y.second; });
+            int pos = 0; double acc = 0.0;
+            for (size_t i = 0; i < team.size(); ++i) {
+                acc += (double)team[i].first * nt / sum;
+                int end = i + 1 == team.size() ? nt : (int)(acc + 0.5);
+                if (end - pos < 1) end = pos + 1;
+                if (end > nt) end = nt;
+                cuts[k].push_back({team[i].second, pos, end});
+                pos = end;
+            }
+        }
+        return true;
+    };
+    if (ntape > 0) {
+        int64_t lo = target, hi = target + (int64_t)(2 * nt + Q64_PART_OVH) * 100;
+        while (!cover(hi, false)) hi += (int64_t)nt * 100;                    // always ends: with cap = nt every block is one workgroup's
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (cover(mid, false)) hi = mid; else lo = mid + 1; }
+        (void)cover(hi, true);
+    }
+    lists.assign(ncu, {});
+    for (int k = 0; k < ntape; ++k) {
+        const Blk& bk = bigs[nb + k];
+        const int np = (int)cuts[k].size();
+        const int slab0 = np > 1 ? nslab : 0, cn = np > 1 ? ncnt : 0;
+        if (np > 1) { nslab += np; ++ncnt; }
+        for (int p = 0; p < np; ++p)
+            lists[cuts[k][p].cu].push_back({bk.b, bk.head, bk.q_first, 2, cuts[k][p].t0 * 64, (cuts[k][p].t1 - cuts[k][p].t0) * 64, slab0, p, np, cn});
+    }
+    for (int c = 0; c < ncu; ++c) for (const auto& w : whole[c]) lists[c].push_back(w);
+}
+}  // namespace
+
+// tuning / test aid: the schedule as text ("cu: kind head q_first k_row0 Sk part/nparts | ...")
+extern "C" int ltx_dbg_q64_schedule(int B, int heads, int Sq, int Sk, int n_cu, int xcd, char* out, int cap) {
+    std::vector<std::vector<Q64Item>> all(n_cu);
+    int nslab = 0, ncnt = 0;
+    const int G = xcd ? 8 : 1;
+    for (int x = 0; x < G; ++x) {
+        std::vector<std::pair<int, int>> bh;
+        for (int b = 0; b < B; ++b) for (int h = 0; h < heads; ++h) if (!xcd || (h & 7) == x) bh.push_back({b, h});
+        std::vector<std::vector<Q64Item>> lists;
+        q64_schedule_group(bh, Sq, Sk, n_cu / G, lists, nslab, ncnt);
+        for (int c = 0; c < n_cu / G; ++c) all[c * G + x] = lists[c];
+    }
+    std::string t;
+    for (int c = 0; c < n_cu; ++c) {
+        t += std::to_string(c) + ":";
+        for (const auto& it : all[c]) t += " " + std::to_string(it.kind) + "," + std::to_string(it.b) + "," + std::to_string(it.head) + "," + std::to_string(it.q_first) + "," + std::to_string(it.k_row0) + "," +
+                                          std::to_string(it.Sk) + "," + std::to_string(it.part) + "/" + std::to_string(it.nparts) + "," + std::to_string(it.slab0) + "," + std::to_string(it.cnt);
+        t += "\n";
+    }
+    if ((int)t.size() + 1 > cap) return (int)t.size() + 1;
+    memcpy(out, t.c_str(), t.size() + 1);
+    return 0;
+}
+
+static int q64_n_cu() {
+    static std::mutex mu; static std::map<int, int> per_dev;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_dev.find(dev);
+    if (it != per_dev.end()) return it->second;
+    hipDeviceProp_t p; int n = 256;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    per_dev[dev] = n;
+    return n;
+}
+
+// 32-bit buffer arithmetic of the kernels above: every row offset (and the "dropped row" offset 0x80000000) must stay below 2^31
+bool ltx_attention_q64_fits(const AttnArgs& a) {
+    const double lim = 2147483648.0 - 256.0;
+    return (double)a.Sk * a.ldk * 2.0 < lim && (double)a.Sk * a.ldv * 2.0 < lim && (double)a.Sq * a.ldq * 2.0 < lim && (double)a.Sq * a.ldo * 2.0 < lim;
+}
+
+static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    const int xcd = (a.xcd_heads && n_cu % 8 == 0) ? 1 : 0;
+    Q64Plan plan; Q64Ws ws;
+    {
+        std::lock_guard<std::mutex> lock(g_q64_mu);
+        const auto key = std::make_tuple(dev, a.B, a.heads, a.Sq, a.Sk, xcd);
+        auto it = g_q64_plans.find(key);
+        if (it == g_q64_plans.end()) {
+            std::vector<Q64Item> flat; std::vector<int> first(n_cu + 1, 0);
+            std::vector<std::vector<Q64Item>> all(n_cu);
+            int nslab = 0, ncnt = 0;
+            const int G = xcd ? 8 : 1;
+            for (int x = 0; x < G; ++x) {
+                std::vector<std::pair<int, int>> bh;
+                for (int b = 0; b < a.B; ++b) for (int h = 0; h < a.heads; ++h) if (!xcd || (h & 7) == x) bh.push_back({b, h});
+                std::vector<std::vector<Q64Item>> lists;
+                q64_schedule_group(bh, a.Sq, a.Sk, n_cu / G, lists, nslab, ncnt);
+                for (int c = 0; c < n_cu / G; ++c) all[c * G + x] = lists[c];      // blocks b and b + 8 share an XCD
+            }
+            for (int c = 0; c < n_cu; ++c) { first[c] = (int)flat.size(); flat.insert(flat.end(), all[c].begin(), all[c].end()); }
+            first[n_cu] = (int)flat.size();
+            Q64Plan np; np.grid = n_cu; np.nslab = nslab; np.ncnt = ncnt;
+            HIP_TRY(hipMalloc(&np.items, flat.size() * sizeof(Q64Item) + 16));
+            HIP_TRY(hipMalloc(&np.first, first.size() * sizeof(int)));
+            HIP_TRY(hipMemcpy(np.items, flat.data(), flat.size() * sizeof(Q64Item), hipMemcpyHostToDevice));      // once per shape (ltx_warmup)
+            HIP_TRY(hipMemcpy(np.first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+            it = g_q64_plans.emplace(key, np).first;
+        }
+        plan = it->second;
+        Q64Ws& w = g_q64_ws[std::make_pair(dev, s)];
+        const size_t need_f = (size_t)(plan.nslab > 0 ? plan.nslab : 1) * SLAB_F, need_c = (size_t)(plan.ncnt > 0 ? plan.ncnt : 1);
+        if (w.slab_f < need_f) { if (w.slabs) (void)hipFree(w.slabs); w.slabs = nullptr; HIP_TRY(hipMalloc(&w.slabs, need_f * sizeof(float))); w.slab_f = need_f; }
+        if (w.ncnt < need_c) {
+            const size_t n = need_c < 1024 ? 1024 : need_c;
+            if (w.cnt) (void)hipFree(w.cnt);
+            w.cnt = nullptr; HIP_TRY(hipMalloc(&w.cnt, n * sizeof(unsigned))); w.ncnt = n;
+            HIP_TRY(hipMemsetAsync(w.cnt, 0, n * sizeof(unsigned), s));      // once: every merger hands its counter back at zero
+        }
+        ws = w;
+    }
+    hipLaunchKernelGGL(attn_q64_persist_kernel, dim3((unsigned)plan.grid), dim3(256), 0, s, a, plan.items, plan.first, ws.slabs, ws.cnt);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
 
 // Split of a head's queries into big (256) and small (128) blocks: as many big blocks as fill whole rounds of the
 // chip's CUs (one block per CU), the rest as small blocks that run in about half a big block's time, so the last
 // round of the grid is short instead of running a few long blocks on a mostly idle chip.
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) LTX_FAIL(LTX_ERR_HIP, "attention: device query failed");
-        n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    }
+    const int n_cu = q64_n_cu();
     const int heads_total = a.heads * a.B;
+    {
+        // persistent form (LTX_ATTN_Q64_PERSIST=1; key counts in whole tiles, more work than one round of blocks).  Measured
+        // on MI355X at S = 4992, 32 heads: 183 us against 178 us for the block grid below - a 128-query block costs 0.59 of a
+        // 256-query block (not the 0.70 the split was sized for), and publish + merge cost a workgroup 1.4 + 4.5 (up to 9.5) us,
+        // which is what halving the last round saves.  Kept as a tested option; the block grid stays the default.
+        const char* pe = getenv("LTX_ATTN_Q64_PERSIST");
+        const bool on = pe && pe[0] == '1';
+        const int64_t blocks = (int64_t)heads_total * ((a.Sq + 255) / 256);
+        if (on && a.Sk % 64 == 0 && a.Sk >= 64 * 2 * Q64_MIN_PART && blocks > n_cu && !getenv("LTX_ATTN_Q64_BIG")) return launch_q64_persist(a, n_cu, s);
+    }
     const int nbig_max = a.Sq / 256;                                   // whole big blocks per head
     int nbig = nbig_max;
     if (const char* e = getenv("LTX_ATTN_Q64_BIG")) { nbig = atoi(e); if (nbig > nbig_max) nbig = nbig_max; if (nbig < 0) nbig = 0; }
