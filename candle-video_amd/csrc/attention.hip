@@ -939,7 +939,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         switch (a.hd) {
             case 16: hipLaunchKernelGGL((attn_bf16_kernel<16, false>), grid, block, 0, s, ax); break;
             case 32: hipLaunchKernelGGL((attn_bf16_kernel<32, false>), grid, block, 0, s, ax); break;
-            case 64: if (a.q_prescaled && attn_q64_enabled()) return ltx_launch_attention_q64(ax, s);
+            case 64: if (a.q_prescaled && attn_q64_enabled() && ltx_attention_q64_fits(ax)) return ltx_launch_attention_q64(ax, s);
                      else if (a.q_prescaled && attn_pipe_enabled()) hipLaunchKernelGGL(attn_pipe64_kernel, grid, block, 0, s, ax);
                      else if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
                      else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);

@@ -310,9 +310,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * A_STAGE + 2 * BN * ROWB;
     static std::atomic<unsigned long long> attr_devs{0};
     auto kern = conv_halo_kernel<BN, WGM, WGN, EPI>;
-    if (ltx_once_per_device(attr_devs)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    }
+    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
     GemmArgs ga = g;
     const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)

@@ -176,12 +176,12 @@ extern "C" int ltx_dit_get_config(const ltx_dit* m, ltx_dit_config* out) {
     return LTX_OK;
 }
 
-extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
-                               const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
-                               const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
-                               ltx_dtype io_dtype, void* out, ltx_stream stream) {
-    if (!m || !hidden || !enc || !timestep || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: null argument");
-    if (B < 1 || B > 8) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: batch must be 1..8");
+// one forward of up to 8 batch rows (the per-batch scalars - timesteps, skip-mask rows - travel as kernel arguments)
+static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
+                          const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
+                          const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
+                          ltx_dtype io_dtype, void* out, ltx_stream stream) {
+    if (B < 1 || B > 8) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: internal batch chunk must be 1..8");
     if (S < 1 || K < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: empty sequence");
     if (!video_coords && (int64_t)num_frames * height * width != S)
         LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: num_frames*height*width must equal S when video_coords is absent");
@@ -341,6 +341,35 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
         if (iodt != dt) LTX_TRY(ltx_launch_cast(m->outT.p, dt, out, iodt, M * c.out_channels, s));
     }
     if (!m->ctx_mode) ctx->valid = false;
+    return LTX_OK;
+}
+
+// The trait puts no bound on the batch (t2v_pipeline.rs:68-80).  Batch rows never interact in the forward
+// (ltx_transformer.rs:1029-1172: every op is per row or per (row, token)), so a larger batch runs as chunks of 8 rows with the
+// same results as one call would give.
+extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
+                               const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
+                               const float* rope_scale, const float* video_coords, const float* skip_layer_mask,
+                               ltx_dtype io_dtype, void* out, ltx_stream stream) {
+    if (!m || !hidden || !enc || !timestep || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: null argument");
+    if (B < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_forward: batch must be at least 1");
+    if (B <= 8) return dit_forward_b8(m, hidden, enc, timestep, enc_mask, B, S, K, num_frames, height, width, rope_scale, video_coords, skip_layer_mask, io_dtype, out, stream);
+    const size_t esz = io_dtype == LTX_BF16 ? 2 : 4;
+    const int L = m->cfg.num_layers;
+    std::vector<float> mask_chunk;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        const int bc = B - b0 < 8 ? B - b0 : 8;
+        const float* slm = nullptr;
+        if (skip_layer_mask) {                              // [L, B] -> [L, bc]
+            mask_chunk.resize((size_t)L * bc);
+            for (int l = 0; l < L; ++l) for (int b = 0; b < bc; ++b) mask_chunk[(size_t)l * bc + b] = skip_layer_mask[(size_t)l * B + b0 + b];
+            slm = mask_chunk.data();
+        }
+        LTX_TRY(dit_forward_b8(m, (const char*)hidden + (size_t)b0 * S * m->cfg.in_channels * esz, (const char*)enc + (size_t)b0 * K * m->cfg.caption_channels * esz,
+                               timestep + b0, enc_mask ? enc_mask + (size_t)b0 * K : nullptr, bc, S, K, num_frames, height, width, rope_scale,
+                               video_coords ? video_coords + (size_t)b0 * S * 3 : nullptr, slm, io_dtype,
+                               (char*)out + (size_t)b0 * S * m->cfg.out_channels * esz, stream));
+    }
     return LTX_OK;
 }
 

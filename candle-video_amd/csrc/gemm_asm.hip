@@ -136,7 +136,7 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static std::atomic<unsigned long long> attr_devs{0};
     auto kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
-    if (ltx_once_per_device(attr_devs)) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     GemmArgs ga = g;
     const char* xr = getenv("LTX_XCD_REMAP");
     ga.xcd_remap = xr ? (xr[0] == '1') : 1;

@@ -457,9 +457,7 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
     static std::atomic<unsigned long long> attr_devs{0};
     // PIN = true: the pinned fragment-stream schedule (A/B on MI355X: linear +-1 %, conv +1..4 % over the compiler's order)
     auto kern = gemm_big_kernel<BM, BN, WGM, WGN, EPI, CONV, true>;
-    if (ltx_once_per_device(attr_devs)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    }
+    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
     LTX_TRY(plan_tail_split(&ga, tiles, BM, BN, 64 * WGM * WGN, smem, s));
@@ -582,7 +580,24 @@ struct PlanKey {
 std::map<PlanKey, int> g_plans;
 std::mutex g_plan_mu;
 
+// The predicates tune_plan applies before it measures a plan: a cached / loaded plan must pass them again for the shape
+// it is used on (a stale or hand-edited plan file, or one saved under other LTX_* settings).
+bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
+    if (plan >= kPlanHalo) return plan <= kPlanHalo + 1 && !split_shape;
+    if (plan >= kPlanP8) return plan <= kPlanP8 + 1 && !split_shape && nk >= 2 && N > 64 && !(plan == kPlanP8 && N <= 128);
+    return plan >= 0 && plan < kNumTiles && tile_fits(kTiles[plan], N);
+}
+bool plan_ok(const GemmArgs& g, int epi, int plan) {
+    const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
+    if (!plan_shape_ok(plan, g.N, nk, ltx_gemm_split_factor(g) > 1)) return false;
+    if (plan >= kPlanHalo) return true;                    // run_plan checks the halo kernel's own eligibility (epilogue-dependent)
+    if (plan >= kPlanP8) return ltx_gemm_p8_fits(g);
+    (void)epi;
+    return true;
+}
+
 int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
+    if (!plan_ok(g, epi, plan)) plan = ltx_gemm_big_pick_tile(g.M, g.N);
     if (plan >= kPlanHalo) {
         const int bn = plan == kPlanHalo ? 128 : 256;
         if (ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
@@ -598,8 +613,12 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     void* scratch = nullptr;
     if (hipMalloc(&scratch, (size_t)g.M * g.N * sizeof(bf16_t)) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
     g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    struct Guard {                                           // events and scratch are released on every return path
+        void* scratch; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Guard() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (scratch) (void)hipFree(scratch); }
+    } guard{scratch};
+    HIP_TRY(hipEventCreate(&guard.e0)); HIP_TRY(hipEventCreate(&guard.e1));
+    const hipEvent_t e0 = guard.e0, e1 = guard.e1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     float best = 1e30f;
     const char* p8e = getenv("LTX_GEMM_P8");
@@ -637,8 +656,6 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
             if (ok && ms < best) { best = ms; *plan_out = plan; }     // a plan whose launch failed is never the winner
         }
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    HIP_TRY(hipFree(scratch));
     return LTX_OK;
 }
 }  // namespace
@@ -707,6 +724,14 @@ extern "C" int ltx_plan_load(const char* path) {
         if (sscanf(line, "%d %d %d %d %d %d %d %d %63s", &key.M, &key.N, &key.K, &key.conv, &key.ntaps, &key.T, &key.H, &key.W, name) != 9) { fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: malformed line: ") + line); }
         const int plan = plan_from_name(name);
         if (plan < 0) { fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: unknown plan name: ") + name); }
+        {   // the shape-level predicates of tune_plan (run_plan re-checks the call's own operands and falls back to the static model)
+            GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = key.conv; g.ntaps = key.conv ? key.ntaps : 1;
+            const int nk = (key.K + 63) / 64 * g.ntaps;
+            const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && (!key.conv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0));
+            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanHalo && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
+                fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: plan not valid for its shape: ") + line);
+            }
+        }
         g_plans[key] = plan; ++n;
     }
     fclose(f);

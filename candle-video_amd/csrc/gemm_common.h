@@ -109,12 +109,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
 
 }  // namespace
 
-// hipFuncSetAttribute is per device: a per-kernel-instantiation bit mask of the devices already configured
-// (several devices in one process).  Returns true the first time it is called for the current device.
+// hipFuncSetAttribute is per device: a per-kernel-instantiation bit mask of the devices already configured (several
+// devices in one process).  The check and the call run under one lock and the bit is published only after the call
+// succeeded: a second thread on the same device either waits for the attribute or finds it set, and a failed call is
+// retried by the next launch instead of leaving the kernel permanently mis-configured.
 #include <atomic>
-static inline bool ltx_once_per_device(std::atomic<unsigned long long>& mask) {
+#include <mutex>
+static inline int ltx_set_max_dyn_smem(std::atomic<unsigned long long>& mask, const void* kern, int smem) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const unsigned long long bit = 1ull << dev;
-    return (mask.fetch_or(bit) & bit) == 0;
+    const bool tracked = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    const unsigned long long bit = tracked ? 1ull << dev : 0ull;
+    if (tracked && (mask.load(std::memory_order_acquire) & bit)) return LTX_OK;
+    static std::mutex mu;                                   // one lock for all instantiations: taken once per (kernel, device)
+    std::lock_guard<std::mutex> lock(mu);
+    if (tracked && (mask.load(std::memory_order_acquire) & bit)) return LTX_OK;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    if (tracked) mask.fetch_or(bit, std::memory_order_release);
+    return LTX_OK;
 }

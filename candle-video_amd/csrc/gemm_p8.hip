@@ -262,9 +262,7 @@ int launch_one8(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (2 * 128 * 128 + BN * 128);
     static std::atomic<unsigned long long> attr_devs{0};
     auto kern = gemm_p8_kernel<BN, WGM, WGN, EPI, CONV>;
-    if (ltx_once_per_device(attr_devs)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    }
+    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     dim3 grid((unsigned)(cdiv(g.M, 256) * cdiv(g.N, BN))), block(512);
     hipLaunchKernelGGL(kern, grid, block, smem, s, g);
     LTX_CHECK_LAUNCH();

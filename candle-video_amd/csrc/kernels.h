@@ -113,6 +113,7 @@ struct AttnArgs {
 };
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
+bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row offset below 2^31 (its 32-bit buffer arithmetic)
 bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------

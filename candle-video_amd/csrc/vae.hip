@@ -21,7 +21,7 @@ struct ConvW {
 };
 struct TimeEmbW { LinearW l1, l2; int dim = 0; };
 struct ResnetW { ConvW c1, c2; void* sst = nullptr; };
-struct UpBlockW { ConvW up; TimeEmbW te; std::vector<ResnetW> res; int ch = 0, cin = 0; };
+struct UpBlockW { ConvW up; TimeEmbW te; std::vector<ResnetW> res; int ch = 0, cin = 0; bool residual = true; };
 
 struct ltx_vae {
     ltx_vae_config cfg{};
@@ -158,6 +158,7 @@ int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
     for (int bi = 0; bi < nb; ++bi) {
         UpBlockW& u = v->ups[bi];
         const std::string p = "up_blocks." + std::to_string(bi);
+        u.residual = c.decoder_upsample_residual[nb - 1 - bi] != 0;   // reversed like the other lists (vae.rs:1516-1517)
         u.ch = boc[bi] / upf[bi];                       // vae.rs:1548
         u.cin = u.ch * upf[bi];                         // upsampler in-channels (vae.rs:1215)
         if (u.cin != cur) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder up-block channel chain mismatch");
@@ -295,7 +296,7 @@ int decoder_forward(ltx_vae* v, const void* z, int B, int F, int H, int W, const
     LTX_TRY(conv3d(v, v->conv_in, z, v->X.p, d, EPI_BIAS, nullptr, 0, s));
     for (auto& r : v->mid) LTX_TRY(resnet(v, r, v->mid_te, v->mid_ch, d, tvc, s));
     for (auto& u : v->ups) {
-        LTX_TRY(conv3d(v, u.up, v->X.p, v->Y.p, d, EPI_D2S, v->X.p, 0, s));
+        LTX_TRY(conv3d(v, u.up, v->X.p, v->Y.p, d, EPI_D2S, u.residual ? v->X.p : nullptr, 0, s));   // vae.rs:1164-1168
         std::swap(v->X, v->Y);
         d.T = 2 * d.T - 1; d.H *= 2; d.W *= 2;
         for (auto& r : u.res) LTX_TRY(resnet(v, r, u.te, u.ch, d, tvc, s));
@@ -460,6 +461,15 @@ extern "C" int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weigh
         if (cfg->decoder_upsample_factor[i] < 1 || cfg->decoder_block_out_channels[i] % (8 * cfg->decoder_upsample_factor[i]) != 0)
             LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder channels must be multiples of 8*upsample_factor");
     }
+    {
+        const ltx_vae_config& c = *cfg; const int nb = c.n_blocks;
+    // what this decoder does not implement is refused, not ignored: noise injection draws from the device RNG
+        // (vae.rs:741-753, not reproducible), spatial-only up-blocks use a (1,2,2) depth-to-space (vae.rs:1225-1236)
+        for (int i = 0; i <= nb; ++i)
+            if (c.decoder_inject_noise[i]) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder_inject_noise[" + std::to_string(i) + "] is set: noise injection inside the resnets is not supported");
+        for (int i = 0; i < nb; ++i)
+            if (!c.decoder_spatiotemporal_scaling[i]) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder_spatiotemporal_scaling[" + std::to_string(i) + "] is false: spatial-only (1,2,2) up-blocks are not supported");
+    }
     HIP_TRY(hipSetDevice(device));
     ltx_vae* v = new ltx_vae();
     v->cfg = *cfg; v->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32; v->device = device;
@@ -482,8 +492,14 @@ extern "C" const float* ltx_vae_latents_std(const ltx_vae* v) { return v ? v->st
 
 static int check_decode_args(ltx_vae* v, int B, int F, int H, int W) {
     if (!v) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: null handle");
-    if (B < 1 || B > 8 || F < 1 || H < 1 || W < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: bad shape");
+    if (B < 1 || F < 1 || H < 1 || W < 1) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: bad shape");
     return LTX_OK;
+}
+// The trait has no batch bound (t2v_pipeline.rs:102); samples never interact in the decoder (vae.rs:2107-2121 even decodes them
+// one at a time under use_slicing), so batches beyond the 8 per-sample scalars a launch carries run as chunks of 8.
+static size_t out_elems_per_sample(const ltx_vae* v, int F, int H, int W) {
+    const ltx_vae_config& c = v->cfg;
+    return (size_t)c.out_channels * ((size_t)(F - 1) * c.temporal_compression_ratio + 1) * ((size_t)H * c.spatial_compression_ratio) * ((size_t)W * c.spatial_compression_ratio);
 }
 
 extern "C" int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtype, const float* timestep,
@@ -491,6 +507,13 @@ extern "C" int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtyp
                               float* out, ltx_stream stream) {
     LTX_TRY(check_decode_args(v, B, F, H, W));
     if (!latents || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode: null tensor");
+    if (B > 8) {
+        const size_t in_b = (size_t)v->cfg.latent_channels * F * H * W * (io_dtype == LTX_BF16 ? 2 : 4), out_b = out_elems_per_sample(v, F, H, W);
+        for (int b0 = 0; b0 < B; b0 += 8)
+            LTX_TRY(ltx_vae_decode(v, (const char*)latents + b0 * in_b, io_dtype, timestep ? timestep + b0 : nullptr, B - b0 < 8 ? B - b0 : 8, F, H, W, tiling,
+                                   postprocess, out + b0 * out_b, stream));
+        return LTX_OK;
+    }
     HIP_TRY(hipSetDevice(v->device));
     hipStream_t s = (hipStream_t)stream;
     const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
@@ -506,6 +529,13 @@ extern "C" int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const floa
     LTX_TRY(check_decode_args(v, B, F, H, W));
     if (!tokens || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode_tokens: null tensor");
     if (noise && !noise_scale) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_decode_tokens: noise needs noise_scale");
+    if (B > 8) {
+        const size_t in_e = (size_t)v->cfg.latent_channels * F * H * W, out_b = out_elems_per_sample(v, F, H, W);
+        for (int b0 = 0; b0 < B; b0 += 8)
+            LTX_TRY(ltx_vae_decode_tokens(v, tokens + b0 * in_e, noise ? noise + b0 * in_e : nullptr, noise ? noise_scale + b0 : nullptr, timestep ? timestep + b0 : nullptr,
+                                          B - b0 < 8 ? B - b0 : 8, F, H, W, tiling, postprocess, out + b0 * out_b, stream));
+        return LTX_OK;
+    }
     HIP_TRY(hipSetDevice(v->device));
     hipStream_t s = (hipStream_t)stream;
     const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
@@ -521,6 +551,13 @@ extern "C" int ltx_vae_prepare_latents(ltx_vae* v, const float* tokens, const fl
     LTX_TRY(check_decode_args(v, B, F, H, W));
     if (!tokens || !out_tokens) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_prepare_latents: null tensor");
     if (noise && !noise_scale) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_prepare_latents: noise needs noise_scale");
+    if (B > 8) {
+        const size_t in_e = (size_t)v->cfg.latent_channels * F * H * W;
+        for (int b0 = 0; b0 < B; b0 += 8)
+            LTX_TRY(ltx_vae_prepare_latents(v, tokens + b0 * in_e, noise ? noise + b0 * in_e : nullptr, noise ? noise_scale + b0 : nullptr, B - b0 < 8 ? B - b0 : 8, F, H, W,
+                                            out_tokens + b0 * in_e, stream));
+        return LTX_OK;
+    }
     HIP_TRY(hipSetDevice(v->device));
     const int C = v->cfg.latent_channels; const int64_t S = (int64_t)F * H * W;
     TimeVec ns; ns.n = B; for (int i = 0; i < 8; ++i) ns.t[i] = (noise && i < B) ? noise_scale[i] : 0.f;

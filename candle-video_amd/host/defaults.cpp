@@ -17,6 +17,9 @@ extern "C" void ltx_vae_config_default(ltx_vae_config* c) {
     for (int i = 0; i < 5; ++i) c->decoder_layers_per_block[i] = lpb[i];
     c->patch_size = 4; c->patch_size_t = 1; c->timestep_conditioning = 1; c->decoder_causal = 0;
     c->scaling_factor = 1.0f; c->spatial_compression_ratio = 32; c->temporal_compression_ratio = 8;
+    for (int i = 0; i < 5; ++i) c->decoder_inject_noise[i] = 0;                                   // vae.rs:87
+    for (int i = 0; i < 4; ++i) { c->decoder_upsample_residual[i] = i < 3; c->decoder_spatiotemporal_scaling[i] = i < 3; }   // vae.rs:78, 88
+    c->resnet_eps = 1e-6f;                                                                         // vae.rs:83
 }
 extern "C" void ltx_tiling_default(ltx_tiling* t) {
     t->use_tiling = 1; t->use_framewise_decoding = 1;

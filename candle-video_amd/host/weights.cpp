@@ -396,6 +396,71 @@ extern "C" int ltx_weights_resolve(const char* path, char* out, size_t cap, size
     return LTX_OK;
 }
 
+// AutoencoderKLLtxVideoConfig's serde view of vae/config.json (vae.rs:30-66): field names and aliases, lists in file order
+extern "C" int ltx_vae_config_from_json(const char* json_path, ltx_vae_config* cfg) {
+    if (!json_path || !cfg) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_config_from_json: null argument");
+    std::string text;
+    {
+        FILE* f = fopen(json_path, "rb");
+        if (!f) LTX_FAIL(LTX_ERR_ARG, std::string("cannot open '") + json_path + "'");
+        char buf[4096]; size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) { text.append(buf, n); if (text.size() > (1u << 22)) break; }
+        fclose(f);
+    }
+    JsonParser jp{text.data(), text.data() + text.size(), {}};
+    Json root;
+    if (!jp.value(root) || root.kind != Json::OBJ) LTX_FAIL(LTX_ERR_ARG, std::string("'") + json_path + "': invalid JSON" + (jp.err.empty() ? "" : ": " + jp.err));
+    auto field = [&](const char* name, const char* alias) -> const Json* { const Json* j = root.get(name); return j ? j : (alias ? root.get(alias) : nullptr); };
+    auto bad = [&](const char* name) { ltx_set_error(std::string("'") + json_path + "': field '" + name + "' has the wrong type or length"); return LTX_ERR_ARG; };
+    auto num_i = [&](const char* name, const char* alias, int* dst) -> int {
+        const Json* j = field(name, alias); if (!j) return LTX_OK;
+        if (j->kind != Json::NUM || j->num < 0 || j->num > 1e9 || j->num != (double)(int64_t)j->num) return bad(name);
+        *dst = (int)j->num; return LTX_OK;
+    };
+    auto num_f = [&](const char* name, const char* alias, float* dst) -> int {
+        const Json* j = field(name, alias); if (!j) return LTX_OK;
+        if (j->kind != Json::NUM) return bad(name);
+        *dst = (float)j->num; return LTX_OK;
+    };
+    auto flag = [&](const char* name, const char* alias, int* dst) -> int {
+        const Json* j = field(name, alias); if (!j) return LTX_OK;
+        if (j->kind != Json::BOOL) return bad(name);
+        *dst = j->b ? 1 : 0; return LTX_OK;
+    };
+    // lists: at most `cap` entries; *count (when given) receives the length
+    auto list = [&](const char* name, const char* alias, int* dst, int cap, bool booleans, int* count) -> int {
+        const Json* j = field(name, alias); if (!j) return LTX_OK;
+        if (j->kind != Json::ARR || (int)j->arr.size() > cap) return bad(name);
+        for (size_t i = 0; i < j->arr.size(); ++i) {
+            const Json& e = j->arr[i];
+            if (booleans) { if (e.kind != Json::BOOL) return bad(name); dst[i] = e.b ? 1 : 0; }
+            else { if (e.kind != Json::NUM || e.num < 0 || e.num > 1e9 || e.num != (double)(int64_t)e.num) return bad(name); dst[i] = (int)e.num; }
+        }
+        if (count) *count = (int)j->arr.size();
+        return LTX_OK;
+    };
+    LTX_TRY(num_i("out_channels", nullptr, &cfg->out_channels));
+    LTX_TRY(num_i("latent_channels", nullptr, &cfg->latent_channels));
+    int nb = cfg->n_blocks;
+    LTX_TRY(list("decoder_block_out_channels", nullptr, cfg->decoder_block_out_channels, 4, false, &nb));
+    if (nb < 1) return bad("decoder_block_out_channels");
+    cfg->n_blocks = nb;
+    LTX_TRY(list("decoder_spatiotemporal_scaling", "decoder_spatio_temporal_scaling", cfg->decoder_spatiotemporal_scaling, 4, true, nullptr));
+    LTX_TRY(list("decoder_layers_per_block", nullptr, cfg->decoder_layers_per_block, 5, false, nullptr));
+    LTX_TRY(num_i("patch_size", nullptr, &cfg->patch_size));
+    LTX_TRY(num_i("patch_size_t", nullptr, &cfg->patch_size_t));
+    LTX_TRY(num_f("resnet_eps", "resnet_norm_eps", &cfg->resnet_eps));
+    LTX_TRY(num_f("scaling_factor", nullptr, &cfg->scaling_factor));
+    LTX_TRY(num_i("spatial_compression_ratio", nullptr, &cfg->spatial_compression_ratio));
+    LTX_TRY(num_i("temporal_compression_ratio", nullptr, &cfg->temporal_compression_ratio));
+    LTX_TRY(list("decoder_inject_noise", nullptr, cfg->decoder_inject_noise, 5, true, nullptr));
+    LTX_TRY(list("decoder_upsample_residual", "upsample_residual", cfg->decoder_upsample_residual, 4, true, nullptr));
+    LTX_TRY(list("decoder_upsample_factor", "upsample_factor", cfg->decoder_upsample_factor, 4, false, nullptr));
+    LTX_TRY(flag("timestep_conditioning", nullptr, &cfg->timestep_conditioning));
+    LTX_TRY(flag("decoder_causal", nullptr, &cfg->decoder_causal));
+    return LTX_OK;
+}
+
 #ifndef LTX_HOST_ONLY
 extern "C" int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* path, int unified,
                                          ltx_dtype model_dtype, int device, ltx_dit** out) {
@@ -405,8 +470,21 @@ extern "C" int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* 
 }
 extern "C" int ltx_vae_create_from_files(const ltx_vae_config* cfg, const char* path, int unified,
                                          ltx_dtype model_dtype, int device, ltx_vae** out) {
+    if (!cfg || !path) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_create_from_files: null argument");
+    ltx_vae_config c = *cfg;
+    if (!unified) {                                         // main.rs:525-534: vae/config.json beside the weights replaces the preset's config
+        struct stat st;
+        std::string dir = path;
+        if (!(stat(path, &st) == 0 && S_ISDIR(st.st_mode))) { const size_t k = dir.find_last_of('/'); dir = k == std::string::npos ? "." : dir.substr(0, k); }
+        const std::string cj = dir + "/config.json";
+        if (stat(cj.c_str(), &st) == 0 && S_ISREG(st.st_mode)) {
+            ltx_vae_config_default(&c);                     // serde(default): fields the file lacks take Default::default()
+            LTX_TRY(ltx_vae_config_from_json(cj.c_str(), &c));
+            c.timestep_conditioning = 1;
+        }
+    }
     Loaded L;
     LTX_TRY(gather(path, unified, 1, &L));
-    return ltx_vae_create(cfg, L.weights.data(), L.weights.size(), model_dtype, device, out);
+    return ltx_vae_create(&c, L.weights.data(), L.weights.size(), model_dtype, device, out);
 }
 #endif

@@ -61,7 +61,9 @@ class VaeConfigC(C.Structure):
                 ("decoder_block_out_channels", C.c_int * 4), ("decoder_layers_per_block", C.c_int * 5),
                 ("decoder_upsample_factor", C.c_int * 4), ("patch_size", C.c_int), ("patch_size_t", C.c_int),
                 ("timestep_conditioning", C.c_int), ("decoder_causal", C.c_int), ("scaling_factor", C.c_float),
-                ("spatial_compression_ratio", C.c_int), ("temporal_compression_ratio", C.c_int)]
+                ("spatial_compression_ratio", C.c_int), ("temporal_compression_ratio", C.c_int),
+                ("decoder_inject_noise", C.c_int * 5), ("decoder_upsample_residual", C.c_int * 4),
+                ("decoder_spatiotemporal_scaling", C.c_int * 4), ("resnet_eps", C.c_float)]
 
 
 class TilingC(C.Structure):
@@ -143,6 +145,7 @@ _SIGS = {
     "ltx_safetensors_tensor": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "ltx_weights_resolve": [C.c_char_p, C.c_char_p, _sz, _vp],
     "ltx_dit_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp], "ltx_vae_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp],
+    "ltx_vae_config_from_json": [C.c_char_p, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
 for _name, _sig in _SIGS.items():
@@ -423,6 +426,10 @@ class AutoencoderKLLtxVideoConfig:               # vae.rs:32-103 (decoder side)
     scaling_factor: float = 1.0
     spatial_compression_ratio: int = 32
     temporal_compression_ratio: int = 8
+    decoder_inject_noise: Tuple[bool, ...] = (False, False, False, False)     # vae.rs:87 (any True: refused by the engine)
+    decoder_upsample_residual: Tuple[bool, ...] = (True, True, True)            # vae.rs:88
+    decoder_spatiotemporal_scaling: Tuple[bool, ...] = (True, True, True)       # vae.rs:78 (any False: refused)
+    resnet_eps: float = 1e-6                                                    # vae.rs:83 (norm3 only: unused by the decoder)
 
 
 class AutoencoderKLLtxVideo:
@@ -439,6 +446,10 @@ class AutoencoderKLLtxVideo:
             c.decoder_upsample_factor[i] = config.decoder_upsample_factor[i]
         for i in range(nb + 1):
             c.decoder_layers_per_block[i] = config.decoder_layers_per_block[i]
+        for i, x in enumerate(config.decoder_inject_noise[:5]): c.decoder_inject_noise[i] = int(x)
+        for i, x in enumerate(config.decoder_upsample_residual[:4]): c.decoder_upsample_residual[i] = int(x)
+        for i, x in enumerate(config.decoder_spatiotemporal_scaling[:4]): c.decoder_spatiotemporal_scaling[i] = int(x)
+        c.resnet_eps = config.resnet_eps
         c.patch_size, c.patch_size_t = config.patch_size, config.patch_size_t
         c.timestep_conditioning = int(config.timestep_conditioning)
         c.decoder_causal = int(config.decoder_causal)
@@ -478,8 +489,28 @@ class AutoencoderKLLtxVideo:
         c = cls._config_c(config)
         self._h = C.c_void_p()
         _check(lib.ltx_vae_create_from_files(C.byref(c), path.encode(), int(unified), _dt(dtype), device, C.byref(self._h)))
+        self.config = self._config_py(self.get_config())       # a vae/config.json beside the weights replaces `config` (main.rs:525-534)
         self._tiling_defaults()
         return self
+
+    def get_config(self) -> "VaeConfigC":
+        """the engine's effective config (ltx_vae_get_config)"""
+        c = VaeConfigC()
+        _check(lib.ltx_vae_get_config(self._h, C.byref(c)))
+        return c
+
+    @staticmethod
+    def _config_py(c: "VaeConfigC") -> "AutoencoderKLLtxVideoConfig":
+        nb = c.n_blocks
+        return AutoencoderKLLtxVideoConfig(
+            latent_channels=c.latent_channels, out_channels=c.out_channels,
+            decoder_block_out_channels=tuple(c.decoder_block_out_channels[:nb]), decoder_layers_per_block=tuple(c.decoder_layers_per_block[:nb + 1]),
+            decoder_upsample_factor=tuple(c.decoder_upsample_factor[:nb]), patch_size=c.patch_size, patch_size_t=c.patch_size_t,
+            timestep_conditioning=bool(c.timestep_conditioning), decoder_causal=bool(c.decoder_causal), scaling_factor=c.scaling_factor,
+            spatial_compression_ratio=c.spatial_compression_ratio, temporal_compression_ratio=c.temporal_compression_ratio,
+            decoder_inject_noise=tuple(bool(x) for x in c.decoder_inject_noise[:nb + 1]),
+            decoder_upsample_residual=tuple(bool(x) for x in c.decoder_upsample_residual[:nb]),
+            decoder_spatiotemporal_scaling=tuple(bool(x) for x in c.decoder_spatiotemporal_scaling[:nb]), resnet_eps=c.resnet_eps)
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -59,7 +59,8 @@ typedef struct {
     int caption_channels;
 } ltx_dit_config;
 
-/* Mirrors the decoder-side fields of AutoencoderKLLtxVideoConfig (vae.rs:32-103). */
+/* Mirrors the decoder-side fields of AutoencoderKLLtxVideoConfig (vae.rs:32-103).  List fields are in config.json order
+ * (the decoder constructor reverses them, vae.rs:1506-1519). */
 typedef struct {
     int latent_channels, out_channels;
     int n_blocks;                        /* len(decoder_block_out_channels), <= 4 */
@@ -71,6 +72,17 @@ typedef struct {
     int decoder_causal;
     float scaling_factor;
     int spatial_compression_ratio, temporal_compression_ratio;
+    /* vae.rs:51, 676-690, 741-753: per-channel noise from the device RNG inside the resnets.  n_blocks + 1 entries; any
+     * non-zero entry is refused by ltx_vae_create (LTX_ERR_UNSUPPORTED): the reference's draw is not reproducible. */
+    int decoder_inject_noise[5];
+    /* vae.rs:52-53, 1103-1129, 1164-1168: whether an up-block's depth-to-space output gets the tiled-repeat residual. */
+    int decoder_upsample_residual[4];
+    /* vae.rs:40-41, 1212-1236: 1 = (2,2,2) upsampler; 0 = the spatial-only (1,2,2) form, refused (LTX_ERR_UNSUPPORTED). */
+    int decoder_spatiotemporal_scaling[4];
+    /* vae.rs:46-47: eps of the resnets' norm3 LayerNorm, which exists only where in_channels != out_channels (vae.rs:655-676)
+     * - never in the decoder, whose resnets keep the channel count (vae.rs:1547-1549, 1242-1258).  Carried for
+     * ltx_vae_get_config round trips; the decoder's RMS norms use the reference's hard-coded 1e-8 (vae.rs:620, 1575). */
+    float resnet_eps;
 } ltx_vae_config;
 
 /* Tiling parameters of AutoencoderKLLtxVideo (vae.rs:1849-1861); NULL = untiled decode. */
@@ -99,7 +111,7 @@ int ltx_dit_get_config(const ltx_dit* m, ltx_dit_config* out);
  *   rope_scale: HOST float[3] or NULL             video_coords [B,S,3] f32 or NULL
  *   skip_layer_mask: HOST f32 [num_layers,B] or NULL (1 = skip)
  *   out      [B,S,out_channels] io_dtype
- * B <= 8. */
+ * Any B >= 1 (batches beyond 8 rows run as chunks of 8: rows never interact in the forward). */
 int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float* timestep,
                     const float* enc_mask, int B, int S, int K, int num_frames, int height, int width,
                     const float* rope_scale, const float* video_coords, const float* skip_layer_mask,

@@ -61,6 +61,14 @@ int ltx_weights_resolve(const char* path, char* out, size_t cap, size_t* n_files
  *   unified == 0 : `path` is the component's own safetensors file or directory (Diffusers layout), tensor names taken
  *                  as they are (WeightLoader::load_single / load_from_directory).
  * F32 and BF16 payloads are accepted (anything else: LTX_ERR_UNSUPPORTED naming the tensor). */
+/* AutoencoderKLLtxVideoConfig from a diffusers `vae/config.json` (serde names and aliases of vae.rs:30-66); fields the file
+ * does not carry keep the value already in *cfg (serde(default) over Default::default() when the caller passed
+ * ltx_vae_config_default).  Host only. */
+int ltx_vae_config_from_json(const char* json_path, ltx_vae_config* cfg);
+
+/* ltx_vae_create_from_files, unified == 0: when a `config.json` sits beside the weights (in `path` if it is a directory, else
+ * in its parent directory) it REPLACES *cfg, exactly as examples/ltx-video/main.rs:525-533 does, and timestep_conditioning is
+ * then forced on (main.rs:534).  unified != 0 uses *cfg as given (main.rs:511-512 takes the preset's). */
 int ltx_dit_create_from_files(const ltx_dit_config* cfg, const char* path, int unified,
                               ltx_dtype model_dtype, int device, ltx_dit** out);
 int ltx_vae_create_from_files(const ltx_vae_config* cfg, const char* path, int unified,

@@ -417,6 +417,7 @@ class VaeConfig:                      # vae.rs:32-103 (decoder-side fields)
     scaling_factor: float = 1.0
     spatial_compression_ratio: int = 32
     temporal_compression_ratio: int = 8
+    decoder_upsample_residual: Tuple[bool, ...] = (True, True, True)     # vae.rs:52-53, 88; reversed like the other lists (:1516-1517)
     # tiling (vae.rs:1849-1854)
     tile_sample_min_height: int = 512
     tile_sample_min_width: int = 512
@@ -571,7 +572,8 @@ def decoder_forward(p: Dict[str, Tensor], cfg: VaeConfig, z: Tensor, temb: Optio
         if ts is not None and cfg.timestep_conditioning:
             e = time_embedder(p, pre + "time_embedder.", ts, h.dtype)
             te = e.reshape(h.shape[0], -1, 1, 1, 1)
-        h = upsampler(p, pre + "upsamplers.0.", h, ch, causal)
+        upr = list(reversed(cfg.decoder_upsample_residual))
+        h = upsampler(p, pre + "upsamplers.0.", h, ch, causal, residual=bool(upr[bi]) if bi < len(upr) else True)
         for i in range(nres[bi + 1]):
             h = resnet_block(p, pre + f"resnets.{i}.", h, te, causal)
     h = rms_norm_channels_first(h)

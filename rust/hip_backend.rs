@@ -13,8 +13,13 @@
 //! (3.6 ms at PCIe Gen5 x16).  A caller that wants nothing on the host between steps uses `HipPipeline::call`, the
 //! one-call form of `LtxPipeline::call` that keeps latents, predictions and the video in HBM (`ltx_pipeline_call`).
 //!
-//! This file could not be compiled in the authoring environment (no Rust toolchain); the C ABI it binds is compiled,
-//! exported and exercised entry point by entry point through ctypes (tests/test_host_cabi.py, tests/test_gpu_*.py).
+//! STATUS: an UNTESTED SKETCH on the Rust side.  This file has never been compiled or type-checked (the authoring
+//! environment has no Rust toolchain and no candle sources): the candle signatures it uses (`Tensor::from_vec`, `dims3`,
+//! the trait imports) are written from the reference's own call sites and need a `cargo check` in a CI job that has a
+//! toolchain before they are relied on.  What IS compiled and tested is everything below the `sys::` calls: the C ABI is
+//! built, exported and exercised entry point by entry point through ctypes (tests/test_host_cabi.py, tests/test_gpu_*.py),
+//! and the struct layouts and declared symbols of `ltxhip-sys` are checked against the headers and the library
+//! (tests/test_cabi_layout_cpu.py).
 
 use std::ffi::{c_void, CStr, CString};
 use std::os::raw::c_int;
@@ -97,16 +102,27 @@ pub struct HipDit {
     cfg: TransformerConfig,
     out_channels: usize,
     hidden: DeviceBuf,
-    enc: DeviceBuf,
-    mask: DeviceBuf,
     coords: DeviceBuf,
     out: DeviceBuf,
-    /// identity of the text context currently uploaded (pointer + length of the candle storage would not survive a
-    /// `to_dtype`, so the bytes are compared): the context cache of the library keys on device pointers, which stay
-    /// the same as long as `enc` / `mask` are not re-uploaded
+    /// Text contexts currently on the device.  `LtxPipeline::call` alternates between the negative and the positive
+    /// prompt under sequential CFG (t2v_pipeline.rs:878-939), so one slot would re-upload the context and drop the
+    /// library's cached caption projection + cross-attention K/V on every forward; a few slots keep them all.  The
+    /// library's cache keys on the device pointers, which stay the same for as long as a slot is not overwritten.
+    ctx: Vec<CtxSlot>,
+    ctx_clock: u64,
+}
+
+/// One uploaded (encoder_hidden_states, mask) pair.  The host copy is the identity of the contents (the pointer of a
+/// candle storage would not survive a `to_dtype`).
+struct CtxSlot {
+    enc: DeviceBuf,
+    mask: DeviceBuf,
     enc_host: Vec<f32>,
     mask_host: Vec<f32>,
+    last_use: u64,
 }
+
+const CTX_SLOTS: usize = 4; // uncond + text + perturbed (same text) + one spare; the library keeps up to 4 contexts
 
 impl HipDit {
     /// From a checkpoint on disk: `path` = the transformer's safetensors file or directory (`unified == false`,
@@ -141,13 +157,42 @@ impl HipDit {
             },
             out_channels: cfg.out_channels as usize,
             hidden: DeviceBuf::new(d),
-            enc: DeviceBuf::new(d),
-            mask: DeviceBuf::new(d),
             coords: DeviceBuf::new(d),
             out: DeviceBuf::new(d),
-            enc_host: Vec::new(),
-            mask_host: Vec::new(),
+            ctx: Vec::new(),
+            ctx_clock: 0,
         }
+    }
+
+    /// Device pointers of the slot holding this context, uploading it (into a free or the least recently used slot) if new.
+    fn context(&mut self, enc: Vec<f32>, mask: Vec<f32>) -> Result<(*const c_void, *const f32)> {
+        self.ctx_clock += 1;
+        let now = self.ctx_clock;
+        if let Some(slot) = self.ctx.iter_mut().find(|c| c.enc_host == enc && c.mask_host == mask) {
+            slot.last_use = now;
+            return Ok((slot.enc.ptr as *const c_void, slot.mask.ptr as *const f32));
+        }
+        let d = self.hidden.device;
+        if self.ctx.is_empty() {
+            check(unsafe { sys::ltx_dit_context_cache(self.h, 1) })?; // first context: open the caching scope
+        }
+        let idx = if self.ctx.len() < CTX_SLOTS {
+            self.ctx.push(CtxSlot { enc: DeviceBuf::new(d), mask: DeviceBuf::new(d), enc_host: Vec::new(), mask_host: Vec::new(), last_use: 0 });
+            self.ctx.len() - 1
+        } else {
+            // a slot is overwritten in place: its device pointers now name other contents, so everything the library
+            // cached is dropped (enable = 0 invalidates, enable = 1 re-opens the scope); the other slots refill on use
+            check(unsafe { sys::ltx_dit_context_cache(self.h, 0) })?;
+            check(unsafe { sys::ltx_dit_context_cache(self.h, 1) })?;
+            (0..self.ctx.len()).min_by_key(|&i| self.ctx[i].last_use).unwrap()
+        };
+        let slot = &mut self.ctx[idx];
+        slot.enc.upload(&enc)?;
+        slot.mask.upload(&mask)?;
+        slot.enc_host = enc;
+        slot.mask_host = mask;
+        slot.last_use = now;
+        Ok((slot.enc.ptr as *const c_void, slot.mask.ptr as *const f32))
     }
 
     /// Default 2B configuration (ltx_transformer.rs:40-58).
@@ -211,16 +256,9 @@ impl VideoTransformer3D for HipDit {
         let rs: Option<[f32; 3]> = rope_interpolation_scale.map(|r| [r.0, r.1, r.2]);
 
         let hidden_d = self.hidden.upload(&hidden)?;
-        // the text context is step-invariant inside one LtxPipeline::call: upload it only when it changed, and let the
-        // library keep its caption projection + cross-attention K/V for as long as the device pointers stay the same
-        if enc != self.enc_host || mask != self.mask_host {
-            check(unsafe { sys::ltx_dit_context_cache(self.h, 0) })?;
-            self.enc.upload(&enc)?;
-            self.mask.upload(&mask)?;
-            self.enc_host = enc;
-            self.mask_host = mask;
-            check(unsafe { sys::ltx_dit_context_cache(self.h, 1) })?;
-        }
+        // the text contexts are step-invariant inside one LtxPipeline::call: each is uploaded once and the library keeps
+        // its caption projection + cross-attention K/V for as long as the slot's device pointers keep their contents
+        let (enc_d, mask_d) = self.context(enc, mask)?;
         let coords_d = match video_coords {
             Some(c) => self.coords.upload(&host_f32(c)?)? as *const f32,
             None => ptr::null(),
@@ -231,9 +269,9 @@ impl VideoTransformer3D for HipDit {
             sys::ltx_dit_forward(
                 self.h,
                 hidden_d,
-                self.enc.ptr as *const c_void,
+                enc_d,
                 t.as_ptr(),
-                self.mask.ptr as *const f32,
+                mask_d,
                 b as c_int,
                 s as c_int,
                 k as c_int,
@@ -279,7 +317,10 @@ impl HipVae {
         let cpath = CString::new(path.to_string_lossy().as_bytes()).map_err(candle_core::Error::wrap)?;
         let mut h: *mut sys::ltx_vae = ptr::null_mut();
         check(unsafe { sys::ltx_vae_create_from_files(cfg, cpath.as_ptr(), unified as c_int, model_dtype(dtype)?, device as c_int, &mut h) })?;
-        Self::wrap(h, cfg, device)
+        // a vae/config.json beside diffusers-layout weights replaces `cfg` (main.rs:525-534): ask the engine what it built
+        let mut eff = *cfg;
+        check(unsafe { sys::ltx_vae_get_config(h, &mut eff) })?;
+        Self::wrap(h, &eff, device)
     }
 
     /// weights: the `decoder.*`, `latents_mean`, `latents_std` keys (vae.rs:1521-1608, 1827-1838)

@@ -57,6 +57,14 @@ pub struct ltx_vae_config {
     pub scaling_factor: c_float,
     pub spatial_compression_ratio: c_int,
     pub temporal_compression_ratio: c_int,
+    /// vae.rs:51 - any non-zero entry is refused (LTX_ERR_UNSUPPORTED); n_blocks + 1 entries, config.json order
+    pub decoder_inject_noise: [c_int; 5],
+    /// vae.rs:52-53 - tiled-repeat residual of each up-block's upsampler
+    pub decoder_upsample_residual: [c_int; 4],
+    /// vae.rs:40-41 - 0 = spatial-only up-block, refused (LTX_ERR_UNSUPPORTED)
+    pub decoder_spatiotemporal_scaling: [c_int; 4],
+    /// vae.rs:46-47 - norm3 only; unused by the decoder
+    pub resnet_eps: c_float,
 }
 
 /// `ltx_tiling`: tiling parameters of AutoencoderKLLtxVideo (vae.rs:1849-1861).
@@ -116,7 +124,7 @@ pub struct ltx_pipeline_params {
 // ---- layout guard: (size, align) per struct on LP64, compared with tests/cabi_layout.c by tests/test_cabi_layout_cpu.py ----
 pub const LAYOUT_LTX_WEIGHT: (usize, usize) = (72, 8);
 pub const LAYOUT_LTX_DIT_CONFIG: (usize, usize) = (40, 4);
-pub const LAYOUT_LTX_VAE_CONFIG: (usize, usize) = (92, 4);
+pub const LAYOUT_LTX_VAE_CONFIG: (usize, usize) = (148, 4);
 pub const LAYOUT_LTX_TILING: (usize, usize) = (32, 4);
 pub const LAYOUT_LTX_PIPELINE_PARAMS: (usize, usize) = (112, 8);
 pub const LAYOUT_LTX_T5_CONFIG: (usize, usize) = (36, 4);
@@ -154,6 +162,7 @@ extern "C" {
 
     // VaeLtxVideo (t2v_pipeline.rs:91-103)
     pub fn ltx_vae_create(cfg: *const ltx_vae_config, weights: *const ltx_weight, n_weights: usize, model_dtype: c_int, device: c_int, out: *mut *mut ltx_vae) -> c_int;
+    pub fn ltx_vae_config_from_json(json_path: *const c_char, cfg: *mut ltx_vae_config) -> c_int;
     pub fn ltx_vae_create_from_files(cfg: *const ltx_vae_config, path: *const c_char, unified: c_int, model_dtype: c_int, device: c_int, out: *mut *mut ltx_vae) -> c_int;
     pub fn ltx_vae_destroy(v: *mut ltx_vae);
     pub fn ltx_vae_get_config(v: *const ltx_vae, out: *mut ltx_vae_config) -> c_int;

@@ -25,7 +25,8 @@ int main(void) {
     BEGIN(ltx_vae_config); F(ltx_vae_config, latent_channels); F(ltx_vae_config, out_channels); F(ltx_vae_config, n_blocks); F(ltx_vae_config, decoder_block_out_channels);
         F(ltx_vae_config, decoder_layers_per_block); F(ltx_vae_config, decoder_upsample_factor); F(ltx_vae_config, patch_size); F(ltx_vae_config, patch_size_t);
         F(ltx_vae_config, timestep_conditioning); F(ltx_vae_config, decoder_causal); F(ltx_vae_config, scaling_factor); F(ltx_vae_config, spatial_compression_ratio);
-        F(ltx_vae_config, temporal_compression_ratio); END();
+        F(ltx_vae_config, temporal_compression_ratio); F(ltx_vae_config, decoder_inject_noise); F(ltx_vae_config, decoder_upsample_residual);
+        F(ltx_vae_config, decoder_spatiotemporal_scaling); F(ltx_vae_config, resnet_eps); END();
     BEGIN(ltx_tiling); F(ltx_tiling, use_tiling); F(ltx_tiling, use_framewise_decoding); F(ltx_tiling, tile_sample_min_height); F(ltx_tiling, tile_sample_min_width);
         F(ltx_tiling, tile_sample_min_num_frames); F(ltx_tiling, tile_sample_stride_height); F(ltx_tiling, tile_sample_stride_width); F(ltx_tiling, tile_sample_stride_num_frames); END();
     BEGIN(ltx_pipeline_params); F(ltx_pipeline_params, height); F(ltx_pipeline_params, width); F(ltx_pipeline_params, num_frames); F(ltx_pipeline_params, frame_rate);

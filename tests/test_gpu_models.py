@@ -278,6 +278,66 @@ def test_models_built_from_checkpoint_files_equal_dict_built_models(hip, tmp_pat
         hip.LtxVideoTransformer3DModel.from_files(tcfg, str(tmp_path / "bad.safetensors"), unified=True)
 
 
+def test_vae_upsample_residual_flags_and_config_json(hip, tmp_path):
+    """decoder_upsample_residual (vae.rs:52-53, 1103-1129, 1164-1168) per up-block, against the oracle in f32 mode; the same
+    flags read from a diffusers `vae/config.json` beside the weights replace the config the caller passed, as
+    examples/ltx-video/main.rs:525-534 does (and force timestep conditioning on)."""
+    import json
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 8, 2, 3, 4, generator=g)
+    ts = torch.tensor([0.05])
+    base = O.decoder_forward(O.synth_weights(O.vae_decoder_weight_shapes(O.VaeConfig(**VAE_CFG)), seed=7), O.VaeConfig(**VAE_CFG), z, ts)
+    for flags in ((False, False, False), (True, False, True), (False, True, True)):
+        kw = dict(VAE_CFG, decoder_upsample_residual=flags)
+        cfg = O.VaeConfig(**kw)
+        w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=7)
+        want = O.decoder_forward(w, cfg, z, ts)
+        assert rel_max(want, base) > 1e-2                      # the flag really changes the function
+        model = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**kw), {"decoder." + k: v.to(DEV) for k, v in w.items()}, torch.float32)
+        got = model.decode(z.to(DEV), ts).cpu()
+        assert rel_max(got, want) <= 1e-3, (flags, rel_max(got, want))
+        assert list(model.get_config().decoder_upsample_residual)[:3] == [int(f) for f in flags]
+    # config.json beside a diffusers-layout weight file: its flags win over the caller's config
+    vdir = tmp_path / "vae"; vdir.mkdir()
+    save_file({"decoder." + k: v.contiguous() for k, v in w.items()}, str(vdir / "diffusion_pytorch_model.safetensors"))
+    (vdir / "config.json").write_text(json.dumps({"latent_channels": 8, "decoder_block_out_channels": [32, 64, 128], "decoder_layers_per_block": [1, 1, 1, 2],
+                                                  "upsample_residual": [False, True, True], "timestep_conditioning": False}))
+    m2 = hip.AutoencoderKLLtxVideo.from_files(hip.AutoencoderKLLtxVideoConfig(), str(vdir / "diffusion_pytorch_model.safetensors"), unified=False, dtype=torch.float32)
+    c2 = m2.get_config()
+    assert list(c2.decoder_upsample_residual)[:3] == [0, 1, 1] and c2.latent_channels == 8 and c2.timestep_conditioning == 1
+    assert rel_max(m2.decode(z.to(DEV), ts).cpu(), want) <= 1e-3
+    (vdir / "config.json").write_text(json.dumps({"decoder_inject_noise": [False, False, True, False]}))
+    with pytest.raises(hip.LtxError, match="decoder_inject_noise"):
+        hip.AutoencoderKLLtxVideo.from_files(hip.AutoencoderKLLtxVideoConfig(), str(vdir), unified=False, dtype=torch.float32)
+
+
+def test_batches_beyond_eight_rows(hip):
+    """The traits put no bound on the batch (t2v_pipeline.rs:68-80, :102): B = 11 through ltx_dit_forward / ltx_vae_decode (run as
+    chunks of 8 rows inside the engine) against the oracle in f32 mode - per-row timesteps, a mask with zeros, a skip-layer mask
+    whose rows differ - and bit-identical to the same rows given as two calls."""
+    dcfg = O.DitConfig(**PIPE_DIT_CFG)
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=11)
+    g = torch.Generator().manual_seed(9)
+    B, Fr, H, W, K = 11, 2, 2, 3, 6
+    lat = torch.randn(B, Fr * H * W, 8, generator=g); pe = torch.randn(B, K, 32, generator=g)
+    pm = (torch.rand(B, K, generator=g) > 0.3).float(); pm[:, 0] = 1
+    ts = torch.linspace(100, 900, B)
+    slm = (torch.rand(dcfg.num_layers, B, generator=g) > 0.5).float()
+    want = O.dit_forward(dw, dcfg, lat, pe, ts, pm, Fr, H, W, skip_layer_mask=slm)
+    model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**PIPE_DIT_CFG), {k: v.to(DEV) for k, v in dw.items()}, torch.float32)
+    got = model.forward(lat.to(DEV), pe.to(DEV), ts, pm.to(DEV), Fr, H, W, None, None, slm)
+    assert rel_max(got.cpu(), want) <= 1e-3, rel_max(got.cpu(), want)
+    a = model.forward(lat[:8].to(DEV), pe[:8].to(DEV), ts[:8], pm[:8].to(DEV), Fr, H, W, None, None, slm[:, :8].contiguous())
+    b = model.forward(lat[8:].to(DEV), pe[8:].to(DEV), ts[8:], pm[8:].to(DEV), Fr, H, W, None, None, slm[:, 8:].contiguous())
+    assert torch.equal(got, torch.cat([a, b]))
+    vcfg, vw, vae = _vae(hip, torch.float32)
+    z = torch.randn(B, 8, 2, 2, 3, generator=g); tv = torch.linspace(0.0, 0.2, B)
+    vid = vae.decode(z.to(DEV), tv).cpu()
+    assert rel_max(vid, O.decoder_forward(vw, vcfg, z, tv)) <= 1e-3
+    assert torch.equal(vid[8:], vae.decode(z[8:].to(DEV), tv[8:]).cpu())
+
+
 def test_pipeline_stochastic_sampling_matches_oracle(hip):
     """SchedulerConfig::stochastic_sampling (0.9.6-distilled preset, configs.rs:210): the C-ABI loop with caller-supplied
     per-step draws against the oracle's scheduler.step stochastic branch, f32, 3 steps with CFG."""
