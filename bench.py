@@ -27,6 +27,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -55,6 +56,8 @@ CONFIGS = {
                name="LTX-Video-0.9.8-13B-distilled 704x1216x161, 7 steps, skip block 42 (configs.rs:264-282), untiled VAE decode"),
 }
 DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232 (the CPU baseline's C1 run)
+# the one full oracle run of the headline workload (10 minutes of 8 host cores; too long for the default bench run)
+FULL_C2_RUN = {"seconds": 622.57, "frames_per_sec": 97 / 622.57, "cores": 8, "cpu": "Intel Xeon @ 2.60GHz (build container)", "record": "profiles/r3_oracle_cpu_runs.json"}
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -101,8 +104,9 @@ def synth_on_device(shapes, dev, seed):
 
 
 def cpu_baseline(cfg, fl_job):
-    """The oracle (a port of the reference's CPU path: f32, un-fused, materialised attention scores, conv3d as per-frame
-    sums of conv2d) timed on this box's host cores, two ways:
+    """The oracle (a torch-CPU port of the reference's CPU path - oneDNN / MKL kernels under an op-for-op restatement: f32,
+    un-fused, materialised attention scores, conv3d as per-frame sums of conv2d; `kind: "torch-port"`, NOT the reference binary
+    and not the plain C++ backend SURVEY 8d sketched) timed on this box's host cores, two ways:
       * MEASURED: BASELINE config C1 in full and end to end - the 28-layer 2B DiT x 7 distilled steps + the full VAE decode
         at 256x384x25 (12.8 TFLOP; the run tests/golden/oracle_c1.safetensors comes from), ~20-40 s;
       * for the workload `value` is quoted on: the same oracle on a bounded SAMPLE of it (1- and 3-layer forwards at the
@@ -136,7 +140,7 @@ def cpu_baseline(cfg, fl_job):
     if cfg["preset"] != "0.9.8-2b-distilled" or cfg["mode"] != "replicas" or cfg["num_frames"] == 25:
         # c1 itself: the measured run IS the baseline; other workloads: scaled by algorithmic FLOPs at the measured CPU rate
         total = fl_job / (fl_c1 / t_c1)
-        return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "c1_measured": c1,
+        return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "torch-port", "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
                 "sample": f"oracle f32 on host: C1 run in full ({t_c1:.1f} s, {fl_c1 / t_c1 / 1e12:.2f} TFLOP/s); this workload's {fl_job / 1e12:.0f} TFLOP "
                           f"at that rate = {total:.0f} s per video" + (" (measured, not scaled)" if cfg["num_frames"] == 25 else " (estimate)")}
     # ---- estimate for C2 from a bounded sample of C2 itself
@@ -164,7 +168,7 @@ def cpu_baseline(cfg, fl_job):
     t_crop = time.time() - t0
     t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
     total = 7 * t_fwd + t_vae
-    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "c1_measured": c1,
+    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "torch-port", "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
             "sample": f"ESTIMATE for this workload from a bounded sample of it ({t_n[1] + t_n[3] + t_crop:.1f} s of CPU work): oracle f32 DiT forwards with 1 and 3 of 28 "
                       f"layers at S={S} ({t_n[1]:.2f} s, {t_n[3]:.2f} s -> {t_fixed:.2f} s + 28 x {t_layer:.2f} s per forward, x7 steps) + VAE decode of a {cf}x{chh}x{cww} "
                       f"latent crop ({t_crop:.2f} s, scaled by conv FLOPs to {F}x{H}x{W}) = {total:.0f} s per video; MEASURED beside it: C1 in full, {t_c1:.1f} s "
@@ -200,13 +204,14 @@ def job_fps(videos_per_step, steps, frames, elapsed):
     return videos_per_step * steps * frames / elapsed
 
 
-def pmc_traffic_bytes(cls):
+def pmc_traffic_bytes(cls, config):
     """Per-launch memory-side traffic of a kernel class from the newest committed rocprofv3 --pmc summary under profiles/
     (separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH doubled on gfx950: MI355X_MICROARCH.md HBM section).
-    bench.py cannot run the profiler on itself; None when no summary is present."""
+    bench.py cannot run the profiler on itself; None when no summary of THIS workload is present (the committed passes
+    are `*_bench_<config>_kernel_stats.json`: a c2 profile says nothing about c5's launches)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernel_stats.json"))):
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_bench_{config}_kernel_stats.json"))):
         try:
             d = json.load(open(f))
             fe, wr = d["pmc"]["FETCH_SIZE"][cls], d["pmc"]["WRITE_SIZE"][cls]
@@ -215,6 +220,77 @@ def pmc_traffic_bytes(cls):
         except Exception:
             continue
     return best if best else (None, None)
+
+
+def sharded_measurements(ltxhip, sharded, dist, dev, world, dit, vae, inputs, F, H, W, dit_step_ms, decode_ms):
+    """The two places where the path DOES shard, measured in this job beside the replicas value,
+    at the headline geometry (512x768x97), on the models and inputs of the main run:
+      c3  LTX-Video 0.9.5 preset (40 steps, CFG 3.0 + STG 1.0 + rescale 0.7: three forwards per step, t2v_pipeline.rs:878-939),
+          whole videos incl. the untiled decode: teams of three ranks (one guidance branch each, one RCCL all-gather of the
+          f32 predictions per step) against every rank running the three branches itself;
+      c4  the reference's tiled framewise decode (vae.rs:2225-2434, 52 decoder calls): temporal tiles split over ONE team of
+          all ranks (strip point to point + one gather of finished frames) against the same decode on one GPU.
+    Collective: every rank calls it.  Returns the dict rank 0 attaches to the bench line."""
+    lat, pe, pm, ne, nm, noise = inputs
+    res = {}
+    ones = torch.ones(1, device=dev); dist.all_reduce(ones)
+    res["rccl_ranks"] = int(ones.item())
+    assert res["rccl_ranks"] == world == dist.get_world_size(), (res["rccl_ranks"], world)
+
+    def timed(fn, n):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
+    # ---- c3: guidance branches
+    pre3 = ltxhip.get_config_by_version("0.9.5")
+    call3 = pre3.pipeline_call(512, 768, 97, postprocess=True)
+    vae.use_tiling = vae.use_framewise_decoding = False
+    team3 = sharded.make_teams(3)
+    p_team = sharded.ShardedLtxPipeline(dit, vae, team3)
+    p_one = ltxhip.LtxPipeline(dit, vae)
+    run_team = lambda: p_team.call(call3, lat, pe, pm, ne, nm, decode_noise=noise)
+    run_one = lambda: p_one.call(call3, lat, pe, pm, ne, nm, decode_noise=noise)
+    run_team(); t_team = timed(run_team, 1)
+    run_one(); t_one = timed(run_one, 1)
+    n_teams = -(-world // 3)
+    res.update({"c3_team3_fps": n_teams * 97 / t_team, "c3_1gpu_fps": world * 97 / t_one, "c3_team3_s_per_video": t_team, "c3_1gpu_s_per_video": t_one,
+                "c3_teams": n_teams, "c3_note": "whole 0.9.5-preset videos (40 steps x 3 forwards + untiled decode); team3 = job throughput with teams of three "
+                                                "ranks (a leftover team is smaller), 1gpu = job throughput with every rank making its own video"})
+    x = torch.zeros(1, 1, F * H * W, 128, device=dev)
+    outs = [torch.empty_like(x) for _ in range(team3.size)]
+    ag = lambda: dist.all_gather(outs, x, group=team3.group) if team3.size > 1 else None
+    ag(); res["allgather_ms"] = 1e3 * timed(ag, 20)
+    res["allgather_bytes_per_rank"] = x.numel() * 4
+
+    # ---- c4: temporal tiles of the tiled framewise decode
+    teamN = sharded.make_teams(world)
+    vae.use_tiling = vae.use_framewise_decoding = True
+    ops_ = sharded.HipOps(dit, vae)
+    z = vae.prepare_latents(lat, F, H, W, noise, [0.025])
+    tl = sharded.Tiling(True, True, vae.tile_sample_min_height, vae.tile_sample_min_width, vae.tile_sample_min_num_frames, vae.tile_sample_stride_height,
+                        vae.tile_sample_stride_width, vae.tile_sample_stride_num_frames, 32, 8)
+    dec_team = lambda: sharded.decode_tile_sharded(ops_.decode_tile_fn(0.05), sharded.HipOps.blend, z, tl, teamN)
+    dec_one = lambda: vae.decode(z, [0.05])
+    dec_team(); t_dt = timed(dec_team, 2)
+    dec_one(); t_d1 = timed(dec_one, 2)
+    vae.use_tiling = vae.use_framewise_decoding = False
+    den = 7 * dit_step_ms * 1e-3
+    res.update({"c4_teamN_fps": 97 / (den + t_dt), "c4_1gpu_fps": 97 / (den + t_d1), "c4_teamN_decode_ms": 1e3 * t_dt, "c4_1gpu_decode_ms": 1e3 * t_d1,
+                "c4_untiled_decode_ms": decode_ms, "c4_note": "one video per team of all ranks: 7 measured denoise steps (replicated) + the tiled framewise decode; "
+                                                             "the untiled decode of the main run stands beside it (tiling multiplies the decoder's work ~3x)"})
+    nfr = -(-97 // world)
+    send = torch.zeros(1, 3, nfr, 512, 768, device=dev)
+    got = [torch.empty_like(send) for _ in range(world)]
+    ga = lambda: dist.all_gather(got, send, group=teamN.group)
+    ga(); res["gather_ms"] = 1e3 * timed(ga, 5)
+    res["gather_bytes_per_rank"] = send.numel() * 4
+    return res
 
 
 def spawn_ranks(n, argv):
@@ -248,7 +324,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # test aid (one-GPU boxes): LTX_BENCH_SAME_GPU=1 puts every rank on cuda:0 and LTX_BENCH_BACKEND=gloo replaces RCCL, so that
+        # the N >= 3 code path can be walked where no multi-GPU node exists; never set by the driver
+        if os.environ.get("LTX_BENCH_SAME_GPU") == "1":
+            local = 0
+        backend = os.environ.get("LTX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -353,7 +437,7 @@ def main():
             ltxhip.prof_enable(False)
             dom = max((n for n in per if "rownorm" not in n), key=lambda n: per[n]["ms_total"])
             ach = per[dom]["TFLOP/s"]
-            traffic, tsrc = pmc_traffic_bytes("conv3d implicit GEMM" if "conv" in dom else "linear GEMM")
+            traffic, tsrc = pmc_traffic_bytes("conv3d implicit GEMM" if "conv" in dom else "linear GEMM", a.config)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: HBM + Infinity Cache)",
                                "traffic_source": tsrc, "avg_launch_ms": per[dom]["avg_ms"],
@@ -367,10 +451,39 @@ def main():
                                  "vae_mid_1024": ltxhip.ops.gemm_plan(F * H * W, 1024, 1024, 1, 27, F, H, W)}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, fl_job)
-        print(json.dumps(out))
+    # N >= 3 on the headline workload: the sharded forms measured in the same job.  This path has never run on real multi-GPU
+    # hardware (no node was available to any round), so it must not be able to cost the job its bench line: errors are
+    # reported inside the line, and a watchdog prints the line without the section and ends every rank if a collective hangs.
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and out is not None and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    watchdog = None
+    if dist is not None and world >= 3 and a.config == "c2" and os.environ.get("LTX_BENCH_SHARDED", "1") != "0":
+        def bail():
+            if out is not None:
+                out.setdefault("sharded", {"error": "timed out (a collective of the sharded section did not complete)"})
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("LTX_BENCH_SHARDED_TIMEOUT", "300")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            sh = sharded_measurements(ltxhip, sharded, dist, dev, world, dit, vae, (lat, pe, pm, ne, nm, noise), F, H, W,
+                                      dit_ms / (n_steps * a.steps), vae_ms / a.steps)
+        except Exception as e:                              # noqa: BLE001 - reported in the line, never fatal
+            sh = {"error": repr(e)[:400]}
+        if out is not None:
+            out["sharded"] = sh
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -146,13 +146,16 @@ _SIGS = {
     "ltx_weights_resolve": [C.c_char_p, C.c_char_p, _sz, _vp],
     "ltx_dit_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp], "ltx_vae_create_from_files": [_vp, C.c_char_p, _i, _i, _i, _vp],
     "ltx_vae_config_from_json": [C.c_char_p, _vp],
+    # ltxhip_team.h: RCCL behind the C ABI (dlopen'ed on first use)
+    "ltx_team_unique_id": [_vp], "ltx_team_create": [_vp, _i, _i, _i, _vp], "ltx_team_destroy": [_vp], "ltx_team_size": [_vp], "ltx_team_rank": [_vp],
+    "ltx_team_allgather_f32": [_vp, _vp, _vp, _sz, _vp], "ltx_team_exchange_f32": [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ltx_last_error"])
 for _name, _sig in _SIGS.items():
     _fn = getattr(lib, _name)          # raises AttributeError if the library lacks a declared symbol
     _fn.argtypes = _sig
     if _name not in ("ltx_calculate_shift", "ltx_vae_latents_mean", "ltx_vae_latents_std", "ltx_name_mapper_create",
-                     "ltx_name_mapper_destroy", "ltx_safetensors_close", "ltx_safetensors_count"):
+                     "ltx_name_mapper_destroy", "ltx_safetensors_close", "ltx_safetensors_count", "ltx_team_destroy"):
         _fn.restype = C.c_int
 lib.ltx_calculate_shift.restype = C.c_float
 lib.ltx_vae_latents_mean.restype = C.c_void_p

@@ -5,8 +5,10 @@ C1's geometry (256x384x25; the CPU oracle needs ~10 minutes for these 120 forwar
 Fixture: tests/golden/oracle_c3.safetensors (tools/gen_fixtures.py c3), weights seeded and re-derived here.
 
 Bars: f32 mode rel-max <= 1e-3 on the final latents and the video slice after 40 guided steps (north_star's parity bar);
-bf16 production kernels: video PSNR > 30 dB against the plain f32 oracle (C1 measures 30.4 dB for 7 un-guided steps on the
-same bar: it includes the reference's own bf16-timestep quirk, ltx_transformer.rs:1051)."""
+bf16 production kernels against the plain f32 oracle: latent rel-L2 <= 3.5e-2 and video PSNR >= 38 dB (measured 0.026 and
+41.3 dB after the 120 forwards; C1/C2/C4 use 2e-2 for 7 un-guided steps - the guided 40-step trajectory accumulates 1.3x that;
+the distance includes the reference's own bf16-timestep quirk, ltx_transformer.rs:1051).  The preset at C2's geometry
+(512x768x97, where the oracle would need days) is held to the engine's f32 mode over 4 guided steps."""
 import math
 import os
 
@@ -81,4 +83,47 @@ def test_c3_preset_bf16_production_kernels_vs_f32_oracle(c3):
     p = psnr(video[:, :, ::4, ::8, ::8], g["video_slice"])
     e = rel_l2(lat, g["latents"])
     print(f"C3 preset bf16 vs plain f32 oracle: latent rel-L2 {e:.4f}, PSNR {p:.1f} dB")
-    assert p > 30.0, (p, e)
+    assert e <= 3.5e-2, e
+    assert p >= 38.0, (p, e)
+
+
+def test_c3_preset_at_c2_geometry_bf16_vs_f32_mode(c3):
+    """BASELINE config C3 at its own size, 512x768x97 (S = 4992): the 0.9.5 preset's guidance path (CFG 3.0 + STG 1.0 through
+    skip block 19 + rescale 0.7: three forwards per step) for 4 steps of its schedule + the untiled decode, bf16 production
+    kernels against the f32 mode of the same engine (the arithmetic the oracle pins at small sizes): latent rel-L2 <= 2e-2,
+    video PSNR >= 38 dB, finite, and the bf16 run repeats bit for bit."""
+    hip, g, dw, vw = c3
+    F, H, W = 13, 16, 24
+    lat = hip.pack_latents(hip.pcg32_randn(42, (1, 128, F, H, W)))
+    pe = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(42)); pm = torch.zeros(1, 128); pm[:, :32] = 1
+    ne = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(43)); nm = torch.zeros(1, 128); nm[:, :8] = 1
+    pre = hip.get_config_by_version("0.9.5")
+    call = pre.pipeline_call(512, 768, 97, postprocess=True)
+    # four steps whose integer timesteps are exact in bf16: the reference rounds the timestep to the model dtype
+    # (ltx_transformer.rs:1051), which is an INPUT difference between the two modes, not an arithmetic one (C1/C2 carry both
+    # oracles for that reason); with these sigmas both modes see 1000, 896, 640, 100
+    call.num_inference_steps, call.sigmas = 4, [1.0, 0.8965, 0.6405, 0.1005]
+    ts = hip.FlowMatchEulerDiscreteScheduler(1.0, call.shift_terminal).set_timesteps(call.sigmas, 0.0)
+    assert [int(t) for t in ts] == [1000, 896, 640, 100] and all(float(torch.tensor(float(t)).bfloat16()) == float(t) for t in ts)
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        dit = hip.LtxVideoTransformer3DModel(pre.transformer, {k: v.bfloat16().float().to(DEV) if v.dim() > 1 else v.to(DEV) for k, v in dw.items()}, dt)
+        vae = hip.AutoencoderKLLtxVideo(pre.vae, {"decoder." + k: (v.bfloat16().float() if v.dim() > 1 else v).to(DEV) for k, v in vw.items()}, dt)
+        pipe = hip.LtxPipeline(dit, vae)
+        runs = []
+        for _ in range(2 if dt == torch.bfloat16 else 1):
+            lat_f, video = pipe.call(call, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV))
+            torch.cuda.synchronize()
+            runs.append((lat_f.float().cpu(), video[:, :, ::4, ::8, ::8].float().cpu()))
+        if len(runs) == 2:
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        res[dt] = runs[0]
+        del pipe, dit, vae
+        torch.cuda.empty_cache()
+    for v in res.values():
+        assert torch.isfinite(v[0]).all() and torch.isfinite(v[1]).all()
+    e = rel_l2(res[torch.bfloat16][0], res[torch.float32][0])
+    p = psnr(res[torch.bfloat16][1], res[torch.float32][1])
+    print(f"C3 preset at 512x768x97, 4 guided steps: bf16 vs f32 mode latent rel-L2 {e:.4f}, PSNR {p:.1f} dB")
+    assert e <= 2e-2, e
+    assert p >= 38.0, p

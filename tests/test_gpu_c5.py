@@ -60,3 +60,103 @@ def test_c5_13b_full_forward_bf16_vs_f32_mode_and_skip_block():
     assert d > 5 * e, (d, e)                        # block 42 is really dropped (the difference is far above rounding)
     assert 0.05 < float(outs["f32"].std()) < 50.0    # not degenerate
     print({"c5_forward_rel_l2_bf16_vs_f32": round(e, 5), "skip42_distance": round(d, 4), "out_std": round(float(outs["f32"].std()), 3)})
+
+
+# ---- C5's decode: 21 x 22 x 38 latent -> 161 x 704 x 1216 ----------------------------------------------
+def _vae(dt):
+    import ltxhip
+    from ltxhip import schema
+    sys.path.insert(0, ROOT)
+    from bench import synth_on_device
+    pre = ltxhip.get_config_by_version("0.9.8-13b-distilled")
+    vw = {"decoder." + k: v for k, v in synth_on_device(schema.vae_decoder_weight_shapes(pre.vae), "cuda:0", 100).items()}
+    return ltxhip, pre, ltxhip.AutoencoderKLLtxVideo(pre.vae, vw, dt, 0)
+
+
+def test_c5_vae_plane_vs_oracle_fixture():
+    """The decoder on C5's 22 x 38 latent plane (every stage has ragged right / bottom conv tiles: 22, 44, 88, 176 rows and
+    38, 76, 152, 304 columns are not multiples of the 16 x 16 voxel patch) against the CPU oracle's decode of the same
+    2-frame latent (tests/golden/oracle_c5vae.safetensors, tools/gen_fixtures.py c5vae): f32 mode <= 1e-3 on a strided
+    slice and on the right / bottom edge strips; bf16 production kernels rel-L2 <= 2e-2 (C4 measures 0.8e-2 .. 1.0e-2)."""
+    import ltxhip
+    from safetensors.torch import load_file
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ltx_oracle as O
+    from conftest import rel_max
+    from test_gpu_c1 import checksum
+    g = load_file(os.path.join(ROOT, "tests", "golden", "oracle_c5vae.safetensors"))
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(O.VaeConfig()), seed=32)
+    assert torch.allclose(checksum(vw), g["vae_weights_checksum"], rtol=1e-9)
+    z = torch.randn(1, 128, 2, 22, 38, generator=torch.Generator().manual_seed(47))
+    assert torch.allclose(torch.tensor([float(z.double().sum()), float(z.double().abs().sum())], dtype=torch.float64), g["latents_checksum"], rtol=1e-9)
+    vwd = {"decoder." + k: v.to("cuda:0") for k, v in vw.items()}
+    for dt, bar in ((torch.float32, 1e-3), (torch.bfloat16, None)):
+        vae = ltxhip.AutoencoderKLLtxVideo(ltxhip.AutoencoderKLLtxVideoConfig(), vwd, dt, 0)
+        v = vae.decode(z.to("cuda:0"), torch.tensor([0.05])).float().cpu()
+        assert tuple(v.shape) == (1, 3, 9, 704, 1216) and torch.isfinite(v).all()
+        parts = {"slice": (v[:, :, ::2, ::16, ::16], g["video_slice"]), "right": (v[:, :, ::2, ::8, 1184:1216:2], g["video_right"]),
+                 "bottom": (v[:, :, ::2, 672:704:2, ::8], g["video_bottom"])}
+        for name, (got, want) in parts.items():
+            if bar is not None:
+                assert rel_max(got, want) <= bar, (name, rel_max(got, want))
+            else:
+                assert rel_l2(got, want) <= 2e-2, (name, rel_l2(got, want))
+        if bar is not None:
+            assert abs(float(v.double().abs().sum()) / float(g["video_moments"][2]) - 1.0) <= 1e-4
+        del vae
+        torch.cuda.empty_cache()
+
+
+def test_c5_vae_full_size_decode_properties():
+    """The full C5 decode (21 x 22 x 38 -> 161 x 704 x 1216, 170 TFLOP, untiled in HBM): finite, repeatable bit for bit, and
+    consistent with the f32 mode of the same engine where that fits (f32 activations of the full video are 4 x 70 GB): a
+    5-latent-frame slab over the whole plane, bf16 vs f32 mode rel-L2 <= 2e-2."""
+    ltxhip, pre, vae = _vae(torch.bfloat16)
+    z = torch.randn(1, 128, 21, 22, 38, generator=torch.Generator().manual_seed(48)).to("cuda:0")
+    v = vae.decode(z, torch.tensor([0.05]))
+    assert tuple(v.shape) == (1, 3, 161, 704, 1216)
+    assert torch.isfinite(v).all()
+    s1 = (float(v.double().sum()), float(v.double().abs().sum()))
+    assert 0.05 < float(v.float().std()) < 50.0
+    v2 = vae.decode(z, torch.tensor([0.05]))
+    assert torch.equal(v, v2)
+    del v2
+    slab = z[:, :, 8:13].contiguous()
+    vb = vae.decode(slab, torch.tensor([0.05])).float().cpu()
+    del vae, v
+    torch.cuda.empty_cache()
+    _, _, vae32 = _vae(torch.float32)
+    vf = vae32.decode(slab, torch.tensor([0.05])).float().cpu()
+    e = rel_l2(vb, vf)
+    print({"c5_decode_sum": s1, "c5_slab_rel_l2_bf16_vs_f32": round(e, 5)})
+    assert e <= 2e-2, e
+
+
+def test_c5_pipeline_end_to_end():
+    """One whole BASELINE-C5 video through ltx_pipeline_call: 13B DiT (skip block 42) x 7 distilled steps + the untiled
+    decode at 704 x 1216 x 161.  Shape, range after postprocess, no non-finite value, and a second call gives the same bits."""
+    import ltxhip
+    from ltxhip import schema
+    sys.path.insert(0, ROOT)
+    from bench import synth_on_device
+    dev = "cuda:0"
+    pre = ltxhip.get_config_by_version("0.9.8-13b-distilled")
+    call = pre.pipeline_call(704, 1216, 161, postprocess=True)
+    F, H, W = 21, 22, 38
+    dit = ltxhip.LtxVideoTransformer3DModel(pre.transformer, synth_on_device(schema.dit_weight_shapes(pre.transformer), dev, 1), torch.bfloat16, 0)
+    vae = ltxhip.AutoencoderKLLtxVideo(pre.vae, {"decoder." + k: v for k, v in synth_on_device(schema.vae_decoder_weight_shapes(pre.vae), dev, 100).items()}, torch.bfloat16, 0)
+    torch.cuda.empty_cache()
+    lat = ltxhip.pack_latents(ltxhip.pcg32_randn(42, (1, 128, F, H, W))).to(dev)
+    pe = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(42)).to(dev)
+    pm = torch.zeros(1, 128); pm[:, :32] = 1; pm = pm.to(dev)
+    noise = torch.randn(1, 128, F, H, W, generator=torch.Generator().manual_seed(44)).to(dev)
+    pipe = ltxhip.LtxPipeline(dit, vae)
+    outs = []
+    for _ in range(2):
+        lat_f, video = pipe.call(call, lat, pe, pm, None, None, decode_noise=noise)
+        torch.cuda.synchronize()
+        assert tuple(video.shape) == (1, 3, 161, 704, 1216) and tuple(lat_f.shape) == (1, F * H * W, 128)
+        assert torch.isfinite(video).all() and torch.isfinite(lat_f).all()
+        assert float(video.min()) >= 0.0 and float(video.max()) <= 255.0 and float(video.float().std()) > 1.0
+        outs.append((lat_f.clone(), video[:, :, ::16].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -545,3 +545,30 @@ def test_timestep_embedding_kernel_vs_oracle(hip, vae_flavour, mult):
     want_b = (O.vae_timestep_embedding((tb * torch.tensor(mult).bfloat16()).float()) if vae_flavour else O.get_timestep_embedding(tb.float())).bfloat16()
     got_b = hip.ops.timestep_embedding(ts, vae_flavour, mult, dtype=torch.bfloat16).cpu()
     assert (got_b.float() - want_b.float()).abs().max() <= 2 ** -7       # one bf16 ulp at 1.0
+
+
+def test_team_collectives_over_rccl_single_rank(hip):
+    """include/ltxhip_team.h on the one GPU of this box: a team of one goes through the real librccl.so calls
+    (ncclGetUniqueId, ncclCommInitRank, ncclAllGather, grouped ncclSend + ncclRecv to itself) - the all-gather of one rank
+    and a self exchange are copies.  Multi-rank behaviour is the same code with nranks > 1 (one process per GPU)."""
+    import ctypes as C
+    ident = (C.c_char * 128)()
+    assert hip.lib.ltx_team_unique_id(ident) == 0, hip.lib.ltx_last_error()
+    assert any(b != b"\x00" for b in ident)
+    t = C.c_void_p()
+    assert hip.lib.ltx_team_create(ident, 1, 0, torch.cuda.current_device(), C.byref(t)) == 0, hip.lib.ltx_last_error()
+    assert hip.lib.ltx_team_size(t) == 1 and hip.lib.ltx_team_rank(t) == 0
+    x = torch.randn(1, 4992, 128, device="cuda")
+    y = torch.zeros_like(x)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip.lib.ltx_team_allgather_f32(t, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.numel(), s) == 0, hip.lib.ltx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    z = torch.zeros(3 * 512 * 768, device="cuda")
+    strip = torch.randn(3 * 512 * 768, device="cuda")
+    assert hip.lib.ltx_team_exchange_f32(t, C.c_void_p(strip.data_ptr()), strip.numel(), 0, C.c_void_p(z.data_ptr()), z.numel(), 0, s) == 0, hip.lib.ltx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(z, strip)
+    assert hip.lib.ltx_team_exchange_f32(t, None, 0, -1, None, 0, -1, s) == 0                 # no peers: nothing to do
+    assert hip.lib.ltx_team_exchange_f32(t, C.c_void_p(strip.data_ptr()), 8, 1, None, 0, -1, s) == 1      # peer outside the team
+    hip.lib.ltx_team_destroy(t)

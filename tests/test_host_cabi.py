@@ -28,7 +28,7 @@ def _declared(header):
 
 def test_library_exports_every_declared_symbol(hip):
     lib = ctypes.CDLL(os.path.join(ROOT, "candle-video_amd", "libltxhip.so"))
-    names = _declared("ltxhip.h") + _declared("ltxhip_ops.h") + _declared("ltxhip_weights.h") + _declared("ltxhip_t5.h") + _declared("ltxhip_frames.h") + _declared("ltxhip_presets.h")
+    names = _declared("ltxhip.h") + _declared("ltxhip_ops.h") + _declared("ltxhip_weights.h") + _declared("ltxhip_t5.h") + _declared("ltxhip_frames.h") + _declared("ltxhip_presets.h") + _declared("ltxhip_team.h")
     assert len(names) >= 45
     for n in names:
         assert hasattr(lib, n), f"libltxhip.so does not export {n}"
@@ -98,3 +98,17 @@ def test_errors_surface_as_exceptions_without_gpu(hip):
         hip.FlowMatchEulerDiscreteScheduler().set_timesteps([], 0.0)
     with pytest.raises(hip.LtxError, match="GPU"):       # host tensors are refused, never silently computed on the CPU
         hip.guidance_combine(torch.zeros(1, 4, 8))
+
+
+def test_team_entry_points_reject_bad_arguments_without_a_gpu(hip):
+    """ltxhip_team.h (RCCL behind the C ABI for hosts without torch.distributed): argument checks come before librccl.so is
+    loaded or a device is touched."""
+    h = ctypes.c_void_p()
+    ident = (ctypes.c_char * 128)()
+    assert hip.lib.ltx_team_create(None, 1, 0, 0, ctypes.byref(h)) == 1
+    assert hip.lib.ltx_team_create(ident, 2, 2, 0, ctypes.byref(h)) == 1 and b"rank" in hip.lib.ltx_last_error()
+    assert hip.lib.ltx_team_create(ident, 0, 0, 0, ctypes.byref(h)) == 1
+    assert hip.lib.ltx_team_unique_id(None) == 1
+    assert hip.lib.ltx_team_size(None) == 0 and hip.lib.ltx_team_rank(None) == -1
+    assert hip.lib.ltx_team_allgather_f32(None, None, None, 4, None) == 1
+    assert hip.lib.ltx_team_exchange_f32(None, None, 0, -1, None, 0, -1, None) == 1

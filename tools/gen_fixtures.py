@@ -386,6 +386,32 @@ def c4_case():
                         "video_slice": "[:, :, ::8, ::16, ::16]; video_edge: [:, :, :, 376:392:2, 376:392:2] of the [1,3,97,512,768] video (before postprocess)"})
 
 
+def c5vae_case():
+    """BASELINE config C5's DECODE geometry: the full VAE decoder (weights of c1_case) on a latent with C5's spatial plane,
+    22 x 38 (704 x 1216 pixels) - not a multiple of the 16 x 16 voxel patches the conv kernels tile the plane with at any
+    stage (22, 44, 88, 176 rows x 38, 76, 152, 304 columns), so every stage has ragged right and bottom tiles - and 2 latent
+    frames (9 video frames; the full 21 frames are 170 TFLOP, hours on the host).  f32, decode timestep 0.05.
+    Committed: a strided slice, the right and bottom edge strips on a stride, and moments."""
+    import time
+    vcfg = O.VaeConfig()
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    z = torch.randn(1, 128, 2, 22, 38, generator=torch.Generator().manual_seed(47))
+    temb = torch.full((1,), 0.05, dtype=torch.float32)
+    t0 = time.time()
+    v = O.vae_decode(vw, vcfg, z, temb, torch.float32, False, False)
+    dt = time.time() - t0
+    assert tuple(v.shape) == (1, 3, 9, 704, 1216)
+    out = {"vae_weights_checksum": weights_checksum(vw),
+           "latents_checksum": torch.tensor([float(z.double().sum()), float(z.double().abs().sum())], dtype=torch.float64),
+           "video_slice": v[:, :, ::2, ::16, ::16], "video_right": v[:, :, ::2, ::8, 1184:1216:2], "video_bottom": v[:, :, ::2, 672:704:2, ::8],
+           "video_moments": torch.tensor([float(v.double().mean()), float(v.double().std()), float(v.double().abs().sum())], dtype=torch.float64),
+           "oracle_seconds": torch.tensor([dt], dtype=torch.float64)}
+    print(f"C5-geometry VAE oracle: {dt:.1f} s, video {tuple(v.shape)} mean {float(v.mean()):.4f} std {float(v.std()):.4f}", flush=True)
+    save_file({k: c(x) for k, x in out.items()}, os.path.join(GOLD, "oracle_c5vae.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py vae_decode of a [1,128,2,22,38] latent (C5's 704x1216 plane, 2 latent frames), untiled, synthetic weights seed 32",
+                        "video_slice": "[:, :, ::2, ::16, ::16]; video_right: [:, :, ::2, ::8, 1184:1216:2]; video_bottom: [:, :, ::2, 672:704:2, ::8] of the [1,3,9,704,1216] video (before postprocess)"})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -401,6 +427,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "c4":
         c4_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5vae":
+        c5vae_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":
         ref_scripts(); ref_scripts_imported()
         sys.exit(0)
@@ -414,6 +443,7 @@ if __name__ == "__main__":
     c1_case()
     c3_case()
     c4_case()
+    c5vae_case()
+    c2_case()           # the headline config in full: ~20 minutes of host time (two 10-minute oracle runs)
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
-    # c2_case() (the headline config in full, ~20 minutes of host time) is generated on request only: gen_fixtures.py c2
     print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
