@@ -163,7 +163,7 @@ inline dim3 grid_for(int64_t n) { int64_t b = cdiv64(n, 256); if (b > 16384) b =
 }  // namespace
 
 int ltx_launch_sinusoid(void* out, int dtype, const TimeVec& tv, const float* tab, int half, int round_t, float tmul, hipStream_t s) {
-    if (tv.n < 1 || tv.n > 8) LTX_FAIL(LTX_ERR_ARG, "batch must be 1..8");
+    if (tv.n < 1 || tv.n > LTX_MAX_BATCH) LTX_FAIL(LTX_ERR_ARG, "batch must be 1..16");
     hipLaunchKernelGGL(sinusoid_kernel, grid_for(tv.n * 2 * half), dim3(256), 0, s, out, dtype, tv, tab, half, round_t, tmul);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }

@@ -117,7 +117,8 @@ bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row off
 bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
-struct TimeVec { float t[8]; int n; };
+constexpr int LTX_MAX_BATCH = 16;      // per-sample scalars a launch carries by value (API batches run as chunks of 8; tile batches use 16)
+struct TimeVec { float t[LTX_MAX_BATCH]; int n; };
 // out[b][0:half] = cos(t_b*tab), out[b][half:] = sin(t_b*tab); t rounded to T first when round_t
 // ggml blocks (device) -> dense tensor (gguf_dequant.hip)
 int ltx_launch_gguf_dequant(const void* blocks_dev, int ggml_type, int64_t numel, void* dst, int dst_dtype, hipStream_t s);

@@ -406,6 +406,9 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
         const int64_t rows_per_block = (int64_t)4 * rpw * NSLOT;
         hipLaunchKernelGGL((rownorm_kernel<T, 1>), dim3((unsigned)cdiv64(a.rows, rows_per_block)), dim3(256), 0, s, a, lpr);
     } else {
+        // (measured and left out, round 3: four rows per wave with the scale / shift operands cached in registers - 312 blocks
+        // instead of 1248 - ran the DiT's 4992 x 2048 rows in 15.9 us against 12.8 us: the pass is bound by how many row loads are
+        // in flight across the chip, not by the operand traffic through the vector-memory path)
         const int64_t rows_per_block = 4 * rpw;
         dim3 grid((unsigned)cdiv64(a.rows, rows_per_block));
         if (nch <= NSLOT * lpr) hipLaunchKernelGGL((rownorm_kernel<T, 0>), grid, dim3(256), 0, s, a, lpr);

@@ -168,34 +168,54 @@ extern "C" void ltx_t5_config_default(ltx_t5_config* c) {
     c->relative_attention_num_buckets = 32; c->relative_attention_max_distance = 128; c->layer_norm_epsilon = 1e-6f;
 }
 
-extern "C" int ltx_t5_create(const ltx_t5_config* cfg, const ltx_weight* weights, size_t n_weights,
-                             ltx_dtype model_dtype, int device, ltx_t5** out) {
-    if (!cfg || !weights || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create: null argument");
-    *out = nullptr;
+namespace {
+// construction in three steps, so that a loader can hand the weights over group by group (ltx_t5_create_from_gguf streams
+// one layer at a time through a small staging buffer) instead of holding the whole model twice
+int t5_begin(const ltx_t5_config* cfg, ltx_dtype model_dtype, int device, std::unique_ptr<ltx_t5>* out) {
     const int D = cfg->d_model, inner = cfg->num_heads * cfg->d_kv;
     if (cfg->num_layers < 1 || D % 8 || inner % 8 || cfg->d_ff % 8 || cfg->relative_attention_num_buckets < 4)
         LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create: d_model, heads*d_kv and d_ff must be multiples of 8");
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<ltx_t5> m(new ltx_t5());
     m->cfg = *cfg; m->device = device; m->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32;
-    WeightMap wm(weights, n_weights);
-    LTX_TRY(own_tensor(m.get(), wm, "shared.weight", (int64_t)cfg->vocab_size * D, m->dtype, &m->embed));
-    void* rt = nullptr;
-    LTX_TRY(own_tensor(m.get(), wm, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
-                       (int64_t)cfg->relative_attention_num_buckets * cfg->num_heads, LTX_DT_F32, &rt));
-    m->rel_table = reinterpret_cast<float*>(rt);
     m->layers.resize(cfg->num_layers);
-    for (int i = 0; i < cfg->num_layers; ++i) {
-        const std::string p = "encoder.block." + std::to_string(i) + ".layer.";
-        ltx_t5::Layer& L = m->layers[i];
-        LTX_TRY(own_fused(m.get(), wm, {p + "0.SelfAttention.q.weight", p + "0.SelfAttention.k.weight", p + "0.SelfAttention.v.weight"}, D, inner, &L.qkv));
-        LTX_TRY(own_fused(m.get(), wm, {p + "0.SelfAttention.o.weight"}, inner, D, &L.o));
-        LTX_TRY(own_tensor(m.get(), wm, p + "0.layer_norm.weight", D, m->dtype, &L.ln0));
-        LTX_TRY(own_fused(m.get(), wm, {p + "1.DenseReluDense.wi_0.weight", p + "1.DenseReluDense.wi_1.weight"}, D, cfg->d_ff, &L.wi));
-        LTX_TRY(own_fused(m.get(), wm, {p + "1.DenseReluDense.wo.weight"}, cfg->d_ff, D, &L.wo));
-        LTX_TRY(own_tensor(m.get(), wm, p + "1.layer_norm.weight", D, m->dtype, &L.ln1));
-    }
-    LTX_TRY(own_tensor(m.get(), wm, "encoder.final_layer_norm.weight", D, m->dtype, &m->final_ln));
+    *out = std::move(m);
+    return LTX_OK;
+}
+int t5_globals(ltx_t5* m, const WeightMap& wm) {
+    const ltx_t5_config& c = m->cfg;
+    LTX_TRY(own_tensor(m, wm, "shared.weight", (int64_t)c.vocab_size * c.d_model, m->dtype, &m->embed));
+    void* rt = nullptr;
+    LTX_TRY(own_tensor(m, wm, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+                       (int64_t)c.relative_attention_num_buckets * c.num_heads, LTX_DT_F32, &rt));
+    m->rel_table = reinterpret_cast<float*>(rt);
+    LTX_TRY(own_tensor(m, wm, "encoder.final_layer_norm.weight", c.d_model, m->dtype, &m->final_ln));
+    return LTX_OK;
+}
+int t5_layer(ltx_t5* m, int i, const WeightMap& wm) {
+    const ltx_t5_config& c = m->cfg;
+    const int D = c.d_model, inner = c.num_heads * c.d_kv;
+    const std::string p = "encoder.block." + std::to_string(i) + ".layer.";
+    ltx_t5::Layer& L = m->layers[i];
+    LTX_TRY(own_fused(m, wm, {p + "0.SelfAttention.q.weight", p + "0.SelfAttention.k.weight", p + "0.SelfAttention.v.weight"}, D, inner, &L.qkv));
+    LTX_TRY(own_fused(m, wm, {p + "0.SelfAttention.o.weight"}, inner, D, &L.o));
+    LTX_TRY(own_tensor(m, wm, p + "0.layer_norm.weight", D, m->dtype, &L.ln0));
+    LTX_TRY(own_fused(m, wm, {p + "1.DenseReluDense.wi_0.weight", p + "1.DenseReluDense.wi_1.weight"}, D, c.d_ff, &L.wi));
+    LTX_TRY(own_fused(m, wm, {p + "1.DenseReluDense.wo.weight"}, c.d_ff, D, &L.wo));
+    LTX_TRY(own_tensor(m, wm, p + "1.layer_norm.weight", D, m->dtype, &L.ln1));
+    return LTX_OK;
+}
+}  // namespace
+
+extern "C" int ltx_t5_create(const ltx_t5_config* cfg, const ltx_weight* weights, size_t n_weights,
+                             ltx_dtype model_dtype, int device, ltx_t5** out) {
+    if (!cfg || !weights || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create: null argument");
+    *out = nullptr;
+    std::unique_ptr<ltx_t5> m;
+    LTX_TRY(t5_begin(cfg, model_dtype, device, &m));
+    WeightMap wm(weights, n_weights);
+    LTX_TRY(t5_globals(m.get(), wm));
+    for (int i = 0; i < cfg->num_layers; ++i) LTX_TRY(t5_layer(m.get(), i, wm));
     *out = m.release();
     return LTX_OK;
 }
@@ -207,53 +227,75 @@ extern "C" int ltx_t5_forward(ltx_t5* m, const int32_t* input_ids, int B, int S,
 }
 
 // QuantizedT5EncoderModel::load_with_config (quantized_t5_encoder.rs:575-603): every tensor is dequantised to f32 on the device
-// (QTensor::dequantize), handed to ltx_t5_create under the Hugging Face name of the same weight, then released.
+// (QTensor::dequantize) and handed to the model under the Hugging Face name of the same weight.  The tensors stream through
+// ONE staging buffer a layer at a time (the largest group, one T5-XXL layer, is 0.77 GB of f32) instead of the whole model
+// sitting in f32 beside its final copy (19 GB in ~220 allocations).
 extern "C" int ltx_t5_create_from_gguf(const ltx_t5_config* cfg, const char* gguf_path, ltx_dtype model_dtype, int device, ltx_t5** out) {
     if (!cfg || !gguf_path || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_t5_create_from_gguf: null argument");
     *out = nullptr;
-    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<ltx_t5> m;
+    LTX_TRY(t5_begin(cfg, model_dtype, device, &m));
     ltx_gguf* g = nullptr;
     LTX_TRY(ltx_gguf_open(gguf_path, &g));
-    struct Guard { ltx_gguf* g; std::vector<void*> tmp; ~Guard() { for (void* p : tmp) (void)hipFree(p); ltx_gguf_close(g); } } guard{g, {}};
+    struct Guard { ltx_gguf* g; void* stage = nullptr; size_t cap = 0; ~Guard() { if (stage) (void)hipFree(stage); ltx_gguf_close(g); } } guard{g};
     const int D = cfg->d_model, inner = cfg->num_heads * cfg->d_kv;
-    std::vector<std::string> names; std::vector<ltx_weight> ws;
-    names.reserve(16 + 12 * (size_t)cfg->num_layers); ws.reserve(names.capacity());
-    auto add = [&](const std::string& gguf_name, const std::string& hf_name, int64_t d0, int64_t d1) -> int {
-        const int idx = ltx_gguf_find(g, gguf_name.c_str());
-        if (idx < 0) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "GGUF tensor '" + gguf_name + "' not found in '" + gguf_path + "'");
-        const char* nm; int type, nd; const int64_t* shp; const void* data; size_t nbytes;
-        LTX_TRY(ltx_gguf_tensor(g, (size_t)idx, &nm, &type, &nd, &shp, &data, &nbytes));
-        int64_t numel = 1; for (int i = 0; i < nd; ++i) numel *= shp[i];
-        const bool ok = d1 ? (nd == 2 && shp[0] == d0 && shp[1] == d1) : (numel == d0);
-        if (!ok) LTX_FAIL(LTX_ERR_ARG, "GGUF tensor '" + gguf_name + "': unexpected shape");
-        void* dev = nullptr;
-        HIP_TRY(hipMalloc(&dev, (size_t)numel * sizeof(float)));
-        guard.tmp.push_back(dev);
-        LTX_TRY(ltx_gguf_dequantize(type, data, 0, numel, LTX_F32, dev, nullptr));
-        names.push_back(hf_name);
-        ltx_weight w; memset(&w, 0, sizeof(w));
-        w.data = dev; w.dtype = LTX_F32; w.ndim = d1 ? 2 : 1; w.shape[0] = d0; w.shape[1] = d1; w.on_device = 1;
-        ws.push_back(w);
+    // one group = the tensors of one construction step: described first (sizes), then dequantised into the staging buffer
+    struct Item { std::string gguf_name, hf_name; int64_t d0, d1; int type; const void* data; int64_t numel; };
+    auto build_group = [&](std::vector<Item>& items, int layer) -> int {
+        size_t need = 0;
+        for (Item& it : items) {
+            const int idx = ltx_gguf_find(g, it.gguf_name.c_str());
+            if (idx < 0) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "GGUF tensor '" + it.gguf_name + "' not found in '" + gguf_path + "'");
+            const char* nm; int nd; const int64_t* shp; size_t nbytes;
+            LTX_TRY(ltx_gguf_tensor(g, (size_t)idx, &nm, &it.type, &nd, &shp, &it.data, &nbytes));
+            it.numel = 1; for (int i = 0; i < nd; ++i) it.numel *= shp[i];
+            const bool ok = it.d1 ? (nd == 2 && shp[0] == it.d0 && shp[1] == it.d1) : (it.numel == it.d0);
+            if (!ok) LTX_FAIL(LTX_ERR_ARG, "GGUF tensor '" + it.gguf_name + "': unexpected shape");
+            need += ((size_t)it.numel * sizeof(float) + 255) & ~(size_t)255;
+        }
+        if (need > guard.cap) {
+            if (guard.stage) { (void)hipFree(guard.stage); guard.stage = nullptr; guard.cap = 0; }
+            HIP_TRY(hipMalloc(&guard.stage, need)); guard.cap = need;
+        }
+        std::vector<ltx_weight> ws(items.size());
+        size_t off = 0;
+        for (size_t k = 0; k < items.size(); ++k) {
+            const Item& it = items[k];
+            void* dev = (char*)guard.stage + off;
+            off += ((size_t)it.numel * sizeof(float) + 255) & ~(size_t)255;
+            LTX_TRY(ltx_gguf_dequantize(it.type, it.data, 0, it.numel, LTX_F32, dev, nullptr));
+            ltx_weight w; memset(&w, 0, sizeof(w));
+            w.name = it.hf_name.c_str(); w.data = dev; w.dtype = LTX_F32; w.ndim = it.d1 ? 2 : 1; w.shape[0] = it.d0; w.shape[1] = it.d1; w.on_device = 1;
+            ws[k] = w;
+        }
+        WeightMap wm(ws.data(), ws.size());
+        LTX_TRY(layer < 0 ? t5_globals(m.get(), wm) : t5_layer(m.get(), layer, wm));
+        HIP_TRY(hipDeviceSynchronize());                     // the model's own copies are complete: the staging buffer is free again
         return LTX_OK;
     };
-    LTX_TRY(add("token_embd.weight", "shared.weight", cfg->vocab_size, D));
-    LTX_TRY(add("enc.blk.0.attn_rel_b.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", cfg->relative_attention_num_buckets, cfg->num_heads));
+    {
+        std::vector<Item> items = {
+            {"token_embd.weight", "shared.weight", cfg->vocab_size, D, 0, nullptr, 0},
+            {"enc.blk.0.attn_rel_b.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", cfg->relative_attention_num_buckets, cfg->num_heads, 0, nullptr, 0},
+            {"enc.output_norm.weight", "encoder.final_layer_norm.weight", D, 0, 0, nullptr, 0}};
+        LTX_TRY(build_group(items, -1));
+    }
     for (int i = 0; i < cfg->num_layers; ++i) {
         const std::string gp = "enc.blk." + std::to_string(i) + ".", hp = "encoder.block." + std::to_string(i) + ".layer.";
-        LTX_TRY(add(gp + "attn_q.weight", hp + "0.SelfAttention.q.weight", inner, D));
-        LTX_TRY(add(gp + "attn_k.weight", hp + "0.SelfAttention.k.weight", inner, D));
-        LTX_TRY(add(gp + "attn_v.weight", hp + "0.SelfAttention.v.weight", inner, D));
-        LTX_TRY(add(gp + "attn_o.weight", hp + "0.SelfAttention.o.weight", D, inner));
-        LTX_TRY(add(gp + "attn_norm.weight", hp + "0.layer_norm.weight", D, 0));
-        LTX_TRY(add(gp + "ffn_gate.weight", hp + "1.DenseReluDense.wi_0.weight", cfg->d_ff, D));      // gelu_new(gate(x)) * up(x), :437-449
-        LTX_TRY(add(gp + "ffn_up.weight", hp + "1.DenseReluDense.wi_1.weight", cfg->d_ff, D));
-        LTX_TRY(add(gp + "ffn_down.weight", hp + "1.DenseReluDense.wo.weight", D, cfg->d_ff));
-        LTX_TRY(add(gp + "ffn_norm.weight", hp + "1.layer_norm.weight", D, 0));
+        std::vector<Item> items = {
+            {gp + "attn_q.weight", hp + "0.SelfAttention.q.weight", inner, D, 0, nullptr, 0},
+            {gp + "attn_k.weight", hp + "0.SelfAttention.k.weight", inner, D, 0, nullptr, 0},
+            {gp + "attn_v.weight", hp + "0.SelfAttention.v.weight", inner, D, 0, nullptr, 0},
+            {gp + "attn_o.weight", hp + "0.SelfAttention.o.weight", D, inner, 0, nullptr, 0},
+            {gp + "attn_norm.weight", hp + "0.layer_norm.weight", D, 0, 0, nullptr, 0},
+            {gp + "ffn_gate.weight", hp + "1.DenseReluDense.wi_0.weight", cfg->d_ff, D, 0, nullptr, 0},      // gelu_new(gate(x)) * up(x), :437-449
+            {gp + "ffn_up.weight", hp + "1.DenseReluDense.wi_1.weight", cfg->d_ff, D, 0, nullptr, 0},
+            {gp + "ffn_down.weight", hp + "1.DenseReluDense.wo.weight", D, cfg->d_ff, 0, nullptr, 0},
+            {gp + "ffn_norm.weight", hp + "1.layer_norm.weight", D, 0, 0, nullptr, 0}};
+        LTX_TRY(build_group(items, i));
     }
-    LTX_TRY(add("enc.output_norm.weight", "encoder.final_layer_norm.weight", D, 0));
-    for (size_t i = 0; i < ws.size(); ++i) ws[i].name = names[i].c_str();
-    HIP_TRY(hipDeviceSynchronize());
-    return ltx_t5_create(cfg, ws.data(), ws.size(), model_dtype, device, out);
+    *out = m.release();
+    return LTX_OK;
 }
 
 extern "C" int ltx_t5_forward_masked(ltx_t5* m, const int32_t* input_ids, const float* attention_mask, int B, int S,

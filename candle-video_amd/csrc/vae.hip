@@ -35,12 +35,12 @@ struct ltx_vae {
     float *mean = nullptr, *std_ = nullptr, *vtab = nullptr;
     int mid_ch = 0, last_ch = 0;
     std::vector<void*> owned;
-    DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats;
+    DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats, predec;
     std::deque<DevBuf> tilebufs;   // deque: growing it must not move DevBufs that Tile.buf points at
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats};
+        DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats, &predec};
         for (DevBuf* b : bs) b->release();
         for (auto& b : tilebufs) b.release();
     }
@@ -217,8 +217,19 @@ GemmArgs conv_args(ltx_vae* v, const ConvW& cw, const Dims& d) {
     return g;
 }
 
+// Samples per conv launch: the fast conv kernels address their operands with 32-bit byte offsets (< 2 GiB per operand).
+// Samples never interact in a conv, so a batch whose activations pass that limit (the batched leaf tiles of a tiled decode
+// at the last stages) runs as sample groups that fit; a single sample beyond the limit goes to the launcher as it is.
+int conv_chunk(ltx_vae* v, const ConvW& cw, const Dims& d) {
+    if (d.B <= 1) return d.B;
+    const int64_t per = (int64_t)d.T * d.H * d.W;
+    const int64_t lim = (2147483648LL - (1 << 20)) / (per * std::max(cw.cin, cw.cout) * (int64_t)ltx_dt_size(v->dtype));
+    return (lim >= 1 && lim < d.B) ? (int)lim : d.B;
+}
+
 // whether conv1 of a resnet can carry norm2 in its epilogue: bf16, the halo-staged kernel with BN == channels
-bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d, int ch) {
+bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d_all, int ch) {
+    Dims d = d_all; d.B = conv_chunk(v, cw, d_all);
     auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
     if (off("LTX_VAE_FUSE_NORM") || off("LTX_GEMM_WIDE_EPI") || off("LTX_CONV_HALO") || off("LTX_GEMM_BIG")) return false;
     if (v->dtype != LTX_DT_BF16 || (ch != 128 && ch != 256) || cw.cout != ch) return false;
@@ -227,16 +238,31 @@ bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d, int ch) {
 }
 
 int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, int epi, const void* resid, int post, hipStream_t s, const PostNorm* pn = nullptr) {
-    GemmArgs g;
-    if (pn && pn->on) { g.pn_on = 1; g.pn_eps = pn->eps; g.pn_act = pn->act; g.pn_mod_stride = pn->mod_stride; g.pn_scale = pn->scale; g.pn_shift = pn->shift; }
-    g.A = x; g.W = cw.w; g.C = y; g.bias = cw.b; g.resid = resid;
-    g.M = (int)d.vox(); g.N = cw.cout; g.K = cw.cin; g.ldc = cw.cout; g.ldr = cw.cout;
-    g.conv = 1; g.B = d.B; g.T = d.T; g.H = d.H; g.Wd = d.W; g.Cin = cw.cin;
-    g.ntaps = 27; g.kh = 3; g.kw = 3;
-    g.pad_t = v->cfg.decoder_causal ? 2 : 1;          // vae.rs:383-412
-    g.post = post;
-    if (epi == EPI_D2S) { g.Cf = cw.cout / 8; g.Cr = cw.cin / 8; g.To = 2 * d.T - 1; g.Ho = 2 * d.H; g.Wo = 2 * d.W; }
-    return ltx_launch_gemm(g, v->dtype, epi, s);
+    const size_t esz = ltx_dt_size(v->dtype);
+    const int64_t per = (int64_t)d.T * d.H * d.W;
+    const int nb = conv_chunk(v, cw, d);
+    size_t out_b, res_b = 0;                              // bytes per sample of the output / residual tensor
+    if (epi == EPI_D2S) { out_b = (size_t)(2 * d.T - 1) * (2 * d.H) * (2 * d.W) * (cw.cout / 8) * esz; res_b = (size_t)per * cw.cin * esz; }
+    else if (epi == EPI_UNPATCH) out_b = (size_t)(cw.cout / 16) * d.T * (4 * d.H) * (4 * d.W) * sizeof(float);
+    else { out_b = (size_t)per * cw.cout * esz; res_b = out_b; }
+    for (int b0 = 0; b0 < d.B; b0 += nb) {
+        const int bc = std::min(nb, d.B - b0);
+        GemmArgs g;
+        if (pn && pn->on) {
+            g.pn_on = 1; g.pn_eps = pn->eps; g.pn_act = pn->act; g.pn_mod_stride = pn->mod_stride;
+            g.pn_scale = pn->scale ? pn->scale + (size_t)b0 * pn->mod_stride : nullptr; g.pn_shift = pn->shift ? pn->shift + (size_t)b0 * pn->mod_stride : nullptr;
+        }
+        g.A = (const char*)x + (size_t)b0 * per * cw.cin * esz; g.W = cw.w; g.C = (char*)y + (size_t)b0 * out_b; g.bias = cw.b;
+        g.resid = resid ? (const char*)resid + (size_t)b0 * res_b : nullptr;
+        g.M = (int)(bc * per); g.N = cw.cout; g.K = cw.cin; g.ldc = cw.cout; g.ldr = cw.cout;
+        g.conv = 1; g.B = bc; g.T = d.T; g.H = d.H; g.Wd = d.W; g.Cin = cw.cin;
+        g.ntaps = 27; g.kh = 3; g.kw = 3;
+        g.pad_t = v->cfg.decoder_causal ? 2 : 1;          // vae.rs:383-412
+        g.post = post;
+        if (epi == EPI_D2S) { g.Cf = cw.cout / 8; g.Cr = cw.cin / 8; g.To = 2 * d.T - 1; g.Ho = 2 * d.H; g.Wo = 2 * d.W; }
+        LTX_TRY(ltx_launch_gemm(g, v->dtype, epi, s));
+    }
+    return LTX_OK;
 }
 
 // CombinedTimestepEmbedder (vae.rs:236-265) + "+ scale_shift_table" -> f32 [B][rows][C]
@@ -322,11 +348,12 @@ int crop_cl(const void* src, void* dst, size_t esz, int B, int T, int H, int W, 
     return LTX_OK;
 }
 
-struct Tile { DevBuf* buf; int t, h, w; };   // decoded f32 NCTHW tile [B*3, t, h, w]
+struct Tile { float* p; int t, h, w; };   // decoded f32 NCTHW tile [B*3, t, h, w]
 
 // tiled_decode (vae.rs:2225-2290) of a channels-last latent window; result into `out` (dims oT,oH,oW given)
+// `pre` (optional): the leaf tiles already decoded, in this loop's order (batched_leaf_decode) - then nothing is decoded here.
 int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, const ltx_tiling& tl,
-                 float* out, std::deque<DevBuf>& pool, size_t& pool_used, hipStream_t s) {
+                 float* out, std::deque<DevBuf>& pool, size_t& pool_used, hipStream_t s, const std::vector<float*>* pre = nullptr) {
     const ltx_vae_config& c = v->cfg;
     const int r = c.spatial_compression_ratio, tr = c.temporal_compression_ratio;
     const size_t esz = ltx_dt_size(v->dtype);
@@ -342,21 +369,28 @@ int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const Ti
         return (*b)->ensure(bytes);
     };
     std::vector<Tile> prev, cur;
-    int oy = 0;
+    int oy = 0; size_t leaf = 0;
     for (int i = 0; i < H; i += ts_h) {
         cur.clear();
         int ox = 0; int row_h = 0;
         for (int j = 0; j < W; j += ts_w) {
             const int h1 = std::min(i + tmin_h, H), w1 = std::min(j + tmin_w, W);
             const int th = h1 - i, tw = w1 - j;
-            LTX_TRY(v->tile_lat.ensure((size_t)B * F * th * tw * c.latent_channels * esz));
-            LTX_TRY(crop_cl(z, v->tile_lat.p, esz, B, F, H, W, c.latent_channels, 0, F, i, h1, j, w1, s));
             Tile t; t.t = oT; t.h = th * r; t.w = tw * r;
-            LTX_TRY(take((size_t)BC * t.t * t.h * t.w * sizeof(float), &t.buf));
-            LTX_TRY(decoder_forward(v, v->tile_lat.p, B, F, th, tw, tv, 0, t.buf->as<float>(), s));
+            if (pre) {
+                if (leaf >= pre->size()) LTX_FAIL(LTX_ERR_ARG, "tiled decode: fewer pre-decoded leaves than tiles");
+                t.p = (*pre)[leaf++];
+            } else {
+                LTX_TRY(v->tile_lat.ensure((size_t)B * F * th * tw * c.latent_channels * esz));
+                LTX_TRY(crop_cl(z, v->tile_lat.p, esz, B, F, H, W, c.latent_channels, 0, F, i, h1, j, w1, s));
+                DevBuf* tb = nullptr;
+                LTX_TRY(take((size_t)BC * t.t * t.h * t.w * sizeof(float), &tb));
+                t.p = tb->as<float>();
+                LTX_TRY(decoder_forward(v, v->tile_lat.p, B, F, th, tw, tv, 0, t.p, s));
+            }
             const size_t ci = cur.size();
             if (!prev.empty()) {        // blend_v with the (already blended) tile above
-                BlendArgs ba; ba.a = prev[ci].buf->as<float>(); ba.b = t.buf->as<float>(); ba.dst = t.buf->as<float>(); ba.BC = BC;
+                BlendArgs ba; ba.a = prev[ci].p; ba.b = t.p; ba.dst = t.p; ba.BC = BC;
                 ba.at = prev[ci].t; ba.ah = prev[ci].h; ba.aw = prev[ci].w; ba.a_len = prev[ci].h;
                 ba.bt = ba.dt = t.t; ba.bh = ba.dh = t.h; ba.bw = ba.dw = t.w;
                 ba.dim = 3; ba.blend = std::min(blend_h, std::min(prev[ci].h, t.h));
@@ -364,7 +398,7 @@ int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const Ti
                 LTX_TRY(ltx_launch_blend(ba, s));
             }
             if (ci > 0) {               // blend_h with the (already blended) tile to the left
-                BlendArgs ba; ba.a = cur[ci - 1].buf->as<float>(); ba.b = t.buf->as<float>(); ba.dst = t.buf->as<float>(); ba.BC = BC;
+                BlendArgs ba; ba.a = cur[ci - 1].p; ba.b = t.p; ba.dst = t.p; ba.BC = BC;
                 ba.at = cur[ci - 1].t; ba.ah = cur[ci - 1].h; ba.aw = cur[ci - 1].w; ba.a_len = cur[ci - 1].w;
                 ba.bt = ba.dt = t.t; ba.bh = ba.dh = t.h; ba.bw = ba.dw = t.w;
                 ba.dim = 4; ba.blend = std::min(blend_w, std::min(cur[ci - 1].w, t.w));
@@ -375,11 +409,72 @@ int tiled_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const Ti
             const int hs = std::min(tl.tile_sample_stride_height, t.h), ws = std::min(tl.tile_sample_stride_width, t.w);
             const int ch = std::min(hs, oH - oy), cw_ = std::min(ws, oW - ox);
             if (ch > 0 && cw_ > 0)
-                LTX_TRY(ltx_launch_copy_window(t.buf->as<float>(), t.t, t.h, t.w, out, oT, oH, oW, BC, oT, ch, cw_, 0, oy, ox, s));
+                LTX_TRY(ltx_launch_copy_window(t.p, t.t, t.h, t.w, out, oT, oH, oW, BC, oT, ch, cw_, 0, oy, ox, s));
             ox += ws; row_h = hs;
         }
         oy += row_h;
         prev = cur;
+    }
+    return LTX_OK;
+}
+
+// Leaf tiles of the framewise + spatially tiled decode, decoded up front in batches.  The reference's tiled decode is a serial
+// loop of independent `decoder.forward` calls on small latents (vae.rs:2382-2408 around :2246-2257; C2: 52 calls of at most
+// 3 x 16 x 16 latents), whose first stages cannot fill the chip one tile at a time (the mid block of one tile is 768
+// voxels).  Leaves that share a latent shape - the same spatial tile of different temporal windows - are stacked along the
+// batch axis (up to 16 samples per decoder call), and the blends then run over the decoded tiles in exactly the reference's
+// order (tiled_decode with `pre`).  A decoder call on a batch gives each sample the bits it gets alone: no op crosses samples.
+// per_window[li] = the window's leaves in tiled_decode's loop order.  LTX_VAE_TILE_BATCH=0: one call per leaf (A/B aid).
+int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeVec* tv, const ltx_tiling& tl,
+                        std::vector<std::vector<float*>>& per_window, hipStream_t s) {
+    const ltx_vae_config& c = v->cfg;
+    const int r = c.spatial_compression_ratio, tr = c.temporal_compression_ratio;
+    const size_t esz = ltx_dt_size(v->dtype);
+    const int tmin_t = tl.tile_sample_min_num_frames / tr, tstride_t = tl.tile_sample_stride_num_frames / tr;
+    const int tmin_h = tl.tile_sample_min_height / r, tmin_w = tl.tile_sample_min_width / r;
+    const int ts_h = tl.tile_sample_stride_height / r, ts_w = tl.tile_sample_stride_width / r;
+    if (tstride_t < 1 || ts_h < 1 || ts_w < 1) LTX_FAIL(LTX_ERR_ARG, "tiling: stride must be >= one latent");
+    struct Leaf { int li, slot, t0, t1, h0, h1, w0, w1; };
+    std::vector<Leaf> leaves;
+    int nwin = 0;
+    for (int i = 0; i < F; i += tstride_t, ++nwin) {
+        const int t1 = std::min(i + tmin_t + 1, F);
+        int slot = 0;
+        for (int y = 0; y < H; y += ts_h)
+            for (int x = 0; x < W; x += ts_w) leaves.push_back({nwin, slot++, i, t1, y, std::min(y + tmin_h, H), x, std::min(x + tmin_w, W)});
+    }
+    per_window.assign(nwin, {});
+    for (const Leaf& l : leaves) if ((int)per_window[l.li].size() <= l.slot) per_window[l.li].resize(l.slot + 1, nullptr);
+    auto elems = [&](const Leaf& l) { return (size_t)B * c.out_channels * ((size_t)(l.t1 - l.t0 - 1) * tr + 1) * ((size_t)(l.h1 - l.h0) * r) * ((size_t)(l.w1 - l.w0) * r); };
+    size_t total = 0;
+    for (const Leaf& l : leaves) total += elems(l);
+    LTX_TRY(v->predec.ensure(total * sizeof(float)));
+    const char* be = getenv("LTX_VAE_TILE_BATCH");
+    int max_n = (be && be[0] == '0') ? 1 : LTX_MAX_BATCH / B; if (max_n < 1) max_n = 1;
+    std::vector<char> done(leaves.size(), 0);
+    float* cursor = v->predec.as<float>();
+    for (size_t a = 0; a < leaves.size(); ++a) {
+        if (done[a]) continue;
+        const Leaf& la = leaves[a];
+        const int nf = la.t1 - la.t0, th = la.h1 - la.h0, tw = la.w1 - la.w0;
+        std::vector<size_t> grp;
+        for (size_t b = a; b < leaves.size() && (int)grp.size() < max_n; ++b) {
+            const Leaf& lb = leaves[b];
+            if (!done[b] && lb.t1 - lb.t0 == nf && lb.h1 - lb.h0 == th && lb.w1 - lb.w0 == tw) { grp.push_back(b); done[b] = 1; }
+        }
+        const int n = (int)grp.size();
+        const size_t leaf_lat = (size_t)B * nf * th * tw * c.latent_channels * esz, leaf_out = elems(la);
+        LTX_TRY(v->tile_lat.ensure(leaf_lat * n));
+        TimeVec tvb; tvb.n = n * B;
+        for (int k = 0; k < LTX_MAX_BATCH; ++k) tvb.t[k] = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const Leaf& l = leaves[grp[k]];
+            LTX_TRY(crop_cl(z, (char*)v->tile_lat.p + leaf_lat * k, esz, B, F, H, W, c.latent_channels, l.t0, l.t1, l.h0, l.h1, l.w0, l.w1, s));
+            per_window[l.li][l.slot] = cursor + leaf_out * k;
+            if (tv) for (int b = 0; b < B; ++b) tvb.t[k * B + b] = tv->t[b];
+        }
+        LTX_TRY(decoder_forward(v, v->tile_lat.p, n * B, nf, th, tw, tv ? &tvb : nullptr, 0, cursor, s));
+        cursor += leaf_out * n;
     }
     return LTX_OK;
 }
@@ -403,6 +498,8 @@ int decode_cl(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeV
         const int blend_t = std::max(tl->tile_sample_min_num_frames - tl->tile_sample_stride_num_frames, 0);
         const int tmin_h = tl->tile_sample_min_height / r, tmin_w = tl->tile_sample_min_width / r;
         DevBuf zt;                       // temporal latent window
+        std::vector<std::vector<float*>> pre;                 // spatially tiled windows: every leaf decoded up front, in batches
+        if (tl->use_tiling && (H > tmin_h || W > tmin_w)) LTX_TRY(batched_leaf_decode(v, z, B, F, H, W, tv, *tl, pre, s));
         int prev_t = 0, prev_stride = 0; int ot = 0; int li = 0;
         for (int i = 0; i < F; i += tstride_t, ++li) {
             const int t1 = std::min(i + tmin_t + 1, F), nf = t1 - i;
@@ -416,7 +513,7 @@ int decode_cl(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeV
             if (rc != LTX_OK) { zt.release(); return rc; }
             const bool sp = tl->use_tiling && (H > tmin_h || W > tmin_w);
             size_t pu = 0;
-            rc = sp ? tiled_decode(v, zt.p, B, nf, H, W, tv, *tl, cur.as<float>(), v->tilebufs, pu, s)
+            rc = sp ? tiled_decode(v, zt.p, B, nf, H, W, tv, *tl, cur.as<float>(), v->tilebufs, pu, s, pre.empty() ? nullptr : &pre[li])
                     : decoder_forward(v, zt.p, B, nf, H, W, tv, 0, cur.as<float>(), s);
             if (rc != LTX_OK) { zt.release(); return rc; }
             // "if i > 0: decoded = decoded[:, :, :-1]" — keep the buffer, shrink the logical length
