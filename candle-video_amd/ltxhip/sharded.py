@@ -271,13 +271,19 @@ def _decode_temporal_sharded(decode_tile, blend, z: torch.Tensor, tl: Tiling, te
     num_sample_frames = (F - 1) * tr + 1
     tiled = _temporal_is_tiled(tl, H, W)
     row = {}
+    # every leaf this rank owns, decoded up front: a `decode_tile` that carries a `.many(list of crops)` attribute (HipOps: leaves
+    # of one shape stacked along the batch axis, as the single-GPU engine does) gets them all at once; results per leaf are the same
+    grids = {li: (_spatial_crops(tl, ranges[li][0], ranges[li][1], H, W) if tiled else [[(ranges[li][0], ranges[li][1], 0, H, 0, W)]]) for li in mine}
+    flat = [(li, ri, ci, c) for li in mine for ri, r_ in enumerate(grids[li]) for ci, c in enumerate(r_)]
+    crops = [z[:, :, c[0]:c[1], c[2]:c[3], c[4]:c[5]].contiguous() for (_, _, _, c) in flat]
+    many = getattr(decode_tile, "many", None)
+    decs = many(crops) if many is not None else [decode_tile(c) for c in crops]
+    leaf = {(li, ri, ci): d.float() for (li, ri, ci, _), d in zip(flat, decs)}
     for li in mine:                                                   # vae.rs:2382-2408
-        t0, t1 = ranges[li]
         if tiled:
-            grid = _spatial_crops(tl, t0, t1, H, W)
-            dec = _assemble_spatial(tl, [[decode_tile(z[:, :, c[0]:c[1], c[2]:c[3], c[4]:c[5]].contiguous()).float() for c in r_] for r_ in grid], H, W, blend)
+            dec = _assemble_spatial(tl, [[leaf[(li, ri, ci)] for ci in range(len(r_))] for ri, r_ in enumerate(grids[li])], H, W, blend)
         else:
-            dec = decode_tile(z[:, :, t0:t1].contiguous()).float()
+            dec = leaf[(li, 0, 0)]
         if li > 0 and dec.shape[2] > 1:
             dec = dec[:, :, :-1]
         row[li] = dec
@@ -416,6 +422,24 @@ class HipOps:
                 return self.vae.decode(zc, [timestep] * zc.shape[0] if timestep is not None else None)
             finally:
                 self.vae.use_tiling, self.vae.use_framewise_decoding = keep
+
+        def many(crops):
+            """leaves of one latent shape stacked along the batch axis (one decoder call per group of <= 8: no op of the
+            decoder crosses samples, so every leaf gets what it gets alone up to the f32 summation order of split-K convs)"""
+            out = [None] * len(crops)
+            groups = {}
+            for i, c in enumerate(crops):
+                groups.setdefault(tuple(c.shape), []).append(i)
+            for idxs in groups.values():
+                nb = crops[idxs[0]].shape[0]
+                step = max(1, 8 // nb)
+                for k in range(0, len(idxs), step):
+                    part = idxs[k:k + step]
+                    dec = fn(torch.cat([crops[i] for i in part], 0))
+                    for j, i in enumerate(part):
+                        out[i] = dec[j * nb:(j + 1) * nb]
+            return out
+        fn.many = many
         return fn
 
     @staticmethod

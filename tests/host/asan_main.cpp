@@ -163,6 +163,27 @@ int main(int argc, char** argv) {
     }
     CHECK(ltx_preset_name(-1) == nullptr && ltx_preset_name(99) == nullptr);
     { ltx_preset p; CHECK(ltx_preset_get(huge.c_str(), &p) == 0 && std::strcmp(p.version, "0.9.5") == 0); }
+    // ---- vae/config.json reader (vae.rs:30-66 serde names and aliases): a full file, every truncation of it, every single-byte
+    // corruption of it - the parser may refuse, it must not read out of bounds or leak
+    {
+        const std::string good = "{\"_class_name\": \"AutoencoderKLLTXVideo\", \"latent_channels\": 128, \"decoder_block_out_channels\": [256, 512, 1024], "
+                                 "\"decoder_spatio_temporal_scaling\": [true, true, true], \"decoder_layers_per_block\": [5, 5, 5, 5], \"patch_size\": 4, \"patch_size_t\": 1, "
+                                 "\"resnet_norm_eps\": 1e-06, \"scaling_factor\": 1.0, \"decoder_inject_noise\": [false, false, false, false], "
+                                 "\"upsample_residual\": [true, false, true], \"upsample_factor\": [2, 2, 2], \"timestep_conditioning\": true, \"decoder_causal\": false, "
+                                 "\"nested\": {\"a\": [1, {\"b\": null}], \"s\": \"x\\\"y\\u00e9\"}}";
+        const std::string cj = dir + "/config.json";
+        auto put = [&](const std::string& text) { FILE* f = std::fopen(cj.c_str(), "wb"); if (!f) return false; std::fwrite(text.data(), 1, text.size(), f); std::fclose(f); return true; };
+        CHECK(put(good));
+        ltx_vae_config c; ltx_vae_config_default(&c);
+        CHECK(ltx_vae_config_from_json(cj.c_str(), &c) == 0);
+        CHECK(c.n_blocks == 3 && c.decoder_upsample_residual[1] == 0 && c.decoder_upsample_residual[2] == 1 && c.decoder_block_out_channels[2] == 1024);
+        for (size_t n = 0; n < good.size(); ++n) { put(good.substr(0, n)); ltx_vae_config d; ltx_vae_config_default(&d); (void)ltx_vae_config_from_json(cj.c_str(), &d); }
+        for (size_t n = 0; n < good.size(); ++n) {
+            std::string bad = good; bad[n] = (char)(bad[n] ^ 0x5a);
+            put(bad); ltx_vae_config d; ltx_vae_config_default(&d); (void)ltx_vae_config_from_json(cj.c_str(), &d);
+        }
+        CHECK(ltx_vae_config_from_json((dir + "/absent.json").c_str(), &c) != 0 && ltx_vae_config_from_json(nullptr, &c) != 0);
+    }
     // ---- frame files: PNG + GIF (main.rs:653-707) on odd sizes, one pixel, and a refused empty frame
     for (int w : {1, 7, 64}) for (int h : {1, 5, 48}) {
         std::vector<uint8_t> rgb((size_t)3 * w * h * 3);
