@@ -75,7 +75,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    // The activation descriptor is based at the earliest frame this tile reads (the clamped frame of tap 0), so the 32-bit
+    // offsets span at most three frames (3 * H * W * Cin * 2 B < 2 GiB) and the tensor itself may be any size - the 13B
+    // model's last stages are 9 and 35 GB (BASELINE C5), which used to fall back to the 128 x 128 register-staged kernel.
+    const int64_t frame_elems = (int64_t)g.H * g.Wd * g.Cin;
+    const int tt0 = t - g.pad_t < 0 ? 0 : (t - g.pad_t > g.T - 1 ? g.T - 1 : t - g.pad_t);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + ((int64_t)b * g.T + tt0) * frame_elems), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
     auto dma = [&](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, unsigned char* lds) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         if (!loader || piece >= A_PIECES) return;
         const int it = grp / KC, kc = grp - it * KC;
         int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);          // replicate pad on T (vae.rs:374-413)
-        const uint32_t soff = (uint32_t)(b * g.T + tt) * frame_bytes + (uint32_t)kc * 128u;
+        const uint32_t soff = (uint32_t)(tt - tt0) * frame_bytes + (uint32_t)kc * 128u;
         dma(ra, a_voff[j], soff, Abuf + (grp & 1) * A_STAGE + piece * 1024);
     };
     auto issue_b = [&](int grp, int hw, int buf) {          // weight tile of step (grp, hw)
@@ -207,7 +212,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     if constexpr (WIDE) {
         if (g.wide_epi) {
             constexpr int CPR = BN / 8, XM = 15, RPP = 64 / CPR;
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.resid ? g.resid : g.C), 0, (int)OOB, 0x00020000);
+            // the residual is addressed inside the tile's own frame (32-bit offsets span one frame of the output)
+            const int64_t frame_row0 = ((int64_t)b * g.T + t) * g.H * g.Wd;
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(g.resid ? g.resid : g.C) + frame_row0 * g.ldr), 0, (int)OOB, 0x00020000);
             auto row_m = [&](int row, bool& inside) {                 // tile row (patch voxel) -> output row index
                 const int y = y0 + (row >> 4), x = x0 + (row & 15);
                 inside = y < g.H && x < g.Wd;
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                     const int row = pi * RPP + lane / CPR, pc = lane % CPR;
                     const int lc = pc ^ (row & XM);
                     bool inside; const int m = row_m(row, inside);
-                    dma(rr, inside ? (uint32_t)(((int64_t)m * g.ldr + n0 + lc * 8) * 2) : OOB, 0u, halo_smem + pi * 1024);
+                    dma(rr, inside ? (uint32_t)((((int64_t)m - frame_row0) * g.ldr + n0 + lc * 8) * 2) : OOB, 0u, halo_smem + pi * 1024);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -315,7 +323,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     GemmArgs ga = g;
     const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
-                  (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.M * g.ldr * 2.0 < 2147483648.0));
+                  (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.H * g.Wd * g.ldr * 2.0 < 2147483648.0));
     if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
     LTX_CHECK_LAUNCH();
@@ -340,8 +348,9 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
     if (g.Cin % 64 != 0 || g.K != g.Cin || g.N % bn != 0) return false;
     if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
     if (g.c_seg_shift) return false;
-    const double a_bytes = (double)g.M * g.Cin * 2.0, w_bytes = 27.0 * g.N * g.K * 2.0;
-    return a_bytes < 2147483648.0 && w_bytes < 2147483648.0;
+    // a tile addresses the three frames around it: those (not the tensor) and the weights must stay below 2 GiB
+    const double frame_bytes = (double)g.H * g.Wd * g.Cin * 2.0, w_bytes = 27.0 * g.N * g.K * 2.0;
+    return 3.0 * frame_bytes < 2147483648.0 && w_bytes < 2147483648.0 && (double)g.B * g.T * g.H * g.Wd < 2147483648.0;
 }
 
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {

@@ -90,8 +90,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
     // lane -> (row in group = lane>>3, physical chunk = lane&7), logical chunk = pc ^ ((row>>1)&7).
     // Addressing is buffer-style (buffer_load_dwordx4 ... lds): a loop-invariant 32-bit byte offset per lane (row start
     // + chunk) plus a wave-uniform scalar offset (K position / tap), out-of-range offsets read as zeros (K tails, conv halo).
-    constexpr uint32_t OOB = 0x80000000u;                 // >= num_records; ltx_gemm_big_eligible keeps operands < 2 GiB
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;                 // >= num_records; ltx_gemm_big_fits keeps every addressed span < 2 GiB
+    // conv mode: the descriptor is based a little before the tile's first voxel (two frames + one row + one voxel: every tap
+    // of every row of the tile, replicate-clamped frames included, lies at a non-negative offset), so the 32-bit offsets span
+    // the tile's own neighbourhood and the activation tensor may be any size (the 13B decode's last stages are 9 and 35 GB)
+    const int64_t m_base = CONV ? (m0 > 2 * g.H * g.Wd + g.Wd + 1 ? (int64_t)m0 - (2 * g.H * g.Wd + g.Wd + 1) : 0) : 0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (CONV ? m_base * g.Cin : 0)), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
     const int lr = lane >> 3, pc = lane & 7;
     int a_chunk[AI], b_chunk[BI];
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             const int h = t1 % g.H; const int t2 = t1 / g.H;
             ct[j] = t2 % g.T;
             vmask[j] = (h > 0 ? 1 : 0) | 2 | (h < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0);
-            a_off[j] = ((uint32_t)m * (uint32_t)g.Cin + a_chunk[j] * 8) * 2u;
+            a_off[j] = ((uint32_t)(m - m_base) * (uint32_t)g.Cin + a_chunk[j] * 8) * 2u;
         } else {
             a_off[j] = ((uint32_t)m * (uint32_t)g.lda + a_chunk[j] * 8) * 2u;
         }
@@ -549,12 +553,22 @@ int ltx_gemm_big_pick_tile(int M, int N) {
     return bi;
 }
 
+// 32-bit buffer offsets (0x80000000 = out of range).  Linear layers address whole operands; a conv tile addresses a window of
+// the activation around itself (gemm_big) or one frame (conv_halo), so only that window has to stay below 2 GiB.
+bool ltx_gemm_big_fits(const GemmArgs& g) {
+    const double w_bytes = (double)(g.conv ? g.ntaps : 1) * g.N * g.K * 2.0;
+    if (w_bytes >= 2147483648.0) return false;
+    if (!g.conv) return (double)g.M * g.lda * 2.0 < 2147483648.0;
+    const double window_rows = 3.0 * g.H * g.Wd + 2.0 * g.Wd + 512.0;      // two frames back, one forward, the tile itself
+    return window_rows * g.Cin * 2.0 < 2147483648.0 && (double)g.B * g.T * g.H * g.Wd < 2147483648.0;
+}
+
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     if (dtype != LTX_DT_BF16) return false;
     const char* off = getenv("LTX_GEMM_BIG");
     if (off && off[0] == '0') return false;
     if (g.conv && (g.kh > 3 || g.kw > 3)) return false;   // the validity mask covers 3x3 (and 1x1) spatial taps
-    if (!ltx_gemm_p8_fits(g)) return false;               // 32-bit buffer offsets: operands < 2 GiB (else gemm.hip's kernel)
+    if (!ltx_gemm_big_fits(g)) return false;              // 32-bit buffer offsets: every addressed span < 2 GiB (else gemm.hip's kernel)
     // Linear layers of any M take the 128-row tiles with the shape-only split-K (small outputs: up to 8 K-ranges per tile, so
     // the weight matrix streams through every CU): context k/v and caption projections (M = 128), the timestep MLPs
     // (M = 1) and the T5 encoder's M = 128 GEMMs run 1.5-2.5x faster than on gemm.hip's 128 x 128 register-staged kernel
@@ -643,6 +657,10 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         HIP_TRY(hipEventRecord(e1, s));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (ms >= 10.f) {                                    // a launch this long (the 13B decode's last stages) is its own measurement
+            if (ms < best) { best = ms; *plan_out = plan; }
+            continue;
+        }
         int n = ms > 0.f ? (int)(1.5f / ms) : 16;
         n = n < 3 ? 3 : (n > 16 ? 16 : n);
         for (int round = 0; round < 3; ++round) {

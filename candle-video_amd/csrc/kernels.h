@@ -61,6 +61,7 @@ int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile ta
 int ltx_gemm_p8_choice(const GemmArgs& g);  // gemm_p8.hip: phase-interleaved 256-row kernel; returns BN (256/128) or 0
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s);
 bool ltx_gemm_p8_fits(const GemmArgs& g);
+bool ltx_gemm_big_fits(const GemmArgs& g);   // gemm_big.hip: every span its 32-bit buffer offsets address stays below 2 GiB
 // conv_halo.hip: 3x3x3 conv with the activation patch + rim staged once per nine in-plane taps; bn = 128 / 256
 bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn);
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s);   // operands addressable with the kernel's 32-bit buffer offsets

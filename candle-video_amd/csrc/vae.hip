@@ -222,6 +222,11 @@ GemmArgs conv_args(ltx_vae* v, const ConvW& cw, const Dims& d) {
 // at the last stages) runs as sample groups that fit; a single sample beyond the limit goes to the launcher as it is.
 int conv_chunk(ltx_vae* v, const ConvW& cw, const Dims& d) {
     if (d.B <= 1) return d.B;
+    {   // the large-tile conv kernels address a window around each tile, not the tensor: whole batch in one launch where they apply
+        GemmArgs g; g.M = (int)std::min<int64_t>(d.vox(), 2147483647); g.N = cw.cout; g.K = cw.cin; g.conv = 1; g.B = d.B; g.T = d.T; g.H = d.H; g.Wd = d.W;
+        g.Cin = cw.cin; g.ntaps = 27; g.kh = 3; g.kw = 3;
+        if (v->dtype == LTX_DT_BF16 && d.vox() < 2147483647 && ltx_gemm_big_eligible(g, v->dtype)) return d.B;
+    }
     const int64_t per = (int64_t)d.T * d.H * d.W;
     const int64_t lim = (2147483648LL - (1 << 20)) / (per * std::max(cw.cin, cw.cout) * (int64_t)ltx_dt_size(v->dtype));
     return (lim >= 1 && lim < d.B) ? (int)lim : d.B;
