@@ -19,6 +19,8 @@ namespace {
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GEMM_ASM_LOOP_INC
 #define GEMM_ASM_LOOP_INC "gemm_asm_loop.inc"
 #endif
@@ -128,14 +130,251 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
     }
 }
 
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16 (LTX_GEMM_ASM=16; tools/gen_gemm_asm.py gen16).  Round 3: the vendor library's
+// kernel for these shapes, disassembled, is this structure - four waves of 128 x 128, LDS-DMA staging - with the 16x16x32 MFMA,
+// the shape that holds a higher clock at equal cycles per FLOP.  Fragment = 16 rows x 32 k: lane (rr = lane & 15, q = lane >> 4)
+// reads row rr of a 16-row block, logical chunk 4 half + q; accumulator block (nb, mb) = D = W_frag x A_frag: the lane holds
+// output row m = mb * 16 + rr and the four consecutive columns nb * 16 + 4 q .. + 3.  Same k order as gemm_big: same bits.
+template <int BM, int BN, int WGM, int WGN> struct AsmLoop16;
+template <> struct AsmLoop16<256, 256, 2, 2> {
+    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[8], T&&... t) { gemm_asm16_loop_256_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], t...); }
+    static __device__ __forceinline__ void store(int, const f32x32 (&c)[8], const u32x8& ad) { gemm_asm16_store_256_256_p0(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], ad); }
+};
+template <> struct AsmLoop16<160, 256, 1, 4> {
+    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[8], T&&... t) { gemm_asm16_loop_160_256(c[0], c[1], c[2], c[3], c[4], t...); }
+    static __device__ __forceinline__ void store(int p, const f32x32 (&c)[8], const u32x8& ad) {
+        if (p == 0) gemm_asm16_store_160_256_p0(c[0], c[1], c[2], c[3], c[4], ad); else gemm_asm16_store_160_256_p1(c[0], c[1], c[2], c[3], c[4], ad);
+    }
+};
+
+#ifdef GEMM_ASM_TRACE      // tools/gemm_asm_tune.py trace: per-wave cycle sums of the K-step's segments (loop generated with trace=1)
+__device__ uint32_t g_asm16_trace[1024 * 4 * 16];   // per wave: 8 segment sums, then entry / loop start / loop end / exit (100 MHz clock) and HW_ID
+#endif
+
+template <int BM, int BN, int WGM, int WGN, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, NT = MB * NB, AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+#ifdef GEMM_ASM_TRACE
+    const uint32_t t_entry = (uint32_t)wall_clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, q = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int ntn = (g.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    if (g.xcd_remap) {
+        const int nblk = (int)gridDim.x, qq = nblk >> 3, r8 = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r8 ? x * (qq + 1) : r8 * (qq + 1) + (x - r8) * qq) + i;
+    }
+    int mt, nt;
+    if (g.group_m > 1) {
+        const int ntm = (g.M + BM - 1) / BM, gsz = g.group_m * ntn;
+        const int grp = bid / gsz, w = bid - grp * gsz, gm0 = grp * g.group_m;
+        const int rows = ntm - gm0 < g.group_m ? ntm - gm0 : g.group_m;
+        nt = w / rows; mt = gm0 + (w - nt * rows);
+    } else { mt = bid / ntn; nt = bid - mt * ntn; }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int lr = lane >> 3, pc = lane & 7;
+    u32x16 dma0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma0[j] = 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = 8 * (j * 4 + wave) + lr;
+        int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
+#ifdef ASM16_NOSWZ        // timing ablation (wrong results): lanes of a piece read ascending addresses
+        dma0[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)pc * 8u) * 2u;
+#else
+        dma0[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = 8 * (j * 4 + wave) + lr;
+        int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
+#ifdef ASM16_NOSWZ
+        dma0[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)pc * 8u) * 2u;
+#else
+        dma0[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+#endif
+    }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)asm_smem;
+    u32x8 rbase;                                               // W [stage][half] then A [stage][half]
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const uint32_t ch = (uint32_t)(((4 * kh + q) ^ ((rr >> 1) & 7)) << 4);
+            rbase[st * 2 + kh] = smem_base + st * STAGE + BM * 128 + (wn * WN + rr) * 128 + ch;
+            rbase[4 + st * 2 + kh] = smem_base + st * STAGE + (wm * WM + rr) * 128 + ch;
+        }
+    const uint64_t ap = (uint64_t)(uintptr_t)g.A, wp = (uint64_t)(uintptr_t)g.W;
+    const u32x4 ra = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ap), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ap >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
+    const u32x4 rw = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
+    const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 1024u));
+    const int nk = __builtin_amdgcn_readfirstlane(g.K / 64);
+    f32x32 c[8];
+#ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
+#else
+    const uint32_t k0 = 0u;
+#endif
+#ifdef GEMM_ASM_TRACE
+    uint32_t tr[8];
+    const uint32_t t_loop0 = (uint32_t)wall_clock64();
+    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2), tr);
+    const uint32_t t_loop1 = (uint32_t)wall_clock64();
+#else
+    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
+#endif
+    // Wide epilogue.  One wave per SIMD hides no latency and the 256 accumulators leave no registers to unroll into, so the
+    // fragment-wise epilogue of gemm_big (serial bias load -> wait -> 8-byte store per block) took 8-10 us of a 60 us block
+    // (tools/gemm_asm_tune.py trace).  Here the f32 accumulators go through LDS - free after the K loop - in row passes of
+    // RP tile rows: the waves that own rows of the pass write their blocks (16-byte chunk c of row r at chunk c ^ (r & 15):
+    // conflict-free for the 8-lane write groups and the 16-lane read groups), then ALL threads walk the pass row-major: thread
+    // (row = tid / 32 + 8 k, cg = tid % 32) owns columns 4 cg .. + 3 and 128 + 4 cg .. + 3 of its rows, keeps its bias / gate
+    // vectors in registers, reads the residual straight from global memory (8 bytes per lane, 256 contiguous bytes per half row)
+    // and applies bias / GELU / gate / residual with the expressions of epilogue(): same bits.
+    // (No fragment-wise fallback in this kernel: extracting elements of the accumulator tuples makes the compiler copy all 256
+    // to VGPRs and spill; shapes that do not meet the conditions - ltx_gemm_asm16_epilogue_ok - stay on gemm_big.)
+    {
+        static_assert(BN == 256, "thread -> column map below");
+        constexpr int RP = BM == 256 ? 128 : 80;           // tile rows per pass: RP KiB of f32 must fit the two stages
+        static_assert(RP * 1024 <= 2 * STAGE && BM % RP == 0 && RP % 16 == 0 && RP % 8 == 0, "pass geometry");
+        constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
+        const int r0 = tid >> 5, cg = tid & 31;
+        int nA = n0 + 4 * cg, nB = nA + 128;
+        const bool okA = nA < g.N, okB = nB < g.N;         // N % 8 == 0: a 4-column group is inside or outside as a whole
+        if (!okA) nA = 0;
+        if (!okB) nB = 0;
+        float bA[4] = {0.f, 0.f, 0.f, 0.f}, bB[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) { load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nA, bA); load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nB, bB); }
+        // Output and residual tiles through buffer descriptors based at the tile's first row: 32-bit offsets, rows beyond M
+        // and column groups beyond N fall out of range (stores dropped, loads return 0) - no branch around a memory operation.
+        // A tile lies in ONE column segment of a segmented output (segment width % 256 == 0: ltx_gemm_asm_eligible).
+        bf16_t* Ct = reinterpret_cast<bf16_t*>(g.C);
+        {
+            int nc = n0;
+            if (g.c_seg_shift) { const int sg = n0 >> g.c_seg_shift; Ct += sg * g.c_seg_stride; nc -= sg << g.c_seg_shift; }
+            Ct += (int64_t)m0 * g.ldc + nc;
+        }
+        const int rows_valid = g.M - m0 < BM ? g.M - m0 : BM;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, (int)(((uint32_t)(rows_valid - 1) * (uint32_t)g.ldc + 256u) * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(g.resid ? g.resid : g.C) + (g.resid ? (int64_t)m0 * g.ldr + n0 : 0)), 0,
+            (int)(g.resid ? ((uint32_t)(rows_valid - 1) * (uint32_t)g.ldr + 256u) * 2u : 0u), 0x00020000);
+        const uint32_t cA = okA ? (uint32_t)(8 * cg) : 0x80000000u, cB = okB ? (uint32_t)(8 * cg + 256) : 0x80000000u;
+        const int m_last = m0 + rows_valid - 1;
+        bool one_batch = true;
+        f32x4 gA = {}, gB = {};
+        if constexpr (EPI == EPI_GATE_RESID) {
+            one_batch = m0 / g.rows_per_batch == m_last / g.rows_per_batch;
+            const float* gp = g.gate + (int64_t)(m0 / g.rows_per_batch) * g.gate_stride;
+            gA = *reinterpret_cast<const f32x4*>(gp + nA); gB = *reinterpret_cast<const f32x4*>(gp + nB);
+        }
+        // value of one 4-column group: the expressions of epilogue() (gemm_common.h), residual already loaded
+        auto finish = [&](const f32x4& acc, const float* bias4, const f32x4& gate_one, const bf16x4& res, int n, int m, float* v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias4[i];
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+            } else if constexpr (HAS_R) {
+                const float r[4] = {(float)res[0], (float)res[1], (float)res[2], (float)res[3]};
+                if constexpr (EPI == EPI_GATE_RESID) {
+                    f32x4 gt = gate_one;
+                    if (!one_batch) gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(m / g.rows_per_batch) * g.gate_stride + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += r[i];
+                }
+            }
+        };
+        u32x8 ad;                                          // LDS address of (local row rr, column block nb) for the stores below
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const int chunk = (wn * WN + (nb < NB ? nb : 0) * 16 + 4 * q) >> 2;
+            ad[nb] = smem_base + (uint32_t)(rr * 1024 + ((chunk ^ rr) << 4));
+        }
+#ifdef GEMM_ASM_TRACE
+        uint32_t t_e0 = 0, t_e1 = 0, t_e2 = 0;
+#endif
+#pragma unroll
+        for (int p = 0; p < BM / RP; ++p) {
+            __syncthreads();                               // K loop (or the previous pass) is done with the LDS image in every wave
+#ifdef GEMM_ASM_TRACE
+            if (p == 0) t_e0 = (uint32_t)wall_clock64();
+#endif
+            // the wave's accumulator blocks of this pass, AGPR -> LDS (generated: gemm_asm16_store_*; the tuples stay opaque here)
+            if (WGM == 1 || wm == p) AsmLoop16<BM, BN, WGM, WGN>::store(p, c, ad);
+#ifdef GEMM_ASM_TRACE
+            if (p == 0) t_e1 = (uint32_t)wall_clock64();
+#endif
+            __syncthreads();
+#ifdef GEMM_ASM_TRACE
+            if (p == 0) t_e2 = (uint32_t)wall_clock64();
+#endif
+            // UN rows per step: all LDS reads and residual loads of the step are issued before the first use (rows beyond M
+            // are computed on clamped addresses and not stored - no branch in front of a load)
+            constexpr int UN = RP % 32 == 0 ? 4 : 5;
+            static_assert((RP / 8) % UN == 0, "row steps");
+#pragma unroll 1
+            for (int k0 = 0; k0 < RP / 8; k0 += UN) {
+                f32x4 vA[UN], vB[UN];
+                bf16x4 qA[UN] = {}, qB[UN] = {};
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const int row = r0 + 8 * (k0 + j);
+                    const unsigned char* rowp = asm_smem + row * 1024;
+                    vA[j] = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
+                    vB[j] = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
+                    if constexpr (HAS_R) {
+                        const uint32_t ro = (uint32_t)(p * RP + row) * (uint32_t)g.ldr * 2u;
+                        qA[j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)(ro + cA), 0, 0));
+                        qB[j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)(ro + cB), 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const int trow = p * RP + r0 + 8 * (k0 + j);
+                    const int m = m0 + trow < g.M ? m0 + trow : g.M - 1;       // gate row of a straddling tile only
+                    float oA[4], oB[4];
+                    finish(vA[j], bA, gA, qA[j], nA, m, oA);
+                    finish(vB[j], bB, gB, qB[j], nB, m, oB);
+                    const uint32_t co = (uint32_t)trow * (uint32_t)g.ldc * 2u;
+                    const bf16x4 pA = {(bf16_t)oA[0], (bf16_t)oA[1], (bf16_t)oA[2], (bf16_t)oA[3]}, pB = {(bf16_t)oB[0], (bf16_t)oB[1], (bf16_t)oB[2], (bf16_t)oB[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pA), rc, (int)(co + cA), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pB), rc, (int)(co + cB), 0, 0);
+                }
+            }
+        }
+#ifdef GEMM_ASM_TRACE
+        if (lane == 0 && blockIdx.x < 1024) { uint32_t* o = g_asm16_trace + (blockIdx.x * 4 + wave) * 16; o[13] = t_e0; o[14] = t_e1; o[15] = t_e2; }
+#endif
+    }
+#ifdef GEMM_ASM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && blockIdx.x < 1024) {
+        uint32_t* o = g_asm16_trace + (blockIdx.x * 4 + wave) * 16;
+        for (int i = 0; i < 8; ++i) o[i] = tr[i];
+        uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[8] = t_entry; o[9] = t_loop0; o[10] = t_loop1; o[11] = (uint32_t)wall_clock64(); o[12] = hwid;
+    }
+#endif
+}
+
 struct AsmTile { int bm, bn; const char* name; };
 const AsmTile kAsmTiles[] = {{256, 256, "asm256x256"}, {320, 256, "asm320x256"}, {160, 256, "asm160x256"}};
 
-template <int BM, int BN, int WGM, int WGN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int EPI, bool MF16 = false>
 int launch_asm(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static std::atomic<unsigned long long> attr_devs{0};
-    auto kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
+    void (*kern)(const GemmArgs);
+    if constexpr (MF16) kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI>; else kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     GemmArgs ga = g;
     const char* xr = getenv("LTX_XCD_REMAP");
@@ -154,13 +393,13 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
     return LTX_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool MF16 = false>
 int launch_asm_epi(const GemmArgs& g, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_BIAS: return launch_asm<BM, BN, WGM, WGN, EPI_BIAS>(g, s);
-        case EPI_GELU: return launch_asm<BM, BN, WGM, WGN, EPI_GELU>(g, s);
-        case EPI_GATE_RESID: return launch_asm<BM, BN, WGM, WGN, EPI_GATE_RESID>(g, s);
-        case EPI_RESID: return launch_asm<BM, BN, WGM, WGN, EPI_RESID>(g, s);
+        case EPI_BIAS: return launch_asm<BM, BN, WGM, WGN, EPI_BIAS, MF16>(g, s);
+        case EPI_GELU: return launch_asm<BM, BN, WGM, WGN, EPI_GELU, MF16>(g, s);
+        case EPI_GATE_RESID: return launch_asm<BM, BN, WGM, WGN, EPI_GATE_RESID, MF16>(g, s);
+        case EPI_RESID: return launch_asm<BM, BN, WGM, WGN, EPI_RESID, MF16>(g, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_asm: bad epilogue");
 }
@@ -171,11 +410,19 @@ int launch_asm_epi(const GemmArgs& g, int epi, hipStream_t s) {
 bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi) {
     if (dtype != LTX_DT_BF16 || g.conv) return false;
     // EXPERIMENT, off unless LTX_GEMM_ASM=1: measured 4-12 % behind gemm_big on the DiT shapes ("one wave per SIMD")
-    const char* e = getenv("LTX_GEMM_ASM");
+    const char* e = getenv("LTX_GEMM_ASM");               // "1": 32x32x16 loop, "16": 16x16x32 loop
     if (!e || e[0] != '1') return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     if (g.K < 128 || g.K % 64 != 0 || g.lda % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
     if ((double)g.M * g.lda * 2.0 >= 2147483648.0 || (double)g.N * g.K * 2.0 >= 2147483648.0) return false;     // 32-bit buffer offsets
+    if (e[1] == '6') {                                     // the 16x16x32 kernel's epilogue: 4-column groups inside or outside N as a whole, 8-byte aligned rows
+        const bool seg_ok = !g.c_seg_shift || ((1 << g.c_seg_shift) % 256 == 0 && g.c_seg_stride % 4 == 0);
+        if ((double)g.ldc * 2.0 * 320.0 >= 2147483648.0 || (double)g.ldr * 2.0 * 320.0 >= 2147483648.0) return false;     // 32-bit offsets inside a tile
+        if (g.N % 8 != 0 || g.ldc % 4 != 0 || ((uintptr_t)g.C & 7) || !seg_ok) return false;
+        if (g.bias && ((uintptr_t)g.bias & 7)) return false;
+        if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
+        if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
+    }
     if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
     return g.M >= 2048 && g.N >= 1024;
 }
@@ -192,7 +439,19 @@ int ltx_gemm_asm_pick_tile(int M, int N) {
 }
 const char* ltx_gemm_asm_tile_name(int i) { return i >= 0 && i < 3 ? kAsmTiles[i].name : ""; }
 
+#ifdef GEMM_ASM_TRACE
+extern "C" int ltx_dbg_gemm_asm16_trace(uint32_t* out, int n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_asm16_trace), (size_t)n_words * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {
+    const char* e = getenv("LTX_GEMM_ASM");
+    if (e && e[0] == '1' && e[1] == '6') {                 // 16x16x32 loop: 256 x 256 and 160 x 256 tiles
+        int tile = ltx_gemm_asm_pick_tile(g.M, g.N);
+        if (tile == 1) tile = 0;                           // no 320 x 256 form (its 320 accumulator registers do not fit the AGPR half)
+        return tile == 0 ? launch_asm_epi<256, 256, 2, 2, true>(g, epi, s) : launch_asm_epi<160, 256, 1, 4, true>(g, epi, s);
+    }
     switch (ltx_gemm_asm_pick_tile(g.M, g.N)) {
         case 0: return launch_asm_epi<256, 256, 2, 2>(g, epi, s);
         case 1: return launch_asm_epi<320, 256, 2, 2>(g, epi, s);

@@ -19,9 +19,10 @@ def hip():
     return ltxhip
 
 
-@pytest.mark.parametrize("tile", ["asm256x256", "asm320x256", "asm160x256"])
+@pytest.mark.parametrize("mode,tile", [("1", "asm256x256"), ("1", "asm320x256"), ("1", "asm160x256"), ("16", "asm256x256"), ("16", "asm160x256")])
 @pytest.mark.parametrize("M,N,K,epi", [(4992, 2048, 2048, 0), (4992, 6144, 2048, 1), (3001, 4104, 192, 0), (4992, 2048, 8192, 3)])
-def test_asm_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
+def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
+    """mode "1": the 32x32x16 loop; "16": the 16x16x32 loop (round 3: the MFMA shape of the vendor kernel for these shapes)."""
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
@@ -31,7 +32,7 @@ def test_asm_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
     try:
         os.environ.pop("LTX_GEMM_ASM", None); os.environ.pop("LTX_GEMM_ASM_TILE", None)
         ref = hip.ops.linear(x, w, b, epi=epi, resid=resid)
-        os.environ["LTX_GEMM_ASM"] = "1"; os.environ["LTX_GEMM_ASM_TILE"] = tile
+        os.environ["LTX_GEMM_ASM"] = mode; os.environ["LTX_GEMM_ASM_TILE"] = tile
         got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
     finally:
         for k, v in old.items():
@@ -42,3 +43,40 @@ def test_asm_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
     ref32 = (x.float() @ w.float().t() + b.float())
     if epi == 0: assert (got.float() - ref32).norm() / ref32.norm() < 3e-3      # and it is a GEMM, not two equal wrongs
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("tile", ["asm256x256", "asm160x256"])
+def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
+    """The remaining epilogues of the DiT on the 16x16x32 loop's wide (LDS-transposed) epilogue: gate * y + residual with one
+    f32 gate row per batch element (ragged M: the last row tile is partial) and the q|k|v projection written as three dense
+    matrices; bit-identical to gemm_big's wide epilogue and to its fragment-wise one (LTX_GEMM_WIDE_EPI=0)."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, N, K = 2 * 1531, 2048, 2048
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    resid = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    gate = torch.randn(2, N, device="cuda", generator=g)
+    w3 = (torch.randn(3 * N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16(); b3 = torch.randn(3 * N, device="cuda", generator=g).bfloat16()
+    keys = ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_WIDE_EPI")
+    old = {k: os.environ.get(k) for k in keys}
+    def run():
+        return hip.ops.linear(x, w, b, epi=2, resid=resid, gate=gate, rows_per_batch=1531), hip.ops.linear_segmented(x, w3, b3, N)
+    try:
+        for k in keys: os.environ.pop(k, None)
+        ref = run()
+        os.environ["LTX_GEMM_WIDE_EPI"] = "0"
+        narrow = run()
+        os.environ.pop("LTX_GEMM_WIDE_EPI")
+        os.environ["LTX_GEMM_ASM"] = "16"; os.environ["LTX_GEMM_ASM_TILE"] = tile
+        wide = run()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    torch.cuda.synchronize()
+    want = resid.float() + gate.repeat_interleave(1531, 0) * (x.float() @ w.float().t() + b.float())
+    assert (ref[0].float() - want).norm() / want.norm() < 4e-3
+    for got in (wide, narrow):
+        for a, r in zip(got, ref):
+            assert torch.equal(a.view(torch.int16), r.view(torch.int16))

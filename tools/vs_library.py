@@ -13,4 +13,8 @@ for name, M, N, K in [("qkv", S, 6144, 2048), ("to_out", S, 2048, 2048), ("ff1",
     for rnd in range(3):
         res.setdefault("ltxhip", []).append(2 * M * N * K / timeit(lambda: ltxhip.ops.linear(x, w, b), iters=10, warm=3) / 1e9)
         res.setdefault("library", []).append(2 * M * N * K / timeit(lambda: torch.nn.functional.linear(x, w, b), iters=10, warm=3) / 1e9)
+        if os.environ.get("VS_ASM"):                       # the opt-in one-wave-per-SIMD asm loop beside them (LTX_GEMM_ASM is read per launch)
+            os.environ["LTX_GEMM_ASM"] = os.environ["VS_ASM"]
+            res.setdefault("asm", []).append(2 * M * N * K / timeit(lambda: ltxhip.ops.linear(x, w, b), iters=10, warm=3) / 1e9)
+            del os.environ["LTX_GEMM_ASM"]
     print(json.dumps({"case": name, "TFLOPs": {k: round(sorted(v)[1], 1) for k, v in res.items()}, "plan": ltxhip.ops.gemm_plan(M, N, K)}))
