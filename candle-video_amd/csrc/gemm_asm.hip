@@ -407,22 +407,33 @@ int launch_asm_epi(const GemmArgs& g, int epi, hipStream_t s) {
 }  // namespace
 
 // Shape-only eligibility (see the header comment): bf16 linear layers large enough to fill the chip with 256-wide tiles.
-bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi) {
-    if (dtype != LTX_DT_BF16 || g.conv) return false;
-    // EXPERIMENT, off unless LTX_GEMM_ASM=1: measured 4-12 % behind gemm_big on the DiT shapes ("one wave per SIMD")
-    const char* e = getenv("LTX_GEMM_ASM");               // "1": 32x32x16 loop, "16": 16x16x32 loop
-    if (!e || e[0] != '1') return false;
+// What the 16x16x32 kernel needs of a call (shape, strides, pointers, epilogue) - no environment: the plan family
+// "asm16:*" of gemm_big.hip measures it beside the gemm_big tiles wherever this holds.
+bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi) {
+    if (g.conv || g.pn_on) return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     if (g.K < 128 || g.K % 64 != 0 || g.lda % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
     if ((double)g.M * g.lda * 2.0 >= 2147483648.0 || (double)g.N * g.K * 2.0 >= 2147483648.0) return false;     // 32-bit buffer offsets
-    if (e[1] == '6') {                                     // the 16x16x32 kernel's epilogue: 4-column groups inside or outside N as a whole, 8-byte aligned rows
-        const bool seg_ok = !g.c_seg_shift || ((1 << g.c_seg_shift) % 256 == 0 && g.c_seg_stride % 4 == 0);
-        if ((double)g.ldc * 2.0 * 320.0 >= 2147483648.0 || (double)g.ldr * 2.0 * 320.0 >= 2147483648.0) return false;     // 32-bit offsets inside a tile
-        if (g.N % 8 != 0 || g.ldc % 4 != 0 || ((uintptr_t)g.C & 7) || !seg_ok) return false;
-        if (g.bias && ((uintptr_t)g.bias & 7)) return false;
-        if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
-        if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
-    }
+    // epilogue: 4-column groups inside or outside N as a whole, 8-byte aligned rows, a tile inside one column segment
+    const bool seg_ok = !g.c_seg_shift || ((1 << g.c_seg_shift) % 256 == 0 && g.c_seg_stride % 4 == 0);
+    if ((double)g.ldc * 2.0 * 320.0 >= 2147483648.0 || (double)g.ldr * 2.0 * 320.0 >= 2147483648.0) return false;     // 32-bit offsets inside a tile
+    if (g.N % 8 != 0 || g.ldc % 4 != 0 || ((uintptr_t)g.C & 7) || !seg_ok) return false;
+    if (g.bias && ((uintptr_t)g.bias & 7)) return false;
+    if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
+    if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
+    if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
+    return g.M >= 512 && g.N >= 512;
+}
+
+// LTX_GEMM_ASM forces the family for every shape it serves (tests, A/B): "1" the 32x32x16 loop, "16" the 16x16x32 loop.
+bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi) {
+    if (dtype != LTX_DT_BF16 || g.conv) return false;
+    const char* e = getenv("LTX_GEMM_ASM");
+    if (!e || e[0] != '1') return false;
+    if (e[1] == '6') return ltx_gemm_asm16_fits(g, epi) && g.M >= 2048 && g.N >= 1024;
+    if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
+    if (g.K < 128 || g.K % 64 != 0 || g.lda % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
+    if ((double)g.M * g.lda * 2.0 >= 2147483648.0 || (double)g.N * g.K * 2.0 >= 2147483648.0) return false;     // 32-bit buffer offsets
     if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
     return g.M >= 2048 && g.N >= 1024;
 }
@@ -444,6 +455,10 @@ extern "C" int ltx_dbg_gemm_asm16_trace(uint32_t* out, int n_words) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_asm16_trace), (size_t)n_words * 4) == hipSuccess ? 0 : -1;
 }
 #endif
+
+int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {     // tile 0: 256 x 256, 1: 160 x 256
+    return tile == 0 ? launch_asm_epi<256, 256, 2, 2, true>(g, epi, s) : launch_asm_epi<160, 256, 1, 4, true>(g, epi, s);
+}
 
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {
     const char* e = getenv("LTX_GEMM_ASM");

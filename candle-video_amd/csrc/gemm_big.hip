@@ -587,6 +587,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
 namespace {
 constexpr int kPlanP8 = 100;
 constexpr int kPlanHalo = 200;           // + {0: BN=128, 1: BN=256} (conv_halo.hip)
+constexpr int kPlanAsm16 = 300;          // + {0: 256 x 256, 1: 160 x 256} (gemm_asm.hip, the 16x16x32 one-wave-per-SIMD kernel; linear layers)
 struct PlanKey {
     int M, N, K, conv, ntaps, T, H, W;
     bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
@@ -597,6 +598,7 @@ std::mutex g_plan_mu;
 // The predicates tune_plan applies before it measures a plan: a cached / loaded plan must pass them again for the shape
 // it is used on (a stale or hand-edited plan file, or one saved under other LTX_* settings).
 bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
+    if (plan >= kPlanAsm16) return plan <= kPlanAsm16 + 1 && !split_shape && nk >= 2 && N >= 512 && N % 8 == 0;
     if (plan >= kPlanHalo) return plan <= kPlanHalo + 1 && !split_shape;
     if (plan >= kPlanP8) return plan <= kPlanP8 + 1 && !split_shape && nk >= 2 && N > 64 && !(plan == kPlanP8 && N <= 128);
     return plan >= 0 && plan < kNumTiles && tile_fits(kTiles[plan], N);
@@ -604,6 +606,7 @@ bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
 bool plan_ok(const GemmArgs& g, int epi, int plan) {
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     if (!plan_shape_ok(plan, g.N, nk, ltx_gemm_split_factor(g) > 1)) return false;
+    if (plan >= kPlanAsm16) return ltx_gemm_asm16_fits(g, epi);
     if (plan >= kPlanHalo) return true;                    // run_plan checks the halo kernel's own eligibility (epilogue-dependent)
     if (plan >= kPlanP8) return ltx_gemm_p8_fits(g);
     (void)epi;
@@ -612,6 +615,7 @@ bool plan_ok(const GemmArgs& g, int epi, int plan) {
 
 int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
     if (!plan_ok(g, epi, plan)) plan = ltx_gemm_big_pick_tile(g.M, g.N);
+    if (plan >= kPlanAsm16) return ltx_launch_gemm_asm16(g, epi, plan - kPlanAsm16, s);
     if (plan >= kPlanHalo) {
         const int bn = plan == kPlanHalo ? 128 : 256;
         if (ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
@@ -640,8 +644,13 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     const char* he = getenv("LTX_CONV_HALO");
     const bool halo_off = he && he[0] == '0';
     const bool split_shape = ltx_gemm_split_factor(g) > 1;     // split shapes run gemm_big tiles only (same K partition in every plan)
-    for (int plan = 0; plan < kPlanHalo + 2; ++plan) {
-        if (plan < kPlanP8) {
+    const char* a16 = getenv("LTX_GEMM_ASM16");
+    const bool asm16_off = a16 && a16[0] == '0';
+    for (int plan = 0; plan < kPlanAsm16 + 2; ++plan) {
+        if (plan >= kPlanAsm16) {
+            if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
+        } else if (plan >= kPlanHalo + 2) { plan = kPlanAsm16 - 1; continue; }
+        else if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
             if (!tile_fits(kTiles[plan], g.N)) continue;
             if (const char* ex = getenv("LTX_GEMM_EXCLUDE")) { if (strstr(ex, kTiles[plan].name)) continue; }   // A/B aid: tiles left out of the measurement
@@ -688,11 +697,13 @@ PlanKey plan_key(const GemmArgs& g) {
     return key;
 }
 const char* plan_name(int plan) {
+    if (plan >= kPlanAsm16) return plan == kPlanAsm16 ? "asm16:256x256" : "asm16:160x256";
     if (plan >= kPlanHalo) return plan == kPlanHalo ? "halo:128" : "halo:256";
     if (plan >= kPlanP8) return plan == kPlanP8 ? "p8:256" : "p8:128";
     return plan >= 0 && plan < kNumTiles ? kTiles[plan].name : "";
 }
 int plan_from_name(const char* n) {
+    if (!strcmp(n, "asm16:256x256")) return kPlanAsm16; if (!strcmp(n, "asm16:160x256")) return kPlanAsm16 + 1;
     if (!strcmp(n, "halo:128")) return kPlanHalo; if (!strcmp(n, "halo:256")) return kPlanHalo + 1;
     if (!strcmp(n, "p8:256")) return kPlanP8; if (!strcmp(n, "p8:128")) return kPlanP8 + 1;
     for (int i = 0; i < kNumTiles; ++i) if (!strcmp(n, kTiles[i].name)) return i;
@@ -746,7 +757,7 @@ extern "C" int ltx_plan_load(const char* path) {
             GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = key.conv; g.ntaps = key.conv ? key.ntaps : 1;
             const int nk = (key.K + 63) / 64 * g.ntaps;
             const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && (!key.conv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0));
-            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanHalo && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
+            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanAsm16 && (key.conv || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
                 fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: plan not valid for its shape: ") + line);
             }
         }
@@ -766,7 +777,7 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     if (split_shape) {                                     // gemm_big tiles only: one K partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
         if (!getenv("LTX_GEMM_TILE")) (void)cached_or_tuned_plan(g, s, &plan);
-        if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);
+        if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)
         return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
     }
     if (const char* he = getenv("LTX_CONV_HALO")) {        // "128" / "256" force the halo-staged conv kernel where eligible (tests, A/B)

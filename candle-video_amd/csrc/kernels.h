@@ -55,6 +55,8 @@ int ltx_gemm_split_factor(const GemmArgs& g);   // gemm_big.hip: K-ranges a smal
 // gemm_asm.hip: one-wave-per-SIMD kernels with a generated asm K loop; eligibility is a function of the shape only
 bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi);
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s);
+bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi);                       // the 16x16x32 one-wave-per-SIMD kernel (plan family asm16:*)
+int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s);
 int ltx_gemm_asm_pick_tile(int M, int N);
 const char* ltx_gemm_asm_tile_name(int i);
 int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table
