@@ -136,15 +136,26 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
 // reads row rr of a 16-row block, logical chunk 4 half + q; accumulator block (nb, mb) = D = W_frag x A_frag: the lane holds
 // output row m = mb * 16 + rr and the four consecutive columns nb * 16 + 4 q .. + 3.  Same k order as gemm_big: same bits.
 template <int BM, int BN, int WGM, int WGN> struct AsmLoop16;
+// run: the K loop; store(p, wm, ...): the wave's accumulator blocks that belong to row pass p of the epilogue -> LDS
 template <> struct AsmLoop16<256, 256, 2, 2> {
-    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[8], T&&... t) { gemm_asm16_loop_256_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], t...); }
-    static __device__ __forceinline__ void store(int, const f32x32 (&c)[8], const u32x8& ad) { gemm_asm16_store_256_256_p0(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], ad); }
+    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[10], const u32x8& rb, const u32x16& d0, const u32x2&, T&&... t) {
+        gemm_asm16_loop_256_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], rb, d0, t...); }
+    static __device__ __forceinline__ void store(int p, int wm, const f32x32 (&c)[10], const u32x8& ad) {
+        if (wm == p) gemm_asm16_store_256_256_p0(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], ad); }
 };
 template <> struct AsmLoop16<160, 256, 1, 4> {
-    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[8], T&&... t) { gemm_asm16_loop_160_256(c[0], c[1], c[2], c[3], c[4], t...); }
-    static __device__ __forceinline__ void store(int p, const f32x32 (&c)[8], const u32x8& ad) {
-        if (p == 0) gemm_asm16_store_160_256_p0(c[0], c[1], c[2], c[3], c[4], ad); else gemm_asm16_store_160_256_p1(c[0], c[1], c[2], c[3], c[4], ad);
-    }
+    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[10], const u32x8& rb, const u32x16& d0, const u32x2&, T&&... t) {
+        gemm_asm16_loop_160_256(c[0], c[1], c[2], c[3], c[4], rb, d0, t...); }
+    static __device__ __forceinline__ void store(int p, int, const f32x32 (&c)[10], const u32x8& ad) {
+        if (p == 0) gemm_asm16_store_160_256_p0(c[0], c[1], c[2], c[3], c[4], ad); else gemm_asm16_store_160_256_p1(c[0], c[1], c[2], c[3], c[4], ad); }
+};
+template <> struct AsmLoop16<320, 256, 2, 2> {             // 320 accumulator registers: a[0:255] and v[192:255]
+    template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[10], const u32x8& rb, const u32x16& d0, const u32x2& d1, T&&... t) {
+        gemm_asm16_loop_320_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], rb, d0, d1, t...); }
+    static __device__ __forceinline__ void store(int p, int wm, const f32x32 (&c)[10], const u32x8& ad) {
+        if (wm != (p >> 1)) return;
+        if ((p & 1) == 0) gemm_asm16_store_320_256_p0(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], ad);
+        else gemm_asm16_store_320_256_p1(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], ad); }
 };
 
 #ifdef GEMM_ASM_TRACE      // tools/gemm_asm_tune.py trace: per-wave cycle sums of the K-step's segments (loop generated with trace=1)
@@ -176,17 +187,18 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     } else { mt = bid / ntn; nt = bid - mt * ntn; }
     const int m0 = mt * BM, n0 = nt * BN;
     const int lr = lane >> 3, pc = lane & 7;
-    u32x16 dma0;
+    u32x16 dma0; u32x2 dma1 = {0x80000000u, 0x80000000u};    // source offsets of the wave's AI + BI (<= 18) pieces of a K-step
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma0[j] = 0x80000000u;
+    auto set_piece = [&](int j, uint32_t v) { if (j < 16) dma0[j] = v; else dma1[j - 16] = v; };
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int row = 8 * (j * 4 + wave) + lr;
         int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
 #ifdef ASM16_NOSWZ        // timing ablation (wrong results): lanes of a piece read ascending addresses
-        dma0[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)pc * 8u) * 2u;
+        set_piece(j, ((uint32_t)m * (uint32_t)g.lda + (uint32_t)pc * 8u) * 2u);
 #else
-        dma0[j] = ((uint32_t)m * (uint32_t)g.lda + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+        set_piece(j, ((uint32_t)m * (uint32_t)g.lda + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u);
 #endif
     }
 #pragma unroll
@@ -194,9 +206,9 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         const int row = 8 * (j * 4 + wave) + lr;
         int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
 #ifdef ASM16_NOSWZ
-        dma0[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)pc * 8u) * 2u;
+        set_piece(AI + j, ((uint32_t)n * (uint32_t)g.K + (uint32_t)pc * 8u) * 2u);
 #else
-        dma0[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+        set_piece(AI + j, ((uint32_t)n * (uint32_t)g.K + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u);
 #endif
     }
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)asm_smem;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     const u32x4 rw = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
     const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 1024u));
     const int nk = __builtin_amdgcn_readfirstlane(g.K / 64);
-    f32x32 c[8];
+    f32x32 c[10];
 #ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
 #else
@@ -223,10 +235,10 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #ifdef GEMM_ASM_TRACE
     uint32_t tr[8];
     const uint32_t t_loop0 = (uint32_t)wall_clock64();
-    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2), tr);
+    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, dma1, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2), tr);
     const uint32_t t_loop1 = (uint32_t)wall_clock64();
 #else
-    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
+    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, dma1, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
 #endif
     // Wide epilogue.  One wave per SIMD hides no latency and the 256 accumulators leave no registers to unroll into, so the
     // fragment-wise epilogue of gemm_big (serial bias load -> wait -> 8-byte store per block) took 8-10 us of a 60 us block
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
             if (p == 0) t_e0 = (uint32_t)wall_clock64();
 #endif
             // the wave's accumulator blocks of this pass, AGPR -> LDS (generated: gemm_asm16_store_*; the tuples stay opaque here)
-            if (WGM == 1 || wm == p) AsmLoop16<BM, BN, WGM, WGN>::store(p, c, ad);
+            AsmLoop16<BM, BN, WGM, WGN>::store(p, wm, c, ad);
 #ifdef GEMM_ASM_TRACE
             if (p == 0) t_e1 = (uint32_t)wall_clock64();
 #endif
@@ -456,16 +468,16 @@ extern "C" int ltx_dbg_gemm_asm16_trace(uint32_t* out, int n_words) {
 }
 #endif
 
-int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {     // tile 0: 256 x 256, 1: 160 x 256
-    return tile == 0 ? launch_asm_epi<256, 256, 2, 2, true>(g, epi, s) : launch_asm_epi<160, 256, 1, 4, true>(g, epi, s);
+int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {     // tile 0: 256 x 256, 1: 160 x 256, 2: 320 x 256
+    if (tile == 0) return launch_asm_epi<256, 256, 2, 2, true>(g, epi, s);
+    return tile == 1 ? launch_asm_epi<160, 256, 1, 4, true>(g, epi, s) : launch_asm_epi<320, 256, 2, 2, true>(g, epi, s);
 }
 
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {
     const char* e = getenv("LTX_GEMM_ASM");
     if (e && e[0] == '1' && e[1] == '6') {                 // 16x16x32 loop: 256 x 256 and 160 x 256 tiles
-        int tile = ltx_gemm_asm_pick_tile(g.M, g.N);
-        if (tile == 1) tile = 0;                           // no 320 x 256 form (its 320 accumulator registers do not fit the AGPR half)
-        return tile == 0 ? launch_asm_epi<256, 256, 2, 2, true>(g, epi, s) : launch_asm_epi<160, 256, 1, 4, true>(g, epi, s);
+        const int tile = ltx_gemm_asm_pick_tile(g.M, g.N);  // kAsmTiles order: 256 x 256, 320 x 256, 160 x 256
+        return ltx_launch_gemm_asm16(g, epi, tile == 0 ? 0 : (tile == 1 ? 2 : 1), s);
     }
     switch (ltx_gemm_asm_pick_tile(g.M, g.N)) {
         case 0: return launch_asm_epi<256, 256, 2, 2>(g, epi, s);

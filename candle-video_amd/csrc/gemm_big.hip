@@ -587,7 +587,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
 namespace {
 constexpr int kPlanP8 = 100;
 constexpr int kPlanHalo = 200;           // + {0: BN=128, 1: BN=256} (conv_halo.hip)
-constexpr int kPlanAsm16 = 300;          // + {0: 256 x 256, 1: 160 x 256} (gemm_asm.hip, the 16x16x32 one-wave-per-SIMD kernel; linear layers)
+constexpr int kPlanAsm16 = 300;          // + {0: 256 x 256, 1: 160 x 256, 2: 320 x 256} (gemm_asm.hip, the 16x16x32 one-wave-per-SIMD kernel; linear layers)
 struct PlanKey {
     int M, N, K, conv, ntaps, T, H, W;
     bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
@@ -598,7 +598,7 @@ std::mutex g_plan_mu;
 // The predicates tune_plan applies before it measures a plan: a cached / loaded plan must pass them again for the shape
 // it is used on (a stale or hand-edited plan file, or one saved under other LTX_* settings).
 bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
-    if (plan >= kPlanAsm16) return plan <= kPlanAsm16 + 1 && !split_shape && nk >= 2 && N >= 512 && N % 8 == 0;
+    if (plan >= kPlanAsm16) return plan <= kPlanAsm16 + 2 && !split_shape && nk >= 2 && N >= 512 && N % 8 == 0;
     if (plan >= kPlanHalo) return plan <= kPlanHalo + 1 && !split_shape;
     if (plan >= kPlanP8) return plan <= kPlanP8 + 1 && !split_shape && nk >= 2 && N > 64 && !(plan == kPlanP8 && N <= 128);
     return plan >= 0 && plan < kNumTiles && tile_fits(kTiles[plan], N);
@@ -646,7 +646,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     const bool split_shape = ltx_gemm_split_factor(g) > 1;     // split shapes run gemm_big tiles only (same K partition in every plan)
     const char* a16 = getenv("LTX_GEMM_ASM16");
     const bool asm16_off = a16 && a16[0] == '0';
-    for (int plan = 0; plan < kPlanAsm16 + 2; ++plan) {
+    for (int plan = 0; plan < kPlanAsm16 + 3; ++plan) {
         if (plan >= kPlanAsm16) {
             if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
         } else if (plan >= kPlanHalo + 2) { plan = kPlanAsm16 - 1; continue; }
@@ -697,13 +697,13 @@ PlanKey plan_key(const GemmArgs& g) {
     return key;
 }
 const char* plan_name(int plan) {
-    if (plan >= kPlanAsm16) return plan == kPlanAsm16 ? "asm16:256x256" : "asm16:160x256";
+    if (plan >= kPlanAsm16) return plan == kPlanAsm16 ? "asm16:256x256" : (plan == kPlanAsm16 + 1 ? "asm16:160x256" : "asm16:320x256");
     if (plan >= kPlanHalo) return plan == kPlanHalo ? "halo:128" : "halo:256";
     if (plan >= kPlanP8) return plan == kPlanP8 ? "p8:256" : "p8:128";
     return plan >= 0 && plan < kNumTiles ? kTiles[plan].name : "";
 }
 int plan_from_name(const char* n) {
-    if (!strcmp(n, "asm16:256x256")) return kPlanAsm16; if (!strcmp(n, "asm16:160x256")) return kPlanAsm16 + 1;
+    if (!strcmp(n, "asm16:256x256")) return kPlanAsm16; if (!strcmp(n, "asm16:160x256")) return kPlanAsm16 + 1; if (!strcmp(n, "asm16:320x256")) return kPlanAsm16 + 2;
     if (!strcmp(n, "halo:128")) return kPlanHalo; if (!strcmp(n, "halo:256")) return kPlanHalo + 1;
     if (!strcmp(n, "p8:256")) return kPlanP8; if (!strcmp(n, "p8:128")) return kPlanP8 + 1;
     for (int i = 0; i < kNumTiles; ++i) if (!strcmp(n, kTiles[i].name)) return i;

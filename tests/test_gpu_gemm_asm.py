@@ -19,7 +19,7 @@ def hip():
     return ltxhip
 
 
-@pytest.mark.parametrize("mode,tile", [("1", "asm256x256"), ("1", "asm320x256"), ("1", "asm160x256"), ("16", "asm256x256"), ("16", "asm160x256")])
+@pytest.mark.parametrize("mode,tile", [("1", "asm256x256"), ("1", "asm320x256"), ("1", "asm160x256"), ("16", "asm256x256"), ("16", "asm160x256"), ("16", "asm320x256")])
 @pytest.mark.parametrize("M,N,K,epi", [(4992, 2048, 2048, 0), (4992, 6144, 2048, 1), (3001, 4104, 192, 0), (4992, 2048, 8192, 3)])
 def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
     """mode "1": the 32x32x16 loop; "16": the 16x16x32 loop (round 3: the MFMA shape of the vendor kernel for these shapes)."""
@@ -45,7 +45,7 @@ def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
 
-@pytest.mark.parametrize("tile", ["asm256x256", "asm160x256"])
+@pytest.mark.parametrize("tile", ["asm256x256", "asm160x256", "asm320x256"])
 def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
     """The remaining epilogues of the DiT on the 16x16x32 loop's wide (LDS-transposed) epilogue: gate * y + residual with one
     f32 gate row per batch element (ragged M: the last row tile is partial) and the q|k|v projection written as three dense

@@ -65,7 +65,8 @@ def measure():
             res[tag + "_trace"] = {nm: round(float(t[:, :, i].mean() / steps), 1) for i, nm in enumerate(names)}
             res[tag + "_cyc_per_step"] = round(float(t[:, :, :7].sum(axis=2).mean() / steps), 1)
             w0 = t[:, 0, :]
-            res[tag + "_block_us"] = {"entry_to_loop": round(float((w0[:, 9] - w0[:, 8]).mean() / 100), 2), "loop": round(float((w0[:, 10] - w0[:, 9]).mean() / 100), 2),
+            res[tag + "_block_us"] = {"entry_to_loop": round(float((w0[:, 9] - w0[:, 8]).mean() / 100), 2), "prologue": round(float(((w0[:, 7] - w0[:, 9]) % 2**32).mean() / 100), 2),
+                                      "loop": round(float((w0[:, 10] - w0[:, 9]).mean() / 100), 2),
                                       "epilogue": round(float((w0[:, 11] - w0[:, 10]).mean() / 100), 2),
                                       "epi_bar0": round(float((w0[:, 13] - w0[:, 10]).mean() / 100), 2), "epi_cvt": round(float((w0[:, 14] - w0[:, 13]).mean() / 100), 2),
                                       "epi_bar1": round(float((w0[:, 15] - w0[:, 14]).mean() / 100), 2), "epi_copy": round(float((w0[:, 11] - w0[:, 15]).mean() / 100), 2)}

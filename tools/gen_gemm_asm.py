@@ -274,11 +274,13 @@ def gen16(BM, BN, WGM, WGN, opt=None):
     STAGE = (BM + BN) * 128
     FS = 4 * (NB + MB)                     # registers per fragment set
     RB = 2 * FS                            # first register after the fragment sets
-    assert 4 * NT <= 256 and AI + BI <= 16 and RB + 8 + AI + BI <= 256
+    assert 4 * NT <= 320 and AI + BI <= 18 and RB + 8 + AI + BI <= 192
     L = []
     emit = L.append
     abl = set(x for x in str(opt.get("abl", "")).split("+") if x)
-    def acc(nb, mb): t = nb * MB + mb; return f"a[{4 * t}:{4 * t + 3}]"
+    def acc(nb, mb):                                       # blocks 0..63 in the AGPR half, the rest (320 x 256 tile) in v[192:255]
+        t = nb * MB + mb
+        return f"a[{4 * t}:{4 * t + 3}]" if t < 64 else f"v[{192 + 4 * (t - 64)}:{192 + 4 * (t - 64) + 3}]"
     def wfrag(st, nb): return f"v[{FS * st + 4 * nb}:{FS * st + 4 * nb + 3}]"
     def afrag(st, mb): return f"v[{FS * st + 4 * NB + 4 * mb}:{FS * st + 4 * NB + 4 * mb + 3}]"
     def reads(stage, kh, st):
@@ -417,10 +419,11 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         emit("s_add_u32 %[ak], %[ak], 128")
         emit("s_add_u32 %[bk], %[bk], 128")
         wrap()
-    for r in range(4 * NT): emit(f"v_accvgpr_write_b32 a{r}, 0")
+    for r in range(4 * NT): emit(f"v_accvgpr_write_b32 a{r}, 0" if r < 256 else f"v_mov_b32 v{192 + r - 256}, 0")
     emit(f"s_waitcnt vmcnt({npieces if PGR == 2 else 0})")
     emit("s_barrier")
     if TRACE:
+        emit("s_memrealtime s[88:89]")                     # 100 MHz clock at the end of the prologue (first two K-steps landed) -> t7
         emit("s_memtime s[72:73]"); emit("s_waitcnt lgkmcnt(0)")
         for r in (60, 62, 64, 66, 68, 70, 84): emit(f"s_mov_b32 s{r}, s72")
         for r in range(76, 84): emit(f"s_mov_b32 s{r}, 0")
@@ -441,7 +444,8 @@ def gen16(BM, BN, WGM, WGN, opt=None):
     emit("s_nop 15")
     emit("s_nop 15")
     if TRACE:
-        for i in range(8): emit(f"s_mov_b32 %[t{i}], s{76 + i}")
+        for i in range(7): emit(f"s_mov_b32 %[t{i}], s{76 + i}")
+        emit("s_mov_b32 %[t7], s88")
     return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, FS=FS, RB=RB, TRACE=TRACE)
 
 
@@ -451,20 +455,24 @@ def c_function16(name, BM, BN, WGM, WGN, opt=None):
     text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
     n32 = (4 * NT + 31) // 32
     sig = ", ".join(f"f32x32& c{i}" for i in range(n32))
-    outs = ", ".join(f'"={{a[{32 * i}:{32 * i + 31}]}}"(c{i})' for i in range(n32))
+    def creg(i): return f"a[{32 * i}:{32 * i + 31}]" if i < 8 else f"v[{192 + 32 * (i - 8)}:{192 + 32 * (i - 8) + 31}]"
+    outs = ", ".join(f'"={{{creg(i)}}}"(c{i})' for i in range(n32))
     clob = [f'"v{i}"' for i in range(0, 2 * FS)] + ['"scc"', '"memory"']
+    npc = d["AI"] + d["BI"]
+    d1sig = ", const u32x2& dma1" if npc > 16 else ""
+    d1in = f', "{{v[{RB + 24}:{RB + 25}]}}"(dma1)' if npc > 16 else ""
     trsig = trouts = ""
     if d["TRACE"]:
-        clob += [f'"s{i}"' for i in range(60, 88)]
+        clob += [f'"s{i}"' for i in range(60, 90)]
         trsig = ", uint32_t (&tr)[8]"
         trouts = ", " + ", ".join(f'[t{i}] "=s"(tr[{i}])' for i in range(8))
     return f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  {len(lines)} instructions: tile {BM} x {BN}, waves {WGM} x {WGN}, v_mfma_f32_16x16x32_bf16.
-__device__ __forceinline__ void gemm_asm16_loop_{name}({sig}, const u32x8& rbase, const u32x16& dma0,
+__device__ __forceinline__ void gemm_asm16_loop_{name}({sig}, const u32x8& rbase, const u32x16& dma0{d1sig},
         const u32x4& ra, const u32x4& rw, int cnt, uint32_t ak, uint32_t bk, uint32_t ldsw, uint32_t kend{trsig}) {{
     uint32_t asoff, bsoff;
     asm volatile(
 {text}        : {outs}, [cnt] "+s"(cnt), [ak] "+s"(ak), [bk] "+s"(bk), [asoff] "=&s"(asoff), [bsoff] "=&s"(bsoff){trouts}
-        : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 8}:{RB + 23}]}}"(dma0), [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), [kend] "s"(kend)
+        : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 8}:{RB + 23}]}}"(dma0){d1in}, [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), [kend] "s"(kend)
         : {", ".join(clob)});
 }}
 """
@@ -472,21 +480,24 @@ __device__ __forceinline__ void gemm_asm16_loop_{name}({sig}, const u32x8& rbase
 
 def store_functions16(name, BM, BN, WGM, WGN):
     """After the K loop: f32 accumulators -> LDS, straight from the AGPRs (ds_write_b128 takes an AGPR source), one function
-    per row pass of the wide epilogue in csrc/gemm_asm.hip (RP tile rows of 1 KiB each; a wave stores the blocks whose rows
-    fall in the pass).  The accumulator tuples are tied INPUTS, so the compiler never copies or extracts them (extracting
-    elements of 1024-bit tuples under a wave-uniform branch is what it cannot do: 'Illegal instruction detected').
-    ad[nb] = LDS byte address of (local row rr, chunk (column block nb, q) ^ rr); block (mb, nb) sits lm * 16 KiB further."""
+    per group of a wave's blocks that falls into one row pass of the wide epilogue in csrc/gemm_asm.hip (RP tile rows of
+    1 KiB each).  The accumulator tuples are tied INPUTS, so the compiler never copies or extracts them (extracting elements
+    of 1024-bit tuples under a wave-uniform branch is what it cannot do: 'Illegal instruction detected').
+    ad[nb] = LDS byte address of (local row rr, chunk (column block nb, q) ^ rr); block (lm, nb) sits lm * 16 KiB further.
+    256 x 256 (waves 2 x 2, RP 128): one group, pass = wm.  160 x 256 (1 x 4, RP 80): groups mb 0-4 / 5-9 = passes 0 / 1.
+    320 x 256 (2 x 2 waves of 160 rows, RP 80): the same two groups, pass = 2 wm + group."""
     WM, WN = BM // WGM, BN // WGN
     MB, NB = WM // 16, WN // 16
     NT = MB * NB
     RP = 128 if BM == 256 else 80
     n32 = (4 * NT + 31) // 32
     sig = ", ".join(f"const f32x32& c{i}" for i in range(n32))
-    ins = ", ".join(f'"{{a[{32 * i}:{32 * i + 31}]}}"(c{i})' for i in range(n32))
+    def creg(i): return f"a[{32 * i}:{32 * i + 31}]" if i < 8 else f"v[{192 + 32 * (i - 8)}:{192 + 32 * (i - 8) + 31}]"
+    ins = ", ".join(f'"{{{creg(i)}}}"(c{i})' for i in range(n32))
     out = ""
-    # pass -> the wave's blocks in it: with WGM == 2 a wave's rows all lie in pass wm (RP == WM); with WGM == 1 pass p holds mb in [p RP/16, (p+1) RP/16)
-    passes = [list(range(MB))] if WGM == 2 else [list(range(p * RP // 16, (p + 1) * RP // 16)) for p in range(BM // RP)]
-    for p, mbs in enumerate(passes):
+    per = min(MB, RP // 16)
+    groups = [list(range(g0, g0 + per)) for g0 in range(0, MB, per)]
+    for p, mbs in enumerate(groups):
         L = []
         far = any((mb - mbs[0]) * 16384 > 65535 for mb in mbs)
         if far:
@@ -495,12 +506,13 @@ def store_functions16(name, BM, BN, WGM, WGN):
             for nb in range(NB):
                 off = (mb - mbs[0]) * 16384
                 t = nb * MB + mb
+                src = f"a[{4 * t}:{4 * t + 3}]" if t < 64 else f"v[{192 + 4 * (t - 64)}:{192 + 4 * (t - 64) + 3}]"
                 base, o = (f"v{nb}", off - 65536) if off > 65535 else (f"v{144 + nb}", off)
-                L.append(f"ds_write_b128 {base}, a[{4 * t}:{4 * t + 3}] offset:{o}")
+                L.append(f"ds_write_b128 {base}, {src} offset:{o}")
         L.append("s_waitcnt lgkmcnt(0)")
         text = "".join(f'        "{x}\\n\\t"\n' for x in L)
         clob = ", ".join([f'"v{i}"' for i in range(NB)] + ['"memory"'])
-        out += f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  Row pass {p} of the wide epilogue, tile {BM} x {BN}: {len(mbs) * NB} accumulator blocks -> LDS (f32).
+        out += f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  Block group {p} of the wide epilogue, tile {BM} x {BN}: {len(mbs) * NB} accumulator blocks -> LDS (f32).
 __device__ __forceinline__ void gemm_asm16_store_{name}_p{p}({sig}, const u32x8& ad) {{
     asm volatile(
 {text}        :
@@ -511,7 +523,7 @@ __device__ __forceinline__ void gemm_asm16_store_{name}_p{p}({sig}, const u32x8&
     return out
 
 
-TILES16 = {"256x256": (256, 256, 2, 2), "160x256": (160, 256, 1, 4)}
+TILES16 = {"256x256": (256, 256, 2, 2), "160x256": (160, 256, 1, 4), "320x256": (320, 256, 2, 2)}
 
 
 def c_function(name, BM, BN, WGM, WGN, opt=None):
