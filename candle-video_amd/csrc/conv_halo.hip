@@ -41,7 +41,12 @@ __device__ __forceinline__ int swz_h(int row, int chunk) { return row * ROWB + (
 
 extern __shared__ __attribute__((aligned(16))) unsigned char halo_smem[];
 
-template <int BN, int WGM, int WGN, int EPI>
+// PIPE (BN = 128, round 3): the per-step barrier sits BETWEEN the two k halves of a step and every fragment is read one half
+// ahead into a second register set, so no MFMA waits on an LDS read issued after a barrier (the bubble of the plain form: with
+// two waves per SIMD both wait at the same barrier, then both wait for their first fragments); the weight tiles run three
+// deep (tile of step s + 2 issued in step s, counted vmcnt at the barrier of step s covers tile s + 1).  LDS-DMA counts per
+// step are made static: out-of-range dummy pieces (zeros into padding / free buffers) where the plain form issues nothing.
+template <int BN, int WGM, int WGN, int EPI, bool PIPE>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     static_assert(NW == 8 && WM % 16 == 0 && WN % 16 == 0, "wave layout");
@@ -50,8 +55,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     constexpr int NL = (HALO_LOADERS == 4 && BN == 128) ? 4 : NW;      // measured: +3..9 % at BN = 128, -4 % at BN = 256
     constexpr int AJ = (A_PIECES + NL - 1) / NL, BJ = BN / (8 * NL);
     constexpr int B_STAGE = BN * ROWB;
+    constexpr int A_ST = PIPE ? AJ * NL * 1024 : A_STAGE;       // PIPE: padded to whole piece rounds (dummy pieces land in the padding)
+    static_assert(!PIPE || (NL == 4 && BN == 128), "pipelined form: four loader waves, 128-wide tile");
     unsigned char* Abuf = halo_smem;
-    unsigned char* Bbuf = halo_smem + 2 * A_STAGE;
+    unsigned char* Bbuf = halo_smem + 2 * A_ST;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         const int it = grp / KC, kc = grp - it * KC;
         int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);          // replicate pad on T (vae.rs:374-413)
         const uint32_t soff = (uint32_t)(tt - tt0) * frame_bytes + (uint32_t)kc * 128u;
-        dma(ra, a_voff[j], soff, Abuf + (grp & 1) * A_STAGE + piece * 1024);
+        dma(ra, a_voff[j], soff, Abuf + (grp & 1) * A_ST + piece * 1024);
     };
     auto issue_b = [&](int grp, int hw, int buf) {          // weight tile of step (grp, hw)
         if (!loader) return;
@@ -144,6 +151,80 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) colpart[iw][kb] = iw * ROWB + (((kb * 4 + fq) ^ (((frow + iw) >> 1) & 7)) << 4);
 
+    if constexpr (PIPE) {
+        // uniform issue: every loader wave issues BJ weight pieces and its halo piece rounds in every step, out of range where
+        // there is nothing to load (past the last step / group, pieces beyond the image's 41)
+        auto issue_a_p = [&](int grp, int j) {
+            if (!loader) return;
+            const int piece = j * NL + lwave;
+            const int it = grp / KC, kc = grp - it * KC;
+            int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);
+            const uint32_t soff = (uint32_t)(tt - tt0) * frame_bytes + (uint32_t)kc * 128u;
+            const bool live = grp < G && piece < A_PIECES;
+            dma(ra, live ? a_voff[j] : OOB, live ? soff : 0u, Abuf + (grp & 1) * A_ST + piece * 1024);
+        };
+        auto issue_b_p = [&](int grp, int hw) {               // weight tile of step (grp, hw) into ring slot hw % 3 (9 steps per group)
+            if (!loader) return;
+            const int it = grp / KC, kc = grp - it * KC;
+            const bool live = grp < G;
+            const uint32_t soff = live ? ((uint32_t)(it * 9 + hw) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u : 0u;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) dma(rw, live ? b_voff[j] : OOB, soff, Bbuf + (hw % 3) * B_STAGE + (j * NL + lwave) * 1024);
+        };
+        Chunk16 w0[FN], a0[FM], w1[FN], a1[FM];
+        auto read_frags = [&](int grp, int hw, int kb, Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
+            const int ih = hw / 3, iw = hw % 3;
+            const unsigned char* As = Abuf + (grp & 1) * A_ST;
+            const unsigned char* Bs = Bbuf + (hw % 3) * B_STAGE;
+#pragma unroll
+            for (int f = 0; f < FN; ++f) wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_h(wn * WN + f * 16 + frow, kb * 4 + fq));
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) af[fm].u = *reinterpret_cast<const u32x4*>(As + rowbase[fm] + colpart[iw][kb] + ih * HW * ROWB);
+        };
+        auto mma_all = [&](Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
+        };
+        auto interleave = [&]() {                             // one fragment read, then its share of the MFMAs
+#pragma unroll
+            for (int i = 0; i < FN + FM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN / (FN + FM), 0);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) issue_a_p(0, j);
+        issue_b_p(0, 0); issue_b_p(0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_frags(0, 0, 0, w0, a0);
+        auto step_p = [&](int grp, auto hw_tag) {
+            constexpr int hw = decltype(hw_tag)::value;
+            constexpr int RPS = (AJ + 5) / 6;                 // halo piece rounds per step, over the first six steps of a group
+            constexpr int na = (hw + 1) * RPS <= AJ ? RPS : (hw * RPS < AJ ? AJ - hw * RPS : 0);
+            if (hw + 2 < 9) issue_b_p(grp, hw + 2); else issue_b_p(grp + 1, hw + 2 - 9);
+#pragma unroll
+            for (int rr = 0; rr < na; ++rr) issue_a_p(grp + 1, hw * RPS + rr);
+            read_frags(grp, hw, 1, w1, a1);                   // second k half of this step: its tiles are long visible
+            mma_all(w0, a0);
+            interleave();
+            // everything issued before this step has landed (tile of step + 1, halo rounds); a raw barrier: __syncthreads() would
+            // add a fence, i.e. vmcnt(0), and wait for the tile of step + 2 as well
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BJ + na) : "memory");
+            if (hw + 1 < 9) read_frags(grp, hw + 1, 0, w0, a0); else read_frags(grp + 1, 0, 0, w0, a0);
+            mma_all(w1, a1);
+            interleave();
+        };
+        for (int grp = 0; grp < G; ++grp) {
+            step_p(grp, std::integral_constant<int, 0>{}); step_p(grp, std::integral_constant<int, 1>{}); step_p(grp, std::integral_constant<int, 2>{});
+            step_p(grp, std::integral_constant<int, 3>{}); step_p(grp, std::integral_constant<int, 4>{}); step_p(grp, std::integral_constant<int, 5>{});
+            step_p(grp, std::integral_constant<int, 6>{}); step_p(grp, std::integral_constant<int, 7>{}); step_p(grp, std::integral_constant<int, 8>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy pieces of the last steps
+        __syncthreads();
+    } else {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) issue_a(0, j);
     issue_b(0, 0, 0);
@@ -160,7 +241,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
             for (int rr = 0; rr < RPS; ++rr) if (hw * RPS + rr < AJ) issue_a(grp + 1, hw * RPS + rr);
         }
-        const unsigned char* As = Abuf + (grp & 1) * A_STAGE;
+        const unsigned char* As = Abuf + (grp & 1) * A_ST;
         const unsigned char* Bs = Bbuf + buf * B_STAGE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -206,6 +287,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         step(grp, std::integral_constant<int, 8>{}, p);
     }
 
+    }
     // ---- wide epilogue (bias / residual): the result tile goes through LDS and leaves as 16-byte stores along the channel
     // rows, the residual tile comes in the same way by LDS-DMA (see gemm_big.hip); same arithmetic as epilogue()
     constexpr bool WIDE = HALO_WIDE_EPI && (EPI == EPI_BIAS || EPI == EPI_RESID);
@@ -313,11 +395,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     }
 }
 
-template <int BN, int WGM, int WGN, int EPI>
+template <int BN, int WGM, int WGN, int EPI, bool PIPE = false>
 int launch_halo(const GemmArgs& g, hipStream_t s) {
-    constexpr int smem = 2 * A_STAGE + 2 * BN * ROWB;
+    constexpr int smem = PIPE ? 2 * 44 * 1024 + 3 * BN * ROWB : 2 * A_STAGE + 2 * BN * ROWB;
     static std::atomic<unsigned long long> attr_devs{0};
-    auto kern = conv_halo_kernel<BN, WGM, WGN, EPI>;
+    auto kern = conv_halo_kernel<BN, WGM, WGN, EPI, PIPE>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
     GemmArgs ga = g;
@@ -330,12 +412,12 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     return LTX_OK;
 }
 
-template <int BN, int WGM, int WGN>
+template <int BN, int WGM, int WGN, bool PIPE = false>
 int launch_halo_epi(const GemmArgs& g, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_BIAS: return launch_halo<BN, WGM, WGN, EPI_BIAS>(g, s);
-        case EPI_RESID: return launch_halo<BN, WGM, WGN, EPI_RESID>(g, s);
-        case EPI_D2S: return launch_halo<BN, WGM, WGN, EPI_D2S>(g, s);
+        case EPI_BIAS: return launch_halo<BN, WGM, WGN, EPI_BIAS, PIPE>(g, s);
+        case EPI_RESID: return launch_halo<BN, WGM, WGN, EPI_RESID, PIPE>(g, s);
+        case EPI_D2S: return launch_halo<BN, WGM, WGN, EPI_D2S, PIPE>(g, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "conv_halo: unsupported epilogue");
 }
@@ -356,5 +438,9 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     if (!ltx_conv_halo_eligible(g, epi, bn)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: shape not eligible");
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
+#if HALO_LOADERS == 4
+    const char* pe = getenv("LTX_CONV_HALO_PIPE");          // "0": the barrier-per-step form (A/B)
+    if (!(pe && pe[0] == '0')) return launch_halo_epi<128, 4, 2, true>(g, epi, s);
+#endif
     return launch_halo_epi<128, 4, 2>(g, epi, s);
 }
