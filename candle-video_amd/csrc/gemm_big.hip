@@ -426,8 +426,10 @@ int ltx_gemm_split_factor(const GemmArgs& g) {
     if (area * 2.0 > chip) return 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     int sf = (int)(chip / area);
-    if (sf > 8) sf = 8;
-    while (sf > 1 && nk / sf < 8) --sf;                // every part keeps at least 8 K-steps
+    static const int max_sf = [] { const char* v = getenv("LTX_GEMM_SPLIT_MAX"); return v ? atoi(v) : 8; }();
+    static const int min_k = [] { const char* v = getenv("LTX_GEMM_SPLIT_MINK"); return v ? atoi(v) : 8; }();
+    if (sf > max_sf) sf = max_sf;
+    while (sf > 1 && nk / sf < min_k) --sf;            // every part keeps at least 8 K-steps
     return sf < 2 ? 1 : sf;
 }
 
@@ -572,9 +574,13 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     // Linear layers of any M take the 128-row tiles with the shape-only split-K (small outputs: up to 8 K-ranges per tile, so
     // the weight matrix streams through every CU): context k/v and caption projections (M = 128), the timestep MLPs
     // (M = 1) and the T5 encoder's M = 128 GEMMs run 1.5-2.5x faster than on gemm.hip's 128 x 128 register-staged kernel
-    // (T5-XXL at 128 tokens 14.9 -> 10.5 ms).  Convs below 1024 output voxels stay there.  LTX_GEMM_BIG_MINM overrides.
-    int min_m = g.conv ? 1024 : 1;
+    // (T5-XXL at 128 tokens 14.9 -> 10.5 ms).  Convs from 256 output voxels up take them too since round 3 (C1's mid block is
+    // 4 x 8 x 12 = 384 voxels of 1024 channels: 11 convs of 57 MB of weights each, 500 us apiece on gemm.hip's kernel, 6.5 of
+    // C1's 63 ms; with the split-K tiles the decode went 11.9 -> 6.3 ms); smaller ones stay there.  LTX_GEMM_BIG_MINM /
+    // LTX_GEMM_BIG_CONV_MINM override.
+    int min_m = g.conv ? 256 : 1;
     if (const char* e = getenv("LTX_GEMM_BIG_MINM")) { min_m = atoi(e); if (g.conv && min_m < 1024) min_m = 1024; }
+    if (g.conv) { if (const char* e = getenv("LTX_GEMM_BIG_CONV_MINM")) min_m = atoi(e); }
     return g.M >= min_m && g.N >= 32;
 }
 
