@@ -422,12 +422,26 @@ std::mutex g_split_mu;
 int ltx_gemm_split_factor(const GemmArgs& g) {
     const char* e = getenv("LTX_GEMM_SPLITK");
     if (e && e[0] == '0') return 1;
-    const double area = (double)g.M * (double)g.N, chip = 256.0 * 256.0 * 256.0;
-    if (area * 2.0 > chip) return 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
-    int sf = (int)(chip / area);
     static const int max_sf = [] { const char* v = getenv("LTX_GEMM_SPLIT_MAX"); return v ? atoi(v) : 8; }();
     static const int min_k = [] { const char* v = getenv("LTX_GEMM_SPLIT_MINK"); return v ? atoi(v) : 8; }();
+    static const bool small_rule = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALLM"); return !(v && v[0] == '0'); }();
+    if (!g.conv && g.M <= 1536 && small_rule) {
+        // Small-M linear layers (C1's 384 tokens, the 128 text rows; round 3, tools/small_m_probe.py): these are latency-bound
+        // weight streams - a K-step costs 0.4-0.75 us whatever it computes - and the in-launch reduction grows faster than
+        // linearly with the parts (1.4 / 6 / 22 us for 2 / 4 / 8), so split only until ~256 blocks are in flight (512 when K is
+        // long), keep >= 16 K-steps per part, and at most 4 parts once there are more than 16 tiles.  The area rule below cut
+        // qkv at M = 384 (144 tiles of 128 x 128) into 4 parts: 36 us against 25 unsplit; M = 1152: 55 against 31.
+        const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+        const int target = nk >= 96 ? 512 : 256;
+        int sf = 1;
+        while (sf * 2 <= 8 && tiles * sf * 2 <= target && nk / (sf * 2) >= 16) sf *= 2;
+        if (tiles > 16 && sf > 4) sf = 4;
+        return sf;
+    }
+    const double area = (double)g.M * (double)g.N, chip = 256.0 * 256.0 * 256.0;
+    if (area * 2.0 > chip) return 1;
+    int sf = (int)(chip / area);
     if (sf > max_sf) sf = max_sf;
     while (sf > 1 && nk / sf < min_k) --sf;            // every part keeps at least 8 K-steps
     return sf < 2 ? 1 : sf;
