@@ -930,6 +930,15 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
             const int nunits = cdiv(a.Sq, 32);
             int groups = cdiv(512, a.B * a.heads);
+            {   // among the group counts that keep ~1.5-2 blocks per CU, the one whose four waves waste the fewest 32-query units
+                // (S = 4992: 156 units per head; 16 groups = 9.75 per group -> 3 rounds of the waves for 2.44 of work; 13 groups = 12 = 3 x 4)
+                int best = groups, best_waste = 1 << 30;
+                for (int gq = groups; gq >= (groups * 3 + 3) / 4 && gq >= 1; --gq) {
+                    const int waste = cdiv(cdiv(nunits, gq), 4) * 4 * gq - nunits;
+                    if (waste < best_waste) { best_waste = waste; best = gq; }
+                }
+                groups = best;
+            }
             if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
             if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
             hipLaunchKernelGGL(attn_cross64_kernel, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
