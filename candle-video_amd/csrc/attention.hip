@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     constexpr int NBUF = (DMA && HD == 64) ? 3 : 2;            // head_dim 128: 32 KiB tiles, two of them (two blocks per CU)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * TILE_BYTES];
 
+    if (a.gate_flag && *a.gate_flag != a.gate_ticket) return;     // exact pass behind attn_q128_kernel: only after an overflow in THAT launch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // 1-D grid.  Blocks L and L+8 share an XCD (one L2): with heads % 8 == 0 every XCD is given WHOLE heads
@@ -953,7 +954,13 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
                      else if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<64, true>), grid, block, 0, s, ax);
                      else hipLaunchKernelGGL((attn_bf16_kernel<64, false>), grid, block, 0, s, ax);
                      break;
-            case 128: if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<128, true>), grid, block, 0, s, ax);
+            case 128: if (a.q_prescaled && ltx_attention_q128_fits(ax)) {
+                          // generated one-wave-per-SIMD loop with the fixed first-tile max, then the exact kernel gated on its overflow flag
+                          int* flag = nullptr; int ticket = 0;
+                          LTX_TRY(ltx_launch_attention_q128(ax, s, &flag, &ticket));
+                          ax.gate_flag = flag; ax.gate_ticket = ticket;
+                          hipLaunchKernelGGL((attn_bf16_kernel<128, true>), grid, block, 0, s, ax);
+                      } else if (a.q_prescaled) hipLaunchKernelGGL((attn_bf16_kernel<128, true>), grid, block, 0, s, ax);
                       else hipLaunchKernelGGL((attn_bf16_kernel<128, false>), grid, block, 0, s, ax);
                       break;
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");

@@ -1,0 +1,157 @@
+// Self-attention at head_dim 128, q prescaled by scale*log2(e), no key bias (the 13B DiT, BASELINE C5: S = 17556, 32 heads):
+// one wave per SIMD, 32 queries per wave, the whole tile loop one generated asm statement (tools/gen_attn_q128_asm.py ->
+// attn_q128_loop.inc).  Round 3: the structure of attn_q64.hip carried to head_dim 128, where it pays more - per 64-key
+// tile a wave issues the same 32 MFMAs of 32x32x16 as the 256-query form at head_dim 64 but HALF the exponentials, so the
+// matrix pipe, not the vector issue port, bounds the loop.  attn_bf16_kernel<128> (attention.hip) runs a tile's phases back
+// to back in each wave and leaves the overlap to a second workgroup on the CU: 0.44-0.46 of the bf16 MFMA peak.
+//
+//   * workgroup = 4 waves = 128 queries of one head; K/V tiles of 64 keys (32 KiB) arrive by buffer LDS-DMA into a ring of
+//     four slots (128 KiB), tile t+4 issued in iteration t, counted vmcnt, one barrier per tile; LDS images and fragment maps
+//     are attention.hip's at KCPR = VCPR = 16 (K rows chunk-XOR-swizzled by row % 16, V read through ds_read_b64_tr_b16);
+//   * FIXED max from the first key tile, row sums on the matrix pipe, exactly as attn_q64.hip; a key count that is not a
+//     multiple of 64 (S = 17556 = 274 x 64 + 20) is handled INSIDE the pipeline: the scores of the last tile's missing keys are
+//     set to -inf between the QK and PV gaps of the last-but-one iteration;
+//   * overflow (a later score beyond the first tile's maximum by ~100 in log2 units; never seen on model activations): every
+//     block checks its row sums and raises a device flag stamped with the launch's ticket; the launcher follows this kernel
+//     with attn_bf16_kernel<128> gated on that flag (exact running max; it returns at once when the flag is not this launch's).
+#include <atomic>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+#ifndef Q128_LOOP_INC
+#define Q128_LOOP_INC "attn_q128_loop.inc"
+#endif
+#include Q128_LOOP_INC
+
+constexpr int BKV = 64, KROW = 256, VROW = 256, TILE_BYTES = BKV * (KROW + VROW), NSLOT = 4;
+
+__global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int* flag, int ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // blocks L and L + 8 share an XCD: with heads % 8 == 0 every XCD is given whole heads (attention.hip)
+    const int nqb = (a.Sq + 127) / 128, per_b = nqb * a.heads;
+    int L = blockIdx.x;
+    const int b = L / per_b; L -= b * per_b;
+    int head, qb;
+    if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / nqb); qb = j % nqb; }
+    else { head = L / nqb; qb = L - head * nqb; }
+    const int q0 = qb * 128 + wave * 32;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * 128;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * 128;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * 128;
+    const int nt = (a.Sk + BKV - 1) / BKV;
+    const int rem = a.Sk - (nt - 1) * BKV;                 // keys of the last tile (64: nothing to mask)
+
+    // LDS-DMA geometry: pieces of 4 rows x 256 B; wave w issues pieces 4w .. 4w+3 of K and of V (rows 16w .. 16w+15); the
+    // tile's bank swizzles are applied to the SOURCE chunk; rows past Sk are out of the buffer's range -> zeros
+    u32x8 dma_u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 4 + (lane >> 4), pc = lane & 15;
+        dma_u[j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)(pc ^ (row & 15)) * 16u;                 // kswz<16>
+        dma_u[4 + j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)(pc ^ ((row & 3) << 2)) * 16u;      // vswz<16>
+    }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    u32x8 kbase, kbase_hi;
+    u32x4 trbase, trbase_hi;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                          // K fragment: row kb*32 + r, chunk 2 ks + h (rows r, r + 32 swizzle alike)
+        kbase[ks] = smem_base + (uint32_t)(r * KROW + (((2 * ks + h) ^ (r & 15)) << 4));
+        kbase_hi[ks] = kbase[ks] + 65536u;
+    }
+    {
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+            trbase[d] = smem_base + (uint32_t)(row * VROW + ((cv ^ ((row & 3) << 2)) << 4) + (trp & 1) * 8);
+            trbase_hi[d] = trbase[d] + 65536u;
+        }
+    }
+    // constant A operand of the row-sum MFMA (attn_q64.hip): 1 where the parities of row and of k's group of 8 agree
+    u32x4 ones_u;
+    {
+        const uint32_t one2 = ((lane & 1) == ((lane >> 4) & 1)) ? 0x3f803f80u : 0u;
+        ones_u = (u32x4){one2, one2, one2, one2};
+    }
+    const int qr = q0 + r;
+    const int qc = qr > a.Sq - 1 ? a.Sq - 1 : qr;
+    const uint32_t qoff = (uint32_t)qc * (uint32_t)a.ldq * 2u + 16u * h;
+    const uint32_t ooff = qr < a.Sq ? (uint32_t)qr * (uint32_t)a.ldo * 2u + 16u * h : 0x80000000u;     // rows past Sq: out of range, dropped
+    auto words = [](const void* p, uint32_t bytes) {
+        const uint64_t u = (uint64_t)(uintptr_t)p;
+        return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) & 0xffffu,
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+    };
+    const u32x4 rk = words(K, (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + 256u);
+    const u32x4 rv = words(V, (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + 256u);
+    const u32x4 rq = words(Q, (uint32_t)(a.Sq - 1) * (uint32_t)a.ldq * 2u + 256u);
+    const u32x4 ro = words(reinterpret_cast<bf16_t*>(a.o) + (int64_t)b * a.Sq * a.ldo + head * 128, (uint32_t)(a.Sq - 1) * (uint32_t)a.ldo * 2u + 256u);
+    const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
+    const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
+    const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 4096u));
+    f32x4 la;
+    q128_full(la, ones_u, kbase, trbase, kbase_hi, trbase_hi, dma_u, qoff, ooff, (lane & 16) ? 1u : 0u, (uint32_t)(4 * h), rk, rv, rq, ro,
+              __builtin_amdgcn_readfirstlane(nt), __builtin_amdgcn_readfirstlane(rem), kstep, vstep, ldsw);
+    // l beyond 2^100 (or NaN): some p overflowed or came close - the stored rows are then not to be trusted; the gated exact
+    // kernel that follows recomputes the whole launch
+    const float l0 = (lane & 16) ? la[1] : la[0];
+#ifndef Q128_NO_FALLBACK      // timing ablations (garbage results) must not start the exact pass
+    if (!(l0 < 0x1p100f)) atomicExch(flag, ticket);
+#else
+    (void)l0; (void)flag; (void)ticket;
+#endif
+}
+
+std::mutex g_q128_mu;
+std::map<int, int*> g_q128_flag;                 // per device: one int, zero-initialised; holds the ticket of the last overflowing launch
+std::atomic<int> g_q128_ticket{1};
+
+}  // namespace
+
+// shapes the generated loop serves: prescaled bf16, head_dim 128, at least two key tiles, 32-bit buffer offsets
+bool ltx_attention_q128_fits(const AttnArgs& a) {
+    const char* e = getenv("LTX_ATTN_Q128");                // "0" = attn_bf16_kernel<128> (A/B aid)
+    if (e && e[0] == '0') return false;
+    if (a.hd != 128 || !a.q_prescaled || a.bias || a.Sk < 128 || a.Sq < 1) return false;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8 || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.o & 15)) return false;
+    const double lim = 2147483648.0 - 512.0;
+    return ((double)a.Sk + 4 * 64) * a.ldk * 2.0 < lim && ((double)a.Sk + 4 * 64) * a.ldv * 2.0 < lim && (double)a.Sq * a.ldq * 2.0 < lim && (double)a.Sq * a.ldo * 2.0 < lim;
+}
+
+// Launches the kernel; *flag_out / *ticket_out identify the overflow flag the caller gates its exact pass on.
+int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, int* ticket_out) {
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    int* flag = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_q128_mu);
+        auto it = g_q128_flag.find(dev);
+        if (it == g_q128_flag.end()) {
+            HIP_TRY(hipMalloc(&flag, sizeof(int)));
+            HIP_TRY(hipMemset(flag, 0, sizeof(int)));
+            g_q128_flag[dev] = flag;
+        } else flag = it->second;
+    }
+    const int ticket = g_q128_ticket.fetch_add(1) | 0x40000000;       // never 0 (the flag's initial value)
+    constexpr int smem = NSLOT * TILE_BYTES;
+    static std::atomic<unsigned long long> attr_devs{0};
+    {
+        const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+        if (!(attr_devs.load() & bit)) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_devs.fetch_or(bit);
+        }
+    }
+    const int blocks = a.B * a.heads * ((a.Sq + 127) / 128);
+    hipLaunchKernelGGL(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, flag, ticket);
+    LTX_CHECK_LAUNCH();
+    *flag_out = flag; *ticket_out = ticket;
+    return LTX_OK;
+}

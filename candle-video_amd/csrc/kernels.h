@@ -113,7 +113,10 @@ struct AttnArgs {
     int q_prescaled = 0;                          // bf16, no bias: q already carries scale*log2(e) (qknorm_rope out_scale0)
     int xcd_heads = 0;                            // set by the launcher: whole heads per XCD (block order, speed only)
     int wide_o = 0;                               // set by the launcher: 16-byte output stores (ldo % 8 == 0, 16-byte aligned o)
+    const int* gate_flag = nullptr; int gate_ticket = 0;   // attn_bf16_kernel<128>: run only if *gate_flag == gate_ticket (exact pass after attn_q128's overflow flag)
 };
+bool ltx_attention_q128_fits(const AttnArgs& a);           // attn_q128.hip: head_dim 128 one-wave-per-SIMD kernel
+int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, int* ticket_out);
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
 bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row offset below 2^31 (its 32-bit buffer arithmetic)

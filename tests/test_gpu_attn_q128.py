@@ -1,0 +1,80 @@
+"""GPU suite: the head_dim-128 self-attention kernel of the 13B model (csrc/attn_q128.hip, generated loop
+tools/gen_attn_q128_asm.py; LtxAttention::forward with flash attention, ltx_transformer.rs:699-712) against an f32 torch
+reference of softmax(q k^T) v in base 2 (q arrives prescaled by scale * log2 e) and against the kernel it replaces
+(attn_bf16_kernel<128>, LTX_ATTN_Q128=0).  Bars: rel-L2 <= 4e-3 vs f32 on the checked rows (bf16 P and bf16 output rounding;
+the replaced kernel measures the same), no non-finite value, bit-repeatable."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+H, D = 4, 128
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    assert torch.cuda.is_available()
+    return ltxhip
+
+
+def qkv(S, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(1, S, H * D, device="cuda", generator=g) * scale * (D ** -0.5) * math.log2(math.e)).bfloat16()
+    k = torch.randn(1, S, H * D, device="cuda", generator=g).bfloat16()
+    v = torch.randn(1, S, H * D, device="cuda", generator=g).bfloat16()
+    return q, k, v
+
+
+def reference(q, k, v, rows):
+    S = q.shape[1]
+    qs = q[0, rows].float().view(len(rows), H, D); ks = k[0].float().view(S, H, D); vs = v[0].float().view(S, H, D)
+    p = torch.softmax(torch.einsum("qhd,khd->hqk", qs, ks) * math.log(2.0), dim=-1)
+    return torch.einsum("hqk,khd->qhd", p, vs).reshape(len(rows), H * D)
+
+
+def rel(a, b): return float((a - b).norm() / b.norm())
+
+
+def run(hip, q, k, v, on):
+    old = os.environ.get("LTX_ATTN_Q128")
+    try:
+        if on: os.environ.pop("LTX_ATTN_Q128", None)
+        else: os.environ["LTX_ATTN_Q128"] = "0"
+        return hip.ops.attention_prescaled(q, k, v, H)
+    finally:
+        if old is None: os.environ.pop("LTX_ATTN_Q128", None)
+        else: os.environ["LTX_ATTN_Q128"] = old
+
+
+@pytest.mark.parametrize("S", [4992, 1300, 192, 17556 // 4 + 1])          # whole tiles; ragged keys + partial last query block; two tiles; 13B-like ragged count
+def test_q128_vs_f32_reference_and_replaced_kernel(hip, S):
+    q, k, v = qkv(S, S)
+    o = run(hip, q, k, v, True)
+    o2 = run(hip, q, k, v, True)
+    old = run(hip, q, k, v, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    assert torch.equal(o.view(torch.int16), o2.view(torch.int16))
+    rows = sorted(set([0, 1, 31, 32, 127, 128, S // 2, S - 129, S - 33, S - 2, S - 1]))
+    ref = reference(q, k, v, rows)
+    e_new, e_old = rel(o[0, rows].float(), ref), rel(old[0, rows].float(), ref)
+    print(f"S={S}: rel-L2 vs f32: q128 {e_new:.5f}, attn_bf16_kernel<128> {e_old:.5f}; between them {rel(o.float(), old.float()):.5f}")
+    assert e_new <= 4e-3, e_new
+    assert rel(o.float(), old.float()) <= 6e-3
+
+
+def test_q128_overflow_falls_back_to_the_exact_kernel(hip):
+    """Scores that grow far beyond the first key tile's maximum overflow exp2(s - m_first); the kernel flags the launch and the
+    gated exact kernel recomputes it: the result must equal the replaced kernel's bit for bit."""
+    S = 1024
+    q, k, v = qkv(S, 7)
+    k[:, 512:] *= 40.0                                   # later keys: scores ~ +-40 sigma of the early ones
+    q = (q.float() * 6.0).bfloat16()
+    o = run(hip, q, k, v, True)
+    old = run(hip, q, k, v, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    assert torch.equal(o.view(torch.int16), old.view(torch.int16))
