@@ -425,7 +425,7 @@ def main():
             # separate, untimed pass with hipEvents around every launch of the heavy kernel classes (on their stream)
             ltxhip.prof_enable(True)
             step()
-            attn_name = "attn_q64_kernel (self attention, 64 queries per wave)" if pre.transformer.attention_head_dim == 64 else "attn_bf16_kernel<128> (self attention)"
+            attn_name = "attn_q64_kernel (self attention, 64 queries per wave)" if pre.transformer.attention_head_dim == 64 else "attn_q128_kernel (self attention, head_dim 128, 64 queries per wave)"
             kinds = {"gemm_asm16_kernel/gemm_big_kernel/gemm_p8_kernel<bf16> (Linear GEMMs, plan per shape)": 0,
                      "gemm_big_kernel/gemm_p8_kernel/conv_halo_kernel<bf16,conv> (conv3d implicit GEMM)": 1, attn_name: 2,
                      "attn_cross64_kernel (cross attention)": 3, "rownorm_kernel<bf16>": 4}

@@ -24,6 +24,7 @@
 namespace {
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 #ifndef Q128_LOOP_INC
 #define Q128_LOOP_INC "attn_q128_loop.inc"
 #endif
@@ -31,18 +32,12 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BKV = 64, KROW = 256, VROW = 256, TILE_BYTES = BKV * (KROW + VROW), NSLOT = 4;
 
-__global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int* flag, int ticket) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One workgroup: queries [q_first, q_first + 128 QB) of (batch b, head) against all keys.  QB = 32-query blocks per wave.
+template <int QB>
+__device__ __forceinline__ void q128_block(const AttnArgs& a, unsigned char* smem, int b, int head, int q_first, int* flag, int ticket) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // blocks L and L + 8 share an XCD: with heads % 8 == 0 every XCD is given whole heads (attention.hip)
-    const int nqb = (a.Sq + 127) / 128, per_b = nqb * a.heads;
-    int L = blockIdx.x;
-    const int b = L / per_b; L -= b * per_b;
-    int head, qb;
-    if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / nqb); qb = j % nqb; }
-    else { head = L / nqb; qb = L - head * nqb; }
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = q_first + wave * 32 * QB;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * 128;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * 128;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * 128;
@@ -81,10 +76,14 @@ __global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int
         const uint32_t one2 = ((lane & 1) == ((lane >> 4) & 1)) ? 0x3f803f80u : 0u;
         ones_u = (u32x4){one2, one2, one2, one2};
     }
-    const int qr = q0 + r;
-    const int qc = qr > a.Sq - 1 ? a.Sq - 1 : qr;
-    const uint32_t qoff = (uint32_t)qc * (uint32_t)a.ldq * 2u + 16u * h;
-    const uint32_t ooff = qr < a.Sq ? (uint32_t)qr * (uint32_t)a.ldo * 2u + 16u * h : 0x80000000u;     // rows past Sq: out of range, dropped
+    u32x2 qoff, ooff;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = q0 + 32 * (qb < QB ? qb : 0) + r;
+        const int qc = qr > a.Sq - 1 ? a.Sq - 1 : qr;
+        qoff[qb] = (uint32_t)qc * (uint32_t)a.ldq * 2u + 16u * h;
+        ooff[qb] = qr < a.Sq ? (uint32_t)qr * (uint32_t)a.ldo * 2u + 16u * h : 0x80000000u;     // rows past Sq: out of range, dropped
+    }
     auto words = [](const void* p, uint32_t bytes) {
         const uint64_t u = (uint64_t)(uintptr_t)p;
         return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) & 0xffffu,
@@ -97,17 +96,44 @@ __global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int
     const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
     const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
     const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 4096u));
-    f32x4 la;
-    q128_full(la, ones_u, kbase, trbase, kbase_hi, trbase_hi, dma_u, qoff, ooff, (lane & 16) ? 1u : 0u, (uint32_t)(4 * h), rk, rv, rq, ro,
-              __builtin_amdgcn_readfirstlane(nt), __builtin_amdgcn_readfirstlane(rem), kstep, vstep, ldsw);
+    const uint32_t sel = (lane & 16) ? 1u : 0u, key0 = (uint32_t)(4 * h);
+    const int nt_u = __builtin_amdgcn_readfirstlane(nt), rem_u = __builtin_amdgcn_readfirstlane(rem);
+    bool bad;
+    if constexpr (QB == 2) {
+        f32x8 la;
+        q128_full_qb2(la, ones_u, kbase, kbase_hi, trbase, trbase_hi, dma_u, qoff, ooff, sel, key0, rk, rv, rq, ro, nt_u, rem_u, kstep, vstep, ldsw);
+        const float l0 = (lane & 16) ? la[1] : la[0], l1 = (lane & 16) ? la[5] : la[4];
+        bad = !(l0 < 0x1p100f) || !(l1 < 0x1p100f);
+    } else {
+        f32x4 la;
+        q128_full(la, ones_u, kbase, trbase, kbase_hi, trbase_hi, dma_u, qoff[0], ooff[0], sel, key0, rk, rv, rq, ro, nt_u, rem_u, kstep, vstep, ldsw);
+        const float l0 = (lane & 16) ? la[1] : la[0];
+        bad = !(l0 < 0x1p100f);
+    }
     // l beyond 2^100 (or NaN): some p overflowed or came close - the stored rows are then not to be trusted; the gated exact
     // kernel that follows recomputes the whole launch
-    const float l0 = (lane & 16) ? la[1] : la[0];
 #ifndef Q128_NO_FALLBACK      // timing ablations (garbage results) must not start the exact pass
-    if (!(l0 < 0x1p100f)) atomicExch(flag, ticket);
+    if (bad) atomicExch(flag, ticket);
 #else
-    (void)l0; (void)flag; (void)ticket;
+    (void)bad; (void)flag; (void)ticket;
 #endif
+}
+
+// Grid: per batch, first heads * nbig big blocks (256 queries: [i * 256, +256)), then heads * nsmall small blocks (128 queries:
+// [nbig * 256 + i * 128, +128)).  Inside each class blocks L, L + 8 share an XCD, which is given whole heads (attention.hip).
+__global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int nbig, int nsmall, int* flag, int ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int per_b = a.heads * (nbig + nsmall);
+    int L = blockIdx.x;
+    const int b = L / per_b; L -= b * per_b;
+    const bool big = L < a.heads * nbig;
+    if (!big) L -= a.heads * nbig;
+    const int n = big ? nbig : nsmall;
+    int head, qb;
+    if (a.xcd_heads) { const int xcd = L & 7, j = L >> 3; head = xcd + 8 * (j / n); qb = j % n; }
+    else { head = L / n; qb = L - head * n; }
+    if (big) q128_block<2>(a, smem, b, head, qb * 256, flag, ticket);
+    else q128_block<1>(a, smem, b, head, nbig * 256 + qb * 128, flag, ticket);
 }
 
 std::mutex g_q128_mu;
@@ -149,8 +175,12 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
             attr_devs.fetch_or(bit);
         }
     }
-    const int blocks = a.B * a.heads * ((a.Sq + 127) / 128);
-    hipLaunchKernelGGL(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, flag, ticket);
+    // 256-query blocks (64 queries per wave: half the K/V bytes per FLOP), the queries left over as 128-query blocks
+    int nbig = a.Sq / 256;
+    if (const char* e = getenv("LTX_ATTN_Q128_BIG")) { const int v = atoi(e); if (v >= 0 && v < nbig) nbig = v; }   // tuning aid (0: 128-query blocks only)
+    const int nsmall = (a.Sq - nbig * 256 + 127) / 128;
+    const int blocks = a.B * a.heads * (nbig + nsmall);
+    hipLaunchKernelGGL(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, nbig, nsmall, flag, ticket);
     LTX_CHECK_LAUNCH();
     *flag_out = flag; *ticket_out = ticket;
     return LTX_OK;

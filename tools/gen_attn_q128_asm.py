@@ -260,6 +260,260 @@ __device__ __forceinline__ void q128_full(f32x4& lacc, const u32x4& ones, const 
 """
 
 
+# ======================================================================================================================
+# 64 queries per wave (256 per workgroup): half the K/V bytes per FLOP of the form above, which measured bound by them
+# (every LDS-DMA piece out of range: +28 %).  Two 32-query blocks per wave share every K and V^T fragment, so the fragments
+# are STREAMED through four-deep register windows (read once, used by two back-to-back MFMAs) instead of being held whole.
+#
+# Register map:
+#   v[0:63]    S^T set X ((qb, kb) -> 16)      a[0:127]    O^T ((qb, d) -> 16)
+#   v[64:127]  S^T set Y                        a[128:191]  Q^T fragments ((qb, ks) -> 4)
+#   v[128:159] P^T operands ((qb, kb, s) -> 4)  a[192:207]  K window (4 fragments), a[208:223] V^T window (4 operands)
+#   v[160:191] -m tuples (q0 | q1)              a[224:227]  0/1 operand of the row-sum MFMA
+#   v[192:199] row sums (q0 | q1), v[200:207] exp temporaries
+#   v[208:215] / v[216:223] K read bases (slots 0,1 / 2,3), v[224:227] / v[228:231] V^T read bases
+#   v[232:239] DMA source offsets (K 4 | V 4), v[240:241] Q offsets, v[242:243] O offsets, v244 l select, v245 4*(lane>>5), v246 -inf
+#
+# Iteration t (slot s = t & 3; CUR = S^T(t) - m with (q0, k0) already exponentiated; NXT receives S^T(t+1)):
+#   QK 32 gaps, fragment f = kb*8 + ks of K(t+1), two gaps each: { MFMA S^T(t+1) q0 | q1 ; one exp of (CUR q0 k1) [f < 8] or
+#      (CUR q1 k0) [f >= 8] ; K read of fragment f+3 (even gaps) ; K piece of tile t+3 (4 of the gaps) }
+#   last QK gaps also start the V^T(t) window; vmcnt(4) [tile t+2 whole], lgkmcnt(0), s_barrier, tail mask when two tiles are left
+#   PV 32 gaps, operand n = j*4 + d (key group j major), two gaps each: { MFMA O^T q0 | q1 ; one exp of (CUR q1 k1) [first 16]
+#      or (NXT q0 k0) [last 16] ; two transpose reads of operand n+3 (even gaps) ; V piece of tile t+3 ; row-sum MFMAs }
+#   the last PV gaps start the K(t+2) window of the next iteration.
+def gen2(opt=None):
+    o_ = dict(abl="", align=1)
+    o_.update(opt or {})
+    abl = set(x for x in str(o_["abl"]).split("+") if x)
+    L = []
+    def emit(ins):
+        op = ins.split()[0]
+        if "nodma" in abl and (op.startswith("buffer_load") and " lds" in ins or ins.startswith("s_add_u32 m0")): return
+        if "noexp" in abl and op.startswith("v_exp"): ins = ins.replace("v_exp_f32_e32", "v_mov_b32_e32")
+        if "nobar" in abl and op == "s_barrier": return
+        L.append(ins)
+    def S(st, qb, kb): return st * 64 + (qb * 2 + kb) * 16
+    def P(qb, kb, s): return 128 + ((qb * 2 + kb) * 2 + s) * 4
+    def MINIT(qb): return 160 + 16 * qb
+    def LACC(qb): return 192 + 4 * qb
+    NEGINF, KEY0 = 246, 245
+    def O(qb, d): return (qb * 4 + d) * 16
+    def Q(qb, ks): return 128 + (qb * 8 + ks) * 4
+    def KW(f): return 192 + 4 * (f & 3)
+    def VW(n): return 208 + 4 * (n & 3)
+    ONES = 224
+    tmp = [0]
+    def temps():
+        a = 200 + 2 * (tmp[0] % 4); tmp[0] += 1
+        return a, a + 1
+    def vr(a, n): return f"v[{a}:{a + n - 1}]"
+    def ar(a, n): return f"a[{a}:{a + n - 1}]"
+    def kbase(ks, slot): return (208 if slot < 2 else 216) + ks
+    def vbase(d, slot): return (224 if slot < 2 else 228) + d
+    def kread(f, slot):                                       # K fragment f = kb*8 + ks of the tile in ring slot `slot`
+        return f"ds_read_b128 {ar(KW(f), 4)}, v{kbase(f & 7, slot)} offset:{(slot & 1) * TILE + (f >> 3) * 32 * KROW}"
+    def vreads(n, slot):                                      # V^T operand n = j*4 + d: two transpose reads
+        j, d = n >> 2, n & 3
+        out = []
+        for hf in range(2):
+            rowc = (j >> 1) * 32 + (j & 1) * 16 + 8 * hf
+            out.append(f"ds_read_b64_tr_b16 {ar(VW(n) + 2 * hf, 2)}, v{vbase(d, slot)} offset:{(slot & 1) * TILE + VBASE + rowc * VROW}")
+        return out
+
+    pending = [None]
+    cur_t = [None]
+    def exp_half(sbase, pbase2, e):
+        i = e >> 1
+        if e & 1 == 0:
+            cur_t[0] = temps()
+            if pending[0]: emit("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % pending[0]); pending[0] = None
+            emit(f"v_exp_f32_e32 v{cur_t[0][0]}, v{sbase + e}")
+        else:
+            emit(f"v_exp_f32_e32 v{cur_t[0][1]}, v{sbase + e}")
+            pending[0] = (pbase2[i >> 2] + (i & 3), cur_t[0][0], cur_t[0][1])
+
+    def mask_tail(st):
+        for qb in range(2):
+            for kb in range(2):
+                for i in range(16):
+                    c = kb * 32 + (i & 3) + 8 * (i >> 2)
+                    emit(f"s_sub_i32 %[stmp], %[rem], {c}")
+                    emit(f"v_cmp_le_i32_e32 vcc, %[stmp], v{KEY0}")
+                    emit(f"v_cndmask_b32_e32 v{S(st, qb, kb) + i}, v{S(st, qb, kb) + i}, v{NEGINF}, vcc")
+
+    def rowsum(rq, ro):                                        # row sums of tile t on the matrix pipe: P operand (kb, s) = ro of query block rq
+        l = vr(LACC(rq), 4)
+        emit(f"v_mfma_f32_16x16x32_bf16 {l}, {ar(ONES, 4)}, {vr(P(rq, ro >> 1, ro & 1), 4)}, {l}")
+
+    label = [20]
+    def body(slot, cur):
+        nxt = cur ^ 1
+        ks1 = (slot + 1) & 3                                   # K(t+1)
+        ks2 = (slot + 2) & 3                                   # K(t+2): the next iteration's window starts here
+        ds = (slot + 3) & 3                                    # tile t+3 goes where tile t-1 was
+        # ---- QK phase: 16 fragments x (q0, q1).  Reads of fragments 0..2 were issued at the end of the previous iteration.
+        for f in range(16):
+            kb, ks = f >> 3, f & 7
+            for qb in range(2):
+                g = 2 * f + qb
+                if qb == 0:
+                    if f + 3 < 16: emit(kread(f + 3, ks1))
+                    emit(f"s_waitcnt lgkmcnt({min(3, 15 - f)})")
+                d = vr(S(nxt, qb, kb), 16)
+                c = vr(MINIT(qb), 16) if ks == 0 else d
+                emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KW(f), 4)}, {ar(Q(qb, ks), 4)}, {c}")
+                if g % 8 == 1:                                 # K piece p of tile t+4: the K half of THIS slot (K(t) was read an iteration ago)
+                    p = g // 8
+                    emit(f"s_add_u32 m0, %[ldsw], {slot * TILE + p * 1024}")
+                if g < 16: exp_half(S(cur, 0, 1), [P(0, 1, 0), P(0, 1, 1)], g)
+                else: exp_half(S(cur, 1, 0), [P(1, 0, 0), P(1, 0, 1)], g - 16)
+                if g % 8 == 1: emit(f"buffer_load_dwordx4 v{232 + g // 8}, %[rk], %[koff] offen lds")
+                if 24 <= g < 28: rowsum(0, g - 24)             # q0: (k0, s) final since the last iteration, (k1, s) since gap 16
+        for n in range(3):                                     # V^T(t) window: operands 0..2
+            for ins in vreads(n, slot): emit(ins)
+        emit("s_waitcnt vmcnt(12)")                            # in flight: K(t+4), V(t+2), K(t+3); landed: K(t+2), V(t+1) and older
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_barrier")
+        lb = label[0]; label[0] += 1
+        emit("s_cmp_eq_u32 %[cnt], 2")
+        emit(f"s_cbranch_scc0 {lb}f")
+        emit("s_nop 15")
+        mask_tail(nxt)
+        emit(f"{lb}:")
+        # ---- PV phase: 16 operands (key group j major) x (q0, q1)
+        for n in range(16):
+            j, d = n >> 2, n & 3
+            for qb in range(2):
+                g = 2 * n + qb
+                if qb == 0:
+                    if n + 3 < 16:
+                        for ins in vreads(n + 3, slot): emit(ins)
+                    emit(f"s_waitcnt lgkmcnt({2 * min(3, 15 - n)})")
+                o = ar(O(qb, d), 16)
+                emit(f"v_mfma_f32_32x32x16_bf16 {o}, {ar(VW(n), 4)}, {vr(P(qb, j >> 1, j & 1), 4)}, {o}")
+                if g % 8 == 1:                                 # V piece p of tile t+3 (V of tile t-1 was last read an iteration ago)
+                    p = g // 8
+                    emit(f"s_add_u32 m0, %[ldsw], {ds * TILE + VBASE + p * 1024}")
+                if g < 16: exp_half(S(cur, 1, 1), [P(1, 1, 0), P(1, 1, 1)], g)
+                else: exp_half(S(nxt, 0, 0), [P(0, 0, 0), P(0, 0, 1)], g - 16)
+                if g % 8 == 1: emit(f"buffer_load_dwordx4 v{236 + g // 8}, %[rv], %[voff] offen lds")
+                if 4 <= g < 6: rowsum(1, g - 4)                # q1: (k0, s) final since PV gap 0
+                if 20 <= g < 22: rowsum(1, 2 + g - 20)         # q1: (k1, s) final since PV gap 16 (P(q0, k0) is being rewritten for tile t+1 by now)
+        if "dmaoob" not in abl:
+            emit("s_add_u32 %[koff], %[koff], %[kstep]")
+            emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        if pending[0]:
+            emit("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % pending[0]); pending[0] = None
+        for f in range(3): emit(kread(f, ks2))                # K(t+2) window for the next iteration's QK phase
+
+    def prologue():
+        for qb in range(2):
+            for ks in range(8):
+                off = f" offset:{32 * ks}" if ks else ""
+                emit(f"buffer_load_dwordx4 {ar(Q(qb, ks), 4)}, v{240 + qb}, %[rq], 0 offen{off}")
+        for tl in range(4):                                   # tiles 0, 1, 2 and the K half of tile 3
+            for p in range(8 if tl < 3 else 4):
+                imm = tl * TILE + (VBASE if p >= 4 else 0) + (p & 3) * 1024
+                emit(f"s_add_u32 m0, %[ldsw], {imm}")
+                emit("s_nop 0")
+                if p < 4: emit(f"buffer_load_dwordx4 v{232 + (p & 3)}, %[rk], %[koff] offen lds")
+                else: emit(f"buffer_load_dwordx4 v{236 + (p & 3)}, %[rv], %[voff] offen lds")
+            emit("s_add_u32 %[koff], %[koff], %[kstep]")
+            if tl < 3: emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        emit(f"v_mov_b32_e32 v{NEGINF}, 0xff800000")
+        emit("s_waitcnt vmcnt(12)")                          # Q^T and tiles 0, 1 landed; tile 2 and K(3) stay in flight
+        emit("s_barrier")
+        for f in range(3): emit(kread(f, 0))
+        for f in range(16):                                   # S^T(0) = K(0) . Q^T
+            kb, ks = f >> 3, f & 7
+            if f + 3 < 16: emit(kread(f + 3, 0))
+            emit(f"s_waitcnt lgkmcnt({min(3, 15 - f)})")
+            for qb in range(2):
+                d = vr(S(0, qb, kb), 16)
+                emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KW(f), 4)}, {ar(Q(qb, ks), 4)}, {'0' if ks == 0 else d}")
+        for i in range(128): emit(f"v_accvgpr_write_b32 a{i}, 0")
+        for i in range(8): emit(f"v_mov_b32_e32 v{192 + i}, 0")
+        emit("s_nop 15")
+        for qb in range(2):                                   # row maxima over tile 0
+            s0 = S(0, qb, 0); m = 200 + qb
+            emit(f"v_max3_f32 v{m}, v{s0}, v{s0 + 1}, v{s0 + 2}")
+            for i in range(3, 31, 2): emit(f"v_max3_f32 v{m}, v{m}, v{s0 + i}, v{s0 + i + 1}")
+            emit(f"v_max_f32_e32 v{m}, v{m}, v{s0 + 31}")
+            emit(f"v_mov_b32_e32 v{202 + qb}, v{m}")
+        emit("s_nop 1")
+        for qb in range(2): emit(f"v_permlane32_swap_b32_e32 v{200 + qb}, v{202 + qb}")
+        for qb in range(2): emit(f"v_max_f32_e32 v{200 + qb}, v{200 + qb}, v{202 + qb}")
+        for qb in range(2):
+            for i in range(16): emit(f"v_xor_b32_e32 v{MINIT(qb) + i}, 0x80000000, v{200 + qb}")
+            for i in range(32): emit(f"v_sub_f32_e32 v{S(0, qb, 0) + i}, v{S(0, qb, 0) + i}, v{200 + qb}")
+        for i in range(8):                                   # first exp slices: (tile 0, q0, k0)
+            t0, t1 = temps()
+            emit(f"v_exp_f32_e32 v{t0}, v{S(0, 0, 0) + 2 * i}")
+            emit(f"v_exp_f32_e32 v{t1}, v{S(0, 0, 0) + 2 * i + 1}")
+            emit("s_nop 0")
+            emit(f"v_cvt_pk_bf16_f32 v{P(0, 0, i >> 2) + (i & 3)}, v{t0}, v{t1}")
+        tmp[0] = 0
+        for f in range(3): emit(kread(f, 1))                  # K(1) window for iteration 0
+
+    def epilogue():
+        emit("v_cmp_ne_u32_e32 vcc, 0, v244")
+        for qb in range(2): emit(f"v_cndmask_b32_e32 v{204 + qb}, v{LACC(qb)}, v{LACC(qb) + 1}, vcc")
+        for qb in range(2): emit(f"v_rcp_f32_e32 v{206 + qb}, v{204 + qb}")
+        R = 0
+        for qb in range(2):
+            for d in range(4):
+                for k in range(2):
+                    base = R; R = (R + 16) % 96
+                    for e in range(8): emit(f"v_accvgpr_read_b32 v{base + e}, a{O(qb, d) + 8 * k + e}")
+                    for e in range(8): emit(f"v_mul_f32_e32 v{base + e}, v{206 + qb}, v{base + e}")
+                    for w in range(4): emit(f"v_cvt_pk_bf16_f32 v{base + 8 + w}, v{base + 2 * w}, v{base + 2 * w + 1}")
+                    emit("s_nop 1")
+                    emit(f"v_permlane32_swap_b32_e32 v{base + 8}, v{base + 10}")
+                    emit(f"v_permlane32_swap_b32_e32 v{base + 9}, v{base + 11}")
+                    emit(f"buffer_store_dwordx4 {vr(base + 8, 4)}, v{242 + qb}, %[ro], 0 offen offset:{d * 64 + 32 * k}")
+
+    emit("s_nop 15")
+    prologue()
+    if "dmaoob" in abl:
+        emit("s_mov_b32 %[koff], 0x80000000"); emit("s_mov_b32 %[voff], 0x80000000")
+    for it in range(4):
+        if int(o_["align"]): emit(".p2align 6" if it == 0 else ".p2align 3")
+        if it == 0: emit("1:")
+        body(it, it & 1)
+        emit("s_add_i32 %[cnt], %[cnt], -1")
+        emit("s_cmp_eq_u32 %[cnt], 0")
+        if it < 3: emit("s_cbranch_scc1 2f")
+        else: emit("s_cbranch_scc0 1b")
+    emit("2:")
+    emit("s_waitcnt vmcnt(0)")
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_nop 15")
+    emit("s_nop 15")
+    epilogue()
+    return L
+
+
+def c_function2(opt=None):
+    lines = gen2(opt)
+    text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
+    used_v = list(range(0, 192)) + list(range(200, 208)) + [246]
+    clob = [f'"v{i}"' for i in used_v] + [f'"a{i}"' for i in range(0, 224)] + ['"vcc"', '"scc"', '"memory"']
+    return f"""// GENERATED by tools/gen_attn_q128_asm.py - do not edit.  {len(lines)} instructions: head_dim 128, 64 queries per wave (two 32-query blocks), prologue + loop + epilogue.
+__device__ __forceinline__ void q128_full_qb2(f32x8& lacc, const u32x4& ones, const u32x8& kbase, const u32x8& kbase_hi, const u32x4& trbase, const u32x4& trbase_hi,
+        const u32x8& dmaoff, const u32x2& qoff, const u32x2& ooff, uint32_t sel, uint32_t key0, const u32x4& rk, const u32x4& rv, const u32x4& rq, const u32x4& ro,
+        int cnt, int rem, uint32_t kstep, uint32_t vstep, uint32_t ldsw) {{
+    uint32_t koff = 0, voff = 0;
+    int stmp;
+    asm volatile(
+{text}        : "={{v[192:199]}}"(lacc), [cnt] "+s"(cnt), [koff] "+s"(koff), [voff] "+s"(voff), [stmp] "=&s"(stmp)
+        : "{{a[224:227]}}"(ones), "{{v[208:215]}}"(kbase), "{{v[216:223]}}"(kbase_hi), "{{v[224:227]}}"(trbase), "{{v[228:231]}}"(trbase_hi),
+          "{{v[232:239]}}"(dmaoff), "{{v[240:241]}}"(qoff), "{{v[242:243]}}"(ooff), "{{v244}}"(sel), "{{v245}}"(key0),
+          [rk] "s"(rk), [rv] "s"(rv), [rq] "s"(rq), [ro] "s"(ro), [rem] "s"(rem), [kstep] "s"(kstep), [vstep] "s"(vstep), [ldsw] "s"(ldsw)
+        : {", ".join(clob)});
+}}
+"""
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "candle-video_amd", "csrc", "attn_q128_loop.inc")
@@ -272,8 +526,12 @@ def main():
             k, v = a.split("="); opt[k] = v
     with open(out, "w") as f:
         f.write(c_function(opt))
+        f.write("\n")
+        f.write(c_function2(opt))
     print("wrote", out, opt)
 
 
 if __name__ == "__main__":
     main()
+
+

@@ -41,7 +41,7 @@ def classify(n):
         return "conv3d implicit GEMM" if "Lb1" in n else "linear GEMM"
     if "attn_cross64_kernel" in n:
         return "attention (cross / generic)"
-    if "attn_pipe64_kernel" in n or "attn_q64_kernel" in n:
+    if "attn_pipe64_kernel" in n or "attn_q64_kernel" in n or "attn_q128_kernel" in n:
         return "attention (self, q-prescaled)"
     if "attn_bf16_kernel" in n:
         return "attention (self, q-prescaled)" if len(a) > 1 and a[1] == "true" else "attention (cross / generic)"
