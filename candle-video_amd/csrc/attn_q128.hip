@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <queue>
+#include <tuple>
+#include <vector>
 #include "common.h"
 #include "kernels.h"
 
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void attn_q128_kernel(const AttnArgs a, int
 }
 
 std::mutex g_q128_mu;
-std::map<int, int*> g_q128_flag;                 // per device: one int, zero-initialised; holds the ticket of the last overflowing launch
+std::map<int, int*> g_q128_flag;                 // per device: 64 ints, zero-initialised; word (ticket & 63) holds the ticket of an overflowing launch
 std::atomic<int> g_q128_ticket{1};
 
 }  // namespace
@@ -160,12 +163,13 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
         std::lock_guard<std::mutex> lock(g_q128_mu);
         auto it = g_q128_flag.find(dev);
         if (it == g_q128_flag.end()) {
-            HIP_TRY(hipMalloc(&flag, sizeof(int)));
-            HIP_TRY(hipMemset(flag, 0, sizeof(int)));
+            HIP_TRY(hipMalloc(&flag, 64 * sizeof(int)));
+            HIP_TRY(hipMemset(flag, 0, 64 * sizeof(int)));
             g_q128_flag[dev] = flag;
         } else flag = it->second;
     }
-    const int ticket = g_q128_ticket.fetch_add(1) | 0x40000000;       // never 0 (the flag's initial value)
+    const int ticket = g_q128_ticket.fetch_add(1) | 0x40000000;       // never 0 (the flags' initial value)
+    flag += ticket & 63;                                               // 64 flag words in rotation: launches in flight on other streams keep their own
     constexpr int smem = NSLOT * TILE_BYTES;
     static std::atomic<unsigned long long> attr_devs{0};
     {
@@ -175,9 +179,38 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
             attr_devs.fetch_or(bit);
         }
     }
-    // 256-query blocks (64 queries per wave: half the K/V bytes per FLOP), the queries left over as 128-query blocks
+    // 256-query blocks (64 queries per wave: half the K/V bytes per FLOP), the queries left over as 128-query blocks.  How many
+    // of each: the split whose greedy schedule (one block per CU, big blocks first, a small block costs 0.55 of a big one)
+    // finishes first - at S = 17556 x 32 heads all 68 big blocks per head (9.0 rounds for 8.57 of work whatever the split), at
+    // shapes with few rounds a shorter tail (S = 4992: 15 big + 9 small per head, 2.55 rounds instead of 3.0).
     int nbig = a.Sq / 256;
-    if (const char* e = getenv("LTX_ATTN_Q128_BIG")) { const int v = atoi(e); if (v >= 0 && v < nbig) nbig = v; }   // tuning aid (0: 128-query blocks only)
+    {
+        static std::mutex mu; static std::map<std::tuple<int, int, int>, int> memo;
+        static int cu_of_dev[64] = {0};                      // per device, queried once
+        std::lock_guard<std::mutex> lock(mu);
+        int n_cu = 256;
+        if (dev >= 0 && dev < 64) {
+            if (!cu_of_dev[dev]) { int v = 0; cu_of_dev[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+            n_cu = cu_of_dev[dev];
+        }
+        const auto key = std::make_tuple(a.Sq, a.B * a.heads, n_cu);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            const int bmax = a.Sq / 256, ht = a.B * a.heads;
+            double best = 1e30; int best_b = bmax;
+            for (int b = bmax; b >= 0 && b >= bmax - 2 * (n_cu / (ht > 0 ? ht : 1)) - 2; --b) {
+                std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+                for (int i = 0; i < n_cu; ++i) cu.push(0.0);
+                const int64_t bigs = (int64_t)ht * b, smalls = (int64_t)ht * ((a.Sq - 256 * b + 127) / 128);
+                double end = 0.0;
+                for (int64_t i = 0; i < bigs + smalls; ++i) { const double t = cu.top() + (i < bigs ? 1.0 : 0.552); cu.pop(); cu.push(t); if (t > end) end = t; }
+                if (end < best - 1e-9) { best = end; best_b = b; }
+            }
+            it = memo.emplace(key, best_b).first;
+        }
+        nbig = it->second;
+    }
+    if (const char* e = getenv("LTX_ATTN_Q128_BIG")) { const int v = atoi(e); if (v >= 0 && v <= a.Sq / 256) nbig = v; }   // tuning aid (0: 128-query blocks only)
     const int nsmall = (a.Sq - nbig * 256 + 127) / 128;
     const int blocks = a.B * a.heads * (nbig + nsmall);
     hipLaunchKernelGGL(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, nbig, nsmall, flag, ticket);
