@@ -1,15 +1,20 @@
 // One-wave-per-SIMD bf16 GEMM for the DiT's linear layers (nn::Linear + the fused epilogues of gemm_common.h):
 //   C[M, N] = epi(A[M, K] @ W[N, K]^T + bias)
 // The K loop is ONE generated inline-asm statement per tile shape (tools/gen_gemm_asm.py -> gemm_asm_loop.inc): four waves
-// of 128 x 128 (or 160 x 128 / 160 x 64) output each, accumulators in the AGPR half of the 512-register file,
-// v_mfma_f32_32x32x16_bf16, and the K-step's 16 LDS-DMA pieces + 32 fragment reads placed one per MFMA gap - the
-// interleave that hipcc cannot be made to emit (round 1's compiler-scheduled form of this layout lost 8-25 %).
+// of 128 x 128 (or 160 x 64 / 160 x 128) output each, accumulators in the AGPR half of the 512-register file, and every
+// LDS-DMA piece and fragment read placed by hand between the MFMAs - the interleave that hipcc cannot be made to emit.
 // LDS image, source-side swizzle, buffer addressing with out-of-range = zeros and the epilogue arithmetic are those of
-// gemm_big.hip.  The MFMA shape differs (32x32x16 here, 16x16x32 there) yet the results are BIT-IDENTICAL to gemm_big's: the
-// matrix core accumulates its bf16 products in ascending k as an f32 chain, so only the k order matters
-// (tests/test_gpu_gemm_asm.py).  Kept as a measured experiment behind LTX_GEMM_ASM=1: operand delivery (13-18 TB/s of L2->LDS
-// over the chip) and MFMA time are both ~1 us per 64-deep K-step of a 256 x 256 tile, and a single in-order wave per SIMD
-// overlaps them worse than gemm_big's two (tools/gemm_asm_tune.py ablations).
+// gemm_big.hip; the results are BIT-IDENTICAL to gemm_big's whatever the MFMA shape: the matrix core accumulates its bf16
+// products in ascending k as an f32 chain, so only the k order matters (tests/test_gpu_gemm_asm.py).
+//
+// Two kernels live here:
+//   * gemm_asm16_kernel (round 3; v_mfma_f32_16x16x32_bf16, tiles 256 x 256, 160 x 256, 320 x 256): the plan family "asm16:*"
+//     that gemm_big.hip's plan measurement tries beside the gemm_big tiles, and the default on every large DiT shape since
+//     the DMA pieces of K-step t + 2 were spread over the whole iteration (s_memtime trace: packed into a third of the
+//     K-step they queued on the CU's address path and stalled the only instruction stream of the SIMD) and the epilogue
+//     was rebuilt around an f32 pass through LDS ("Linear GEMMs, round 3");
+//   * gemm_asm_kernel (round 1; v_mfma_f32_32x32x16_bf16): the first attempt at this structure, kept behind LTX_GEMM_ASM=1
+//     as a measured reference (4-12 % behind gemm_big on the DiT shapes: its DMA pieces are still issued in a burst).
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
     }
 }
 
-// ---- the same kernel on v_mfma_f32_16x16x32_bf16 (LTX_GEMM_ASM=16; tools/gen_gemm_asm.py gen16).  Round 3: the vendor library's
+// ---- the 16x16x32 kernel (plan family asm16:*, or LTX_GEMM_ASM=16 to force it; tools/gen_gemm_asm.py gen16).  The vendor library's
 // kernel for these shapes, disassembled, is this structure - four waves of 128 x 128, LDS-DMA staging - with the 16x16x32 MFMA,
 // the shape that holds a higher clock at equal cycles per FLOP.  Fragment = 16 rows x 32 k: lane (rr = lane & 15, q = lane >> 4)
 // reads row rr of a 16-row block, logical chunk 4 half + q; accumulator block (nb, mb) = D = W_frag x A_frag: the lane holds
