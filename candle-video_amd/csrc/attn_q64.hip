@@ -31,6 +31,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <tuple>
 #include <type_traits>
@@ -1069,11 +1070,29 @@ int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
     int nbig = nbig_max;
     if (const char* e = getenv("LTX_ATTN_Q64_BIG")) { nbig = atoi(e); if (nbig > nbig_max) nbig = nbig_max; if (nbig < 0) nbig = 0; }
     else {
-        // big blocks in whole rounds; if the queries left over (as small blocks) would exceed one round, keep adding rounds
-        const int64_t total_big = (int64_t)heads_total * nbig_max;
-        const int64_t rounds = total_big / n_cu;
-        nbig = (int)(rounds * n_cu / heads_total);
-        if (nbig > nbig_max) nbig = nbig_max;
+        // The split whose greedy schedule (one block per CU, big blocks first; a 128-query block costs 0.59 of a 256-query one,
+        // tools/attn_q64_tune.py) finishes first.  Round 2's rule - big blocks in whole rounds - is that split at one batch
+        // element (S = 4992, 32 heads: 16 big per head, 2.59 rounds for 2.44 of work) but not for batched guidance forwards
+        // (64 heads: 19 big per head = 5.00 rounds against 5.18; 96 heads: 18 = 7.59 against 7.77).  Speed only: a query's
+        // arithmetic does not depend on the size of its block.
+        static std::mutex mu; static std::map<std::tuple<int, int, int>, int> memo;
+        const auto key = std::make_tuple(a.Sq, heads_total, n_cu);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            double best = 1e30; int best_b = nbig_max;
+            for (int b = nbig_max; b >= 0; --b) {
+                std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+                for (int i = 0; i < n_cu; ++i) cu.push(0.0);
+                const int64_t bigs = (int64_t)heads_total * b, smalls = (int64_t)heads_total * ((a.Sq - 256 * b + 127) / 128);
+                if (bigs + smalls > 200000) break;             // (absurd shapes: keep the all-big split)
+                double end = 0.0;
+                for (int64_t i = 0; i < bigs + smalls; ++i) { const double t = cu.top() + (i < bigs ? 1.0 : 0.59); cu.pop(); cu.push(t); if (t > end) end = t; }
+                if (end < best - 1e-9) { best = end; best_b = b; }
+            }
+            it = memo.emplace(key, best_b).first;
+        }
+        nbig = it->second;
     }
     const int rest = a.Sq - nbig * 256;
     const int nsmall = (rest + 127) / 128;
