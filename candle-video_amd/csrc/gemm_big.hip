@@ -807,6 +807,14 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     const int p8 = ltx_gemm_p8_choice(g);
     if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
     int plan = ltx_gemm_big_pick_tile(g.M, g.N);
+    {   // static model (no measured plan: LTX_GEMM_TUNE=0 / ltx_set_autotune(0) without a plan file): the large linear layers take
+        // the one-wave-per-SIMD kernel too, tile by whole rounds x tile area (it won every such shape that was measured)
+        const char* a16 = getenv("LTX_GEMM_ASM16");
+        if (!g.conv && !(a16 && a16[0] == '0') && g.M >= 2048 && g.N >= 1024 && ltx_gemm_asm16_fits(g, epi)) {
+            const int t = ltx_gemm_asm_pick_tile(g.M, g.N);              // 0: 256 x 256, 1: 320 x 256, 2: 160 x 256
+            plan = kPlanAsm16 + (t == 0 ? 0 : (t == 1 ? 2 : 1));
+        }
+    }
     if (!getenv("LTX_GEMM_TILE")) LTX_TRY(cached_or_tuned_plan(g, s, &plan));
     return run_plan(g, epi, plan, s);
 }
