@@ -78,3 +78,19 @@ def test_q128_overflow_falls_back_to_the_exact_kernel(hip):
     torch.cuda.synchronize()
     assert torch.isfinite(o.float()).all()
     assert torch.equal(o.view(torch.int16), old.view(torch.int16))
+
+
+def test_q128_batch_of_two_matches_the_replaced_kernel(hip):
+    """Two batch elements (the block index carries the batch): ragged key count, queries left over as a 128-query block."""
+    S = 600
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = (torch.randn(2, S, H * D, device="cuda", generator=g) * (D ** -0.5) * math.log2(math.e)).bfloat16()
+    k = torch.randn(2, S, H * D, device="cuda", generator=g).bfloat16(); v = torch.randn(2, S, H * D, device="cuda", generator=g).bfloat16()
+    o, old = run(hip, q, k, v, True), run(hip, q, k, v, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    for b in range(2):
+        assert rel(o[b].float(), old[b].float()) <= 6e-3
+        ref = reference(q[b:b + 1], k[b:b + 1], v[b:b + 1], [0, 255, 256, 511, 512, 599])
+        assert rel(o[b, [0, 255, 256, 511, 512, 599]].float(), ref) <= 4e-3
+    assert not torch.equal(o[0], o[1])
