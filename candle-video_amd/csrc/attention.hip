@@ -683,6 +683,13 @@ __global__ __launch_bounds__(256, ATTN_PIPE_OCC) void attn_pipe64_kernel(const A
 // one-shot softmax over all keys (no running max, no rescale), no barrier after the initial load, next unit's Q
 // fragments in flight while the current unit is multiplied.  Keys past Sk read as zeros (buffer range) and get -inf.
 constexpr int XKV = 128;                                 // key capacity of the cross kernel
+#ifdef XTRACE
+__device__ unsigned g_xtrace[4096 * 8];
+extern "C" int ltx_dbg_xtrace(unsigned* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xtrace), (size_t)n * 4) == hipSuccess ? 0 : -1; }
+#define XSTAMP(i) if (lane == 0 && blockIdx.x < 1024) g_xtrace[(blockIdx.x * 4 + wave) * 8 + (i)] = (unsigned)wall_clock64()
+#else
+#define XSTAMP(i)
+#endif
 __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, int groups) {
     constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2, NKB = XKV / 32;
     __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
     const int r = lane & 31, h = lane >> 5;
     const int grp = blockIdx.x % groups, bh = blockIdx.x / groups;
     const int head = bh % a.heads, b = bh / a.heads;
+    XSTAMP(0);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
@@ -752,8 +760,11 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
     int u = grp * 4 + wave;
     bf16x8 qf[NKS], qn[NKS];
+    XSTAMP(1);
     if (u < nunits) load_q(u, qf);
+    int xi = 2;
     for (; u < nunits; u += ustride) {
+        if (xi < 8) { XSTAMP(xi); ++xi; }
         if (u + ustride < nunits) load_q(u + ustride, qn);
         // S^T = K . Q^T for all keys
         f32x16 sacc[NKB];
@@ -826,6 +837,10 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
     }
+#ifdef XTRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (xi < 8) XSTAMP(xi);
+#endif
 }
 
 // ---- exact-f32 flash attention (parity mode): one query per lane, 64 queries per block ----
