@@ -2,6 +2,7 @@
 // One process per GPU; xGMI is point to point, so the only collectives on the data path are the two the path needs:
 // an all-gather of a few MB per denoise step (latency-bound) and one strip send/recv + one gather per tiled decode.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -32,9 +33,19 @@ Rccl g_rccl;
 std::once_flag g_once;
 
 void load_rccl() {
+    // LTX_RCCL_LIB names the library explicitly (a deployment with RCCL outside the loader path; the tests use it to
+    // walk the "no RCCL on this host" branch). dlerror() clears its message when read: read it ONCE.
+    const char* forced = getenv("LTX_RCCL_LIB");
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) { g_rccl.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.so) break; }
-    if (!g_rccl.so) { g_rccl.err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+    std::string why;
+    auto open1 = [&](const char* n) {
+        g_rccl.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.so) { const char* e = dlerror(); if (why.empty()) why = e ? e : "?"; }
+        return g_rccl.so != nullptr;
+    };
+    if (forced && *forced) open1(forced);
+    else for (const char* n : names) if (open1(n)) break;
+    if (!g_rccl.so) { g_rccl.err = "cannot load librccl.so: " + why; return; }
     auto sym = [&](const char* n) { void* p = dlsym(g_rccl.so, n); if (!p && g_rccl.err.empty()) g_rccl.err = std::string("librccl.so lacks ") + n; return p; };
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
@@ -77,7 +88,11 @@ extern "C" int ltx_team_create(const void* id_host, int nranks, int rank, int de
     ltx_team* t = new ltx_team();
     t->nranks = nranks; t->rank = rank; t->device = device;
     ncclResult_t r = g_rccl.CommInitRank(&t->comm, nranks, id, rank);
-    if (r != 0) { delete t; ltx_set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return LTX_ERR_HIP; }
+    if (r != 0) {
+        delete t;
+        ltx_set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+        return LTX_ERR_HIP;
+    }
     *out = t;
     return LTX_OK;
 }

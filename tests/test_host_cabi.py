@@ -112,3 +112,26 @@ def test_team_entry_points_reject_bad_arguments_without_a_gpu(hip):
     assert hip.lib.ltx_team_size(None) == 0 and hip.lib.ltx_team_rank(None) == -1
     assert hip.lib.ltx_team_allgather_f32(None, None, None, 4, None) == 1
     assert hip.lib.ltx_team_exchange_f32(None, None, 0, -1, None, 0, -1, None) == 1
+
+
+def test_team_without_rccl_reports_unsupported_instead_of_crashing():
+    """A host without librccl.so: the first ltx_team_* call must return LTX_ERR_UNSUPPORTED (4) with the loader's message
+    (the loader's dlerror() text is read once - reading it twice hands std::string a null pointer). The library is
+    loaded once per process, so the branch is walked in a child with LTX_RCCL_LIB naming a file that does not exist."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, sys\n"
+        f"lib = ctypes.CDLL({os.path.join(root, 'candle-video_amd', 'libltxhip.so')!r})\n"
+        "lib.ltx_last_error.restype = ctypes.c_char_p\n"
+        "ident = (ctypes.c_char * 128)()\n"
+        "rc = lib.ltx_team_unique_id(ident)\n"
+        "msg = lib.ltx_last_error()\n"
+        "h = ctypes.c_void_p()\n"
+        "rc2 = lib.ltx_team_create(ident, 1, 0, 0, ctypes.byref(h))\n"
+        "print(rc, rc2, msg.decode())\n")
+    env = dict(os.environ, LTX_RCCL_LIB="/nonexistent/librccl-missing.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert (rc, rc2) == ("4", "4") and "cannot load librccl.so" in msg and "librccl-missing" in msg, r.stdout
