@@ -82,3 +82,34 @@ def test_default_output_gif_from_device_video(hip, tmp_path):
     want = v.permute(0, 2, 3, 4, 1).clamp(0, 255).to(torch.uint8)[0]
     for f in range(F):
         assert dec[f][0] == 4 and psnr_u8(dec[f][1], want[f]) > 30.0, (f, psnr_u8(dec[f][1], want[f]))
+
+
+@pytest.mark.parametrize("dim", [2048, 4096])
+def test_rope_table_kernel_vs_reference_scripts(hip, golden, dim):
+    """rope_table_kernel (the DiT's per-forward table, half-width: one value per channel pair) against the reference's own
+    scripts/compare_rope_freqs.py rust_compute_freqs / diffusers_compute_freqs and scripts/debug_rope.py
+    prepare_video_coords_debug, executed unmodified by tools/gen_fixtures.py rope.  Bar: tests/verify_rope_parity.rs:253-254
+    (MSE < 1e-5); left pad of dim % 6 columns exact; small angles to 1e-5.  dim 2048 = the 2B model, 4096 = the 13B."""
+    r = golden("ref_rope_table.safetensors")
+    F_, H_, W_ = (int(v) for v in r["fhw"])
+    scale = tuple(float(v) for v in r["scale"])
+    pad = (dim % 6) // 2
+    mse = lambda a, b: float(((a.double() - b.double()) ** 2).mean())
+    # grid path (ltx_transformer.rs:373-433), batch 2: the script's grid has two identical batch rows
+    c, s = hip.ops.rope_table(2, F_, H_, W_, dim, rope_scale=scale)
+    S = F_ * H_ * W_
+    for b in range(2):
+        cb, sb = c.cpu()[b * S:(b + 1) * S], s.cpu()[b * S:(b + 1) * S]
+        wc, ws = r[f"rust_cos_{dim}_scaled"][0], r[f"rust_sin_{dim}_scaled"][0]
+        assert torch.equal(wc[:, 0::2], wc[:, 1::2])                                  # the table IS pairs: half-width loses nothing
+        assert mse(cb, wc[:, 0::2]) < 1e-5 and mse(sb, ws[:, 0::2]) < 1e-5
+        assert mse(cb, r[f"diffusers_cos_{dim}_scaled_even"][0]) < 1e-5 and mse(sb, r[f"diffusers_sin_{dim}_scaled_even"][0]) < 1e-5
+        assert torch.equal(cb[:, :pad], torch.ones(S, pad)) and torch.equal(sb[:, :pad], torch.zeros(S, pad))
+        assert (cb[:, pad:pad + 48] - wc[:, 2 * pad:2 * pad + 96:2]).abs().max() < 1e-5
+    # video_coords path (:449-463): coords = fractional grid * base
+    grid = r["grid_rand"]
+    coords = (grid * torch.tensor([20.0, 2048.0, 2048.0]))[0]
+    n = coords.shape[0]
+    c2, s2 = hip.ops.rope_table(1, 1, 1, n, dim, coords=coords.to(DEV))
+    assert mse(c2.cpu(), r[f"rust_cos_{dim}_rand"][0][:, 0::2]) < 1e-5 and mse(s2.cpu(), r[f"rust_sin_{dim}_rand"][0][:, 0::2]) < 1e-5
+    assert (c2.cpu()[:, pad:pad + 48] - r[f"rust_cos_{dim}_rand"][0][:, 2 * pad:2 * pad + 96:2]).abs().max() < 1e-5

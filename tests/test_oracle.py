@@ -239,3 +239,72 @@ def test_oracle_pinned_by_three_more_reference_scripts(golden):
     r = golden("ref_rope_rotation.safetensors")
     got = O.apply_rotary_emb(r["x"], r["cos"], r["sin"])
     assert (got - r["out"]).abs().max() < 1e-6 and (got - r["out_diffusers"]).abs().max() < 1e-6
+
+
+# ---------- (a, continued) the RoPE table and grid against the reference's own rope scripts ----------
+ROPE_BASE = (20.0, 2048.0, 2048.0)                    # LtxVideoRotaryPosEmbed base sizes (ltx_transformer.rs:341-371)
+
+
+def _mse(a, b):
+    return float(((a.double() - b.double()) ** 2).mean())
+
+
+@pytest.mark.parametrize("dim", [2048, 4096])
+def test_rope_table_matches_reference_scripts(golden, dim):
+    """LtxVideoRotaryPosEmbed::forward (ltx_transformer.rs:436-524) against scripts/compare_rope_freqs.py
+    (rust_compute_freqs AND diffusers_compute_freqs) and scripts/debug_rope.py, executed unmodified by
+    tools/gen_fixtures.py rope.  Bar: tests/verify_rope_parity.rs:253-254, MSE < 1e-5 (the angles reach 1.5e4 rad in f32).
+    Pins the frequency layout (per frequency: f, h, w), transpose-then-flatten, repeat_interleave 2 and the LEFT pad of
+    dim % 6 columns (2 at dim 2048, 4 at 4096) with cos = 1, sin = 0."""
+    r = golden("ref_rope_table.safetensors")
+    F_, H_, W_ = (int(v) for v in r["fhw"])
+    scale = tuple(float(v) for v in r["scale"])
+    # (1) the grid path: prepare_video_coords (:373-433) with the pipeline's interpolation scale
+    cos, sin = O.rope_cos_sin(dim, 1, F_, H_, W_, scale, None)
+    wc, ws = r[f"rust_cos_{dim}_scaled"], r[f"rust_sin_{dim}_scaled"]
+    assert cos.shape == wc.shape == (1, F_ * H_ * W_, dim)
+    assert _mse(cos, wc) < 1e-5 and _mse(sin, ws) < 1e-5
+    pad = dim % 6
+    assert pad in (2, 4) and torch.equal(cos[..., :pad], wc[..., :pad]) and torch.equal(sin[..., :pad], ws[..., :pad])
+    assert torch.equal(wc[..., :pad], torch.ones_like(wc[..., :pad])) and not torch.equal(wc[..., pad:pad + 2], torch.ones_like(wc[..., :2]))
+    assert _mse(cos[..., 0::2], r[f"diffusers_cos_{dim}_scaled_even"]) < 1e-5 and torch.equal(cos[..., 0::2], cos[..., 1::2])
+    assert _mse(sin[..., 0::2], r[f"diffusers_sin_{dim}_scaled_even"]) < 1e-5 and torch.equal(sin[..., 0::2], sin[..., 1::2])
+    if dim == 2048:
+        assert _mse(cos[..., 0::2], r["debug_cos_2048_scaled_even"]) < 1e-5 and _mse(sin[..., 0::2], r["debug_sin_2048_scaled_even"]) < 1e-5
+    # small angles (the first frequencies) agree far tighter than the bar: not just "both look like noise"
+    assert (cos[..., pad:pad + 96] - wc[..., pad:pad + 96]).abs().max() < 1e-5
+    # (2) the video_coords path (:449-463): coords / base = the script's fractional grid
+    grid = r["grid_rand"]
+    coords = grid * torch.tensor(ROPE_BASE)
+    cos2, sin2 = O.rope_cos_sin(dim, 1, 1, 1, grid.shape[1], None, coords)
+    assert _mse(cos2, r[f"rust_cos_{dim}_rand"]) < 1e-5 and _mse(sin2, r[f"rust_sin_{dim}_rand"]) < 1e-5
+    assert (cos2[..., pad:pad + 96] - r[f"rust_cos_{dim}_rand"][..., pad:pad + 96]).abs().max() < 1e-5
+
+
+def test_rope_grid_order_matches_reference_scripts(golden):
+    """scripts/compare_rope_grid.py (rust_expected_grid, diffusers_rope_grid) and scripts/debug_rope.py
+    (prepare_video_coords_debug): the grid is [B, F*H*W, 3] with columns (f, h, w), f slowest.  The oracle builds the grid
+    inside rope_cos_sin, so it is read back through a dim-6 table: one frequency pi/2, columns (f, f, h, h, w, w), and
+    angle = pi/2 (2 g - 1) is invertible for g in [0, 1]."""
+    r = golden("ref_rope_table.safetensors")
+    F_, H_, W_ = (int(v) for v in r["fhw"])
+
+    def grid_of(scale, batch=1):
+        cos, sin = O.rope_cos_sin(6, batch, F_, H_, W_, scale, None)
+        ang = torch.atan2(sin, cos)[..., 0::2]                       # [B, S, 3]
+        return (ang / (math.pi / 2) + 1) / 2
+
+    frac = grid_of(tuple(b / max(n - 1, 1) for b, n in zip(ROPE_BASE, (F_, H_, W_))))      # scale * 1 / base = 1 / (extent - 1)
+    assert (frac - r["grid_frac"]).abs().max() < 1e-6
+    raw = grid_of(tuple(b * 0.125 for b in ROPE_BASE))                                      # g = index / 8 stays inside [0, 1]
+    assert (raw * 8 - r["grid_raw"]).abs().max() < 1e-5
+    scaled = grid_of(tuple(float(v) for v in r["scale"]), batch=2)
+    assert scaled.shape == r["grid_scaled"].shape and (scaled - r["grid_scaled"]).abs().max() < 1e-6
+
+
+def test_pcg32_gaussians_match_reference_test_rng_script(golden):
+    """scripts/test_rng.py (its own copy of Pcg32, both Box-Muller values kept, f64 math): first ten values for the seed
+    and increment of main.rs:568; utils/deterministic_rng.rs:44-81 computes the same in f32."""
+    want = golden("ref_rope_table.safetensors")["test_rng_values"]
+    got = O.Pcg32(42, 1442695040888963407).randn((10,))
+    assert (got.double() - want).abs().max() < 1e-5

@@ -95,6 +95,54 @@ def ref_scripts_imported():
               metadata={"source": "reference scripts/test_rope_rotation.py executed unmodified: rust_apply_rotary_emb_linear / diffusers_apply_rotary_emb on seeded inputs"})
 
 
+def ref_rope_tables():
+    """The RoPE TABLE and GRID pinned to the reference's own torch-only scripts, executed UNMODIFIED
+    from /root/reference with runpy and asked for the outputs of their own functions:
+      scripts/compare_rope_freqs.py - rust_compute_freqs ("how Rust computes RoPE frequencies") and diffusers_compute_freqs:
+                                      frequency layout, transpose-then-flatten, repeat_interleave 2, LEFT pad of dim % 6
+      scripts/compare_rope_grid.py  - rust_expected_grid / diffusers_rope_grid: (f, h, w) order, f slowest
+      scripts/debug_rope.py         - prepare_video_coords_debug (the grid with rope_interpolation_scale * patch / base,
+                                      ltx_transformer.rs:373-433) and compute_freqs_debug
+      scripts/test_rng.py           - its top-level Pcg32(42, 1442695040888963407) Box-Muller values (both z0 and z1 kept)
+    Full-width tables for dim 2048 (pad 2) and 4096 (pad 4); rows kept small (24 + 12)."""
+    import contextlib, io, runpy
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.getcwd(); os.chdir(td)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                fr = runpy.run_path(os.path.join(REF, "scripts", "compare_rope_freqs.py"), run_name="ref_rope_freqs")
+                gr = runpy.run_path(os.path.join(REF, "scripts", "compare_rope_grid.py"), run_name="ref_rope_grid")
+                db = runpy.run_path(os.path.join(REF, "scripts", "debug_rope.py"), run_name="ref_debug_rope")
+                rg = runpy.run_path(os.path.join(REF, "scripts", "test_rng.py"), run_name="ref_test_rng")
+                F, H, W = 2, 3, 4
+                scale = (8.0 / 25.0, 32.0, 32.0)                     # debug_rope.py main(): the pipeline's interpolation scale
+                grid_scaled = db["prepare_video_coords_debug"](2, F, H, W, scale)          # [2, 24, 3], base (20, 2048, 2048)
+                grid_raw = gr["diffusers_rope_grid"](1, F, H, W)                            # raw (f, h, w) indices
+                grid_frac = gr["rust_expected_grid"](1, F, H, W)                            # index / (extent - 1)
+                g = torch.Generator().manual_seed(31)
+                grid_rand = torch.rand(1, 12, 3, generator=g) * 1.5                         # fractional positions past 1 too
+                out = {"grid_scaled": c(grid_scaled), "grid_raw": c(grid_raw), "grid_frac": c(grid_frac), "grid_rand": c(grid_rand),
+                       "scale": torch.tensor(scale), "fhw": torch.tensor([F, H, W])}
+                for dim in (2048, 4096):
+                    for gname, grid in (("scaled", grid_scaled[:1]), ("rand", grid_rand)):
+                        cr, sr = fr["rust_compute_freqs"](dim, 10000.0, grid)
+                        cd, sd = fr["diffusers_compute_freqs"](dim, 10000.0, grid)
+                        out[f"rust_cos_{dim}_{gname}"], out[f"rust_sin_{dim}_{gname}"] = c(cr), c(sr)
+                        # the diffusers form of the same table: kept half-width (its channel pairs are equal, asserted here)
+                        assert torch.equal(cd[..., 0::2], cd[..., 1::2]) and torch.equal(sd[..., 0::2], sd[..., 1::2])
+                        out[f"diffusers_cos_{dim}_{gname}_even"], out[f"diffusers_sin_{dim}_{gname}_even"] = c(cd[..., 0::2]), c(sd[..., 0::2])
+                cdbg, sdbg = db["compute_freqs_debug"](grid_scaled[:1], dim=2048)
+                out["debug_cos_2048_scaled_even"], out["debug_sin_2048_scaled_even"] = c(cdbg[..., 0::2]), c(sdbg[..., 0::2])
+                out["test_rng_values"] = torch.tensor(rg["values"][:10], dtype=torch.float64)
+        finally:
+            os.chdir(cwd)
+    save_file(out, os.path.join(GOLD, "ref_rope_table.safetensors"),
+              metadata={"source": "reference scripts/compare_rope_freqs.py, compare_rope_grid.py, debug_rope.py, test_rng.py executed unmodified "
+                                  "(runpy): rust_compute_freqs / diffusers_compute_freqs(dim, 10000, grid) for dim 2048 and 4096 on "
+                                  "prepare_video_coords_debug(2, 2, 3, 4, (0.32, 32, 32)) and on a seeded random grid; rust_expected_grid / "
+                                  "diffusers_rope_grid(1, 2, 3, 4); test_rng.py's first ten Box-Muller values"})
+
+
 DIT_CASES = {
     # tests/verify_dit_parity.rs:24-39 config (2 layers, 2 heads x 16, dims 32), smaller grid, no mask, rope scale (1,1,1)
     "A": dict(cfg=dict(in_channels=32, out_channels=32, num_attention_heads=2, attention_head_dim=16, cross_attention_dim=32,
@@ -431,10 +479,14 @@ if __name__ == "__main__":
         c5vae_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":
-        ref_scripts(); ref_scripts_imported()
+        ref_scripts(); ref_scripts_imported(); ref_rope_tables()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rope":
+        ref_rope_tables()
         sys.exit(0)
     ref_scripts()
     ref_scripts_imported()
+    ref_rope_tables()
     for n, s in DIT_CASES.items():
         dit_case(n, s)
     vae_case()
