@@ -22,7 +22,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libltxhip.so")
+# LTXHIP_LIB: a variant build of the SAME library (tools/variants/libltxhip_*.so, the A/B tooling); never a fallback
+_LIB_PATH = os.environ.get("LTXHIP_LIB") or os.path.join(os.path.dirname(_HERE), "libltxhip.so")
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(

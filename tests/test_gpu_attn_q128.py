@@ -28,7 +28,7 @@ def qkv(S, seed, scale=1.0):
     return q, k, v
 
 
-def reference(q, k, v, rows):
+def reference(q, k, v, rows, H=H):
     S = q.shape[1]
     qs = q[0, rows].float().view(len(rows), H, D); ks = k[0].float().view(S, H, D); vs = v[0].float().view(S, H, D)
     p = torch.softmax(torch.einsum("qhd,khd->hqk", qs, ks) * math.log(2.0), dim=-1)
@@ -38,7 +38,7 @@ def reference(q, k, v, rows):
 def rel(a, b): return float((a - b).norm() / b.norm())
 
 
-def run(hip, q, k, v, on):
+def run(hip, q, k, v, on, H=H):
     old = os.environ.get("LTX_ATTN_Q128")
     try:
         if on: os.environ.pop("LTX_ATTN_Q128", None)
@@ -94,3 +94,35 @@ def test_q128_batch_of_two_matches_the_replaced_kernel(hip):
         ref = reference(q[b:b + 1], k[b:b + 1], v[b:b + 1], [0, 255, 256, 511, 512, 599])
         assert rel(o[b, [0, 255, 256, 511, 512, 599]].float(), ref) <= 4e-3
     assert not torch.equal(o[0], o[1])
+
+
+def test_q128_at_the_13b_launch_size_vs_f32_reference(hip):
+    """The 13B model's own launch: 32 heads x 128 at S = 17556 (= 274 x 64 + 20 keys; 68 x 256 + 148 queries per head, so the
+    last query block and the last key tile are both ragged, and row offsets reach 17556 x 4096 x 2 B = 144 MB per operand).
+    Against the f32 reference on a strided row set that touches the first / last row of 256- and 128-query blocks, both
+    sides of the last whole key tile and every ~997th row, ALL 32 heads (an indexing error at this size that both modes of
+    the engine shared would pass the bf16-vs-f32-mode checks of test_gpu_c5.py); and against the replaced kernel
+    (independent code) on the WHOLE output."""
+    H13, S = 32, 17556
+    g = torch.Generator(device="cuda").manual_seed(1313)
+    q = (torch.randn(1, S, H13 * D, device="cuda", generator=g) * (D ** -0.5) * math.log2(math.e)).bfloat16()
+    k = torch.randn(1, S, H13 * D, device="cuda", generator=g).bfloat16()
+    v = torch.randn(1, S, H13 * D, device="cuda", generator=g).bfloat16()
+    o = run(hip, q, k, v, True, H13)
+    o2 = run(hip, q, k, v, True, H13)
+    old = run(hip, q, k, v, False, H13)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    assert torch.equal(o.view(torch.int16), o2.view(torch.int16))
+    rows = sorted(set([0, 1, 63, 64, 127, 128, 255, 256, 511, 512, 17407, 17408, 17535, 17536, S - 21, S - 20, S - 2, S - 1] + list(range(5, S, 997))))
+    ref = reference(q, k, v, rows, H13)
+    got = o[0, rows].float()
+    e = rel(got, ref)
+    per_head = [(rel(got.view(-1, H13, D)[:, h], ref.view(-1, H13, D)[:, h])) for h in range(H13)]
+    per_row = [(rel(got[i], ref[i])) for i in range(len(rows))]
+    print(f"S={S}, 32 heads: rel-L2 vs f32 {e:.5f}; worst head {max(per_head):.5f}, worst row {max(per_row):.5f}; vs replaced kernel {rel(o.float(), old.float()):.5f}")
+    assert e <= 4e-3 and max(per_head) <= 5e-3 and max(per_row) <= 8e-3, (e, max(per_head), max(per_row))
+    assert rel(o.float(), old.float()) <= 6e-3
+    # no row of the full output is off by more than rounding from the independent kernel (a misplaced block would be O(1))
+    d = (o.float() - old.float()).view(S, H13, D).norm(dim=-1) / old.float().view(S, H13, D).norm(dim=-1).clamp_min(1e-6)
+    assert float(d.max()) <= 5e-2, float(d.max())

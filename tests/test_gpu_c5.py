@@ -160,3 +160,46 @@ def test_c5_pipeline_end_to_end():
         assert float(video.min()) >= 0.0 and float(video.max()) <= 255.0 and float(video.float().std()) > 1.0
         outs.append((lat_f.clone(), video[:, :, ::16].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_c5_width_one_layer_vs_oracle():
+    """An ORACLE-backed check at the 13B model's width: the whole forward of a ONE-layer DiT with C5's block
+    shape - D = 4096, 32 heads x 128, caption 4096, cross-attention dim 4096 (configs.rs:243-282) - on a 3 x 22 x 31 grid
+    (S = 2046 = 31 x 64 + 62 keys and 7 x 256 + 254 queries per head: ragged last key tile, ragged last query block; the
+    plane is C5's own 22 rows) with a partially masked prompt, against oracle.dit_forward on the host: f32 mode <= 1e-3
+    rel-max, bf16 production kernels (attn_q128 + the asm16 GEMM plans at K = 4096 / 16384) rel-L2 <= 2e-2 against the f32
+    oracle fed bf16-rounded weights, inputs and timestep.  The full-size C5 checks above compare the engine with its own f32
+    mode; this one cannot share a bug with it."""
+    import ltxhip
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ltx_oracle as O
+    from conftest import rel_max
+    dev = "cuda:0"
+    cfgd = dict(in_channels=128, out_channels=128, num_attention_heads=32, attention_head_dim=128, cross_attention_dim=4096,
+                num_layers=1, caption_channels=4096)
+    cfg = O.DitConfig(**cfgd)
+    w = O.synth_weights(O.dit_weight_shapes(cfg), seed=513)
+    F, H, W, K = 3, 22, 31, 128
+    S = F * H * W
+    g = torch.Generator().manual_seed(514)
+    hidden = torch.randn(1, S, 128, generator=g)
+    enc = torch.randn(1, K, 4096, generator=g)
+    mask = torch.zeros(1, K); mask[:, :45] = 1
+    coords = O.build_video_coords(1, F, H, W)
+    t = torch.tensor([938.0])                                   # exact in bf16: both modes see the same timestep
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    want = O.dit_forward(w, cfg, hidden, enc, t, mask, F, H, W, None, coords)
+    wr = {k: v.bfloat16().float() for k, v in w.items()}
+    want_r = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, F, H, W, None, coords)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = ltxhip.LtxVideoTransformer3DModel(ltxhip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(dev) for k, v in w.items()}, dt)
+        y = m.forward(hidden.to(dev), enc.to(dev), t, mask.to(dev), F, H, W, None, coords.to(dev)).float().cpu()
+        assert y.shape == want.shape and torch.isfinite(y).all()
+        res[dt] = y
+        del m
+        torch.cuda.empty_cache()
+    e32, e16 = rel_max(res[torch.float32], want), rel_l2(res[torch.bfloat16], want_r)
+    print({"c5_width_layer_f32_rel_max": e32, "c5_width_layer_bf16_rel_l2": round(e16, 5)})
+    assert e32 <= 1e-3, e32
+    assert e16 <= 2e-2, e16
