@@ -1,7 +1,8 @@
 // Self-attention at head_dim 128, q prescaled by scale*log2(e), no key bias (the 13B DiT, BASELINE C5: S = 17556, 32 heads):
-// one wave per SIMD, 32 queries per wave, the whole tile loop one generated asm statement (tools/gen_attn_q128_asm.py ->
+// one wave per SIMD, 64 queries per wave (256-query workgroups; 32 per wave in the 128-query form that serves the queries
+// left over), the whole tile loop one generated asm statement (tools/gen_attn_q128_asm.py ->
 // attn_q128_loop.inc).  Round 3: the structure of attn_q64.hip carried to head_dim 128, where it pays more - per 64-key
-// tile a wave issues the same 32 MFMAs of 32x32x16 as the 256-query form at head_dim 64 but HALF the exponentials, so the
+// tile and 32 queries a wave issues the same 32 MFMAs of 32x32x16 as the 256-query form at head_dim 64 but HALF the exponentials, so the
 // matrix pipe, not the vector issue port, bounds the loop.  attn_bf16_kernel<128> (attention.hip) runs a tile's phases back
 // to back in each wave and leaves the overlap to a second workgroup on the CU: 0.44-0.46 of the bf16 MFMA peak.
 //

@@ -436,6 +436,7 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
 }
 
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
+    ltx_prof_kernel(LTX_PROFK_CONV_HALO);
     if (!ltx_conv_halo_eligible(g, epi, bn)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: shape not eligible");
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
 #if HALO_LOADERS == 4

@@ -474,6 +474,7 @@ extern "C" int ltx_dbg_gemm_asm16_trace(uint32_t* out, int n_words) {
 #endif
 
 int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {     // tile 0: 256 x 256, 1: 160 x 256, 2: 320 x 256
+    ltx_prof_kernel(LTX_PROFK_GEMM_ASM16);
     if (tile == 0) return launch_asm_epi<256, 256, 2, 2, true>(g, epi, s);
     return tile == 1 ? launch_asm_epi<160, 256, 1, 4, true>(g, epi, s) : launch_asm_epi<320, 256, 2, 2, true>(g, epi, s);
 }
@@ -484,6 +485,7 @@ int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {
         const int tile = ltx_gemm_asm_pick_tile(g.M, g.N);  // kAsmTiles order: 256 x 256, 320 x 256, 160 x 256
         return ltx_launch_gemm_asm16(g, epi, tile == 0 ? 0 : (tile == 1 ? 2 : 1), s);
     }
+    ltx_prof_kernel(LTX_PROFK_GEMM_ASM);
     switch (ltx_gemm_asm_pick_tile(g.M, g.N)) {
         case 0: return launch_asm_epi<256, 256, 2, 2>(g, epi, s);
         case 1: return launch_asm_epi<320, 256, 2, 2>(g, epi, s);

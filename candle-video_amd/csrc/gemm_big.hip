@@ -642,6 +642,7 @@ int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
         plan = ltx_gemm_big_pick_tile(g.M, g.N);           // an epilogue the halo kernel does not carry
     }
     if (plan >= kPlanP8) return ltx_launch_gemm_p8(g, epi, plan == kPlanP8 ? 256 : 128, s);
+    ltx_prof_kernel(LTX_PROFK_GEMM_BIG);
     return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
 }
 
@@ -789,6 +790,7 @@ extern "C" int ltx_plan_load(const char* path) {
 
 int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     GemmArgs g = g_in;
+    ltx_prof_kernel(LTX_PROFK_GEMM_BIG);                   // the kernels this dispatcher hands over to overwrite it
     // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
     const char* xr = getenv("LTX_XCD_REMAP");
     g.xcd_remap = xr ? (xr[0] == '1') : 1;

@@ -302,6 +302,7 @@ bool ltx_gemm_p8_fits(const GemmArgs& g) {
 }
 
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s) {
+    ltx_prof_kernel(LTX_PROFK_GEMM_P8);
     if ((g.K + 63) / 64 * (g.conv ? g.ntaps : 1) < 2) LTX_FAIL(LTX_ERR_ARG, "gemm_p8: needs at least two K-tiles");
     if (!ltx_gemm_p8_fits(g)) LTX_FAIL(LTX_ERR_ARG, "gemm_p8: operands must be smaller than 2 GiB (32-bit buffer offsets)");
     if (bn == 256) return g.conv ? launch_epi8<256, 2, 4, true>(g, epi, s) : launch_epi8<256, 2, 4, false>(g, epi, s);

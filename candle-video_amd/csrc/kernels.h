@@ -11,6 +11,9 @@ static inline size_t ltx_dt_size(int dt) { return dt == LTX_DT_BF16 ? 2 : 4; }
 enum { LTX_PROF_GEMM = 0, LTX_PROF_CONV = 1, LTX_PROF_ATTN_SELF = 2, LTX_PROF_ATTN_CROSS = 3, LTX_PROF_ROWNORM = 4, LTX_PROF_NKINDS = 5 };
 bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token);   // work: algorithmic flops (or bytes for ROWNORM)
 void ltx_prof_end(void* token, hipStream_t s);
+// which KERNEL served the launch being timed (set by the launcher that actually enqueues it; read by ltx_prof_end)
+enum { LTX_PROFK_GEMM128 = 0, LTX_PROFK_GEMM_BIG = 1, LTX_PROFK_GEMM_P8 = 2, LTX_PROFK_CONV_HALO = 3, LTX_PROFK_GEMM_ASM = 4, LTX_PROFK_GEMM_ASM16 = 5, LTX_PROFK_N = 6 };
+void ltx_prof_kernel(int which);
 
 // ---------------- GEMM / implicit-GEMM conv (gemm.hip) ----------------
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE_RESID = 2, EPI_RESID = 3, EPI_D2S = 4, EPI_UNPATCH = 5 };

@@ -7,27 +7,33 @@
 #include "../../include/ltxhip.h"
 
 namespace {
-struct Rec { int kind; hipEvent_t a, b; double work; };
+struct Rec { int kind; hipEvent_t a, b; double work; int kernel; };
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 bool g_on = false;
 double g_ms[LTX_PROF_NKINDS], g_work[LTX_PROF_NKINDS];
 long long g_cnt[LTX_PROF_NKINDS];
+double g_kms[LTX_PROF_NKINDS][LTX_PROFK_N], g_kwork[LTX_PROF_NKINDS][LTX_PROFK_N];
+long long g_kcnt[LTX_PROF_NKINDS][LTX_PROFK_N];
+thread_local int t_kernel = 0;
 }  // namespace
 
 bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token) {
     *token = nullptr;
     if (!g_on) return false;
-    Rec* r = new Rec{kind, nullptr, nullptr, work};
+    Rec* r = new Rec{kind, nullptr, nullptr, work, 0};
+    t_kernel = 0;
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return false; }
     (void)hipEventRecord(r->a, s);
     *token = r;
     return true;
 }
+void ltx_prof_kernel(int which) { if (which >= 0 && which < LTX_PROFK_N) t_kernel = which; }
 void ltx_prof_end(void* token, hipStream_t s) {
     if (!token) return;
     Rec* r = reinterpret_cast<Rec*>(token);
     (void)hipEventRecord(r->b, s);
+    r->kernel = t_kernel;
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(*r);
     delete r;
@@ -38,20 +44,42 @@ extern "C" int ltx_prof_enable(int on) {
     g_on = on != 0;
     for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_recs.clear();
-    for (int i = 0; i < LTX_PROF_NKINDS; ++i) { g_ms[i] = 0; g_work[i] = 0; g_cnt[i] = 0; }
+    for (int i = 0; i < LTX_PROF_NKINDS; ++i) {
+        g_ms[i] = 0; g_work[i] = 0; g_cnt[i] = 0;
+        for (int k = 0; k < LTX_PROFK_N; ++k) { g_kms[i][k] = 0; g_kwork[i][k] = 0; g_kcnt[i][k] = 0; }
+    }
     return LTX_OK;
 }
-// Synchronises the device, folds all recorded launches into per-kind totals and returns one kind.
-extern "C" int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count) {
-    if (kind < 0 || kind >= LTX_PROF_NKINDS) LTX_FAIL(LTX_ERR_ARG, "ltx_prof_report: bad kind");
+namespace {
+int fold() {     // synchronises the device and folds all recorded launches into the per-kind / per-kernel totals
     HIP_TRY(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lk(g_mu);
     for (auto& r : g_recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.kind] += ms; g_work[r.kind] += r.work; g_cnt[r.kind] += 1; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_ms[r.kind] += ms; g_work[r.kind] += r.work; g_cnt[r.kind] += 1;
+            g_kms[r.kind][r.kernel] += ms; g_kwork[r.kind][r.kernel] += r.work; g_kcnt[r.kind][r.kernel] += 1;
+        }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_recs.clear();
+    return LTX_OK;
+}
+}  // namespace
+// One (class, kernel) cell: the launches of class `kind` that `kernel` (LTX_PROFK_*) served.
+extern "C" int ltx_prof_report_kernel(int kind, int kernel, double* total_ms, double* total_work, long long* count) {
+    if (kind < 0 || kind >= LTX_PROF_NKINDS || kernel < 0 || kernel >= LTX_PROFK_N) LTX_FAIL(LTX_ERR_ARG, "ltx_prof_report_kernel: bad kind / kernel");
+    std::lock_guard<std::mutex> lk(g_mu);
+    LTX_TRY(fold());
+    if (total_ms) *total_ms = g_kms[kind][kernel];
+    if (total_work) *total_work = g_kwork[kind][kernel];
+    if (count) *count = g_kcnt[kind][kernel];
+    return LTX_OK;
+}
+// Folds all recorded launches into per-kind totals and returns one kind.
+extern "C" int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count) {
+    if (kind < 0 || kind >= LTX_PROF_NKINDS) LTX_FAIL(LTX_ERR_ARG, "ltx_prof_report: bad kind");
+    std::lock_guard<std::mutex> lk(g_mu);
+    LTX_TRY(fold());
     if (total_ms) *total_ms = g_ms[kind];
     if (total_work) *total_work = g_work[kind];
     if (count) *count = g_cnt[kind];

@@ -109,7 +109,7 @@ _SIGS = {
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "ltx_pipeline_last_timing": [_vp],
-    "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp],
+    "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp], "ltx_prof_report_kernel": [_i, _i, _vp, _vp, _vp],
     "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_linear_segmented": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
@@ -1053,4 +1053,14 @@ def prof_report(kind: int):
     """-> (total_ms, total_work, count) for kernel class `kind` since prof_enable(True)."""
     ms, work, cnt = C.c_double(), C.c_double(), C.c_longlong()
     _check(lib.ltx_prof_report(kind, C.byref(ms), C.byref(work), C.byref(cnt)))
+    return ms.value, work.value, cnt.value
+
+
+PROF_KERNELS = ("gemm_kernel (128 x 128)", "gemm_big_kernel", "gemm_p8_kernel", "conv_halo_kernel", "gemm_asm_kernel (32x32x16)", "gemm_asm16_kernel")
+
+
+def prof_report_kernel(kind: int, kernel: int):
+    """-> (total_ms, total_work, count) of the launches of class `kind` served by kernel `kernel` (index into PROF_KERNELS)."""
+    ms, work, cnt = C.c_double(), C.c_double(), C.c_longlong()
+    _check(lib.ltx_prof_report_kernel(kind, kernel, C.byref(ms), C.byref(work), C.byref(cnt)))
     return ms.value, work.value, cnt.value

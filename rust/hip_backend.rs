@@ -9,8 +9,8 @@
 //!
 //! candle has no ROCm device, so the pipeline's tensors live on `Device::Cpu`; the two heavy components keep their
 //! weights and workspaces on the GPU and move only the call's operands: per denoise step 2.5 MB of latents in and out
-//! plus (once, thanks to the context cache) the 2 MB of text embeddings; per video 229 MB of f32 frames out
-//! (3.6 ms at PCIe Gen5 x16).  A caller that wants nothing on the host between steps uses `HipPipeline::call`, the
+//! plus (once, thanks to the context cache) the 2 MB of text embeddings; per video 458 MB of f32 frames out
+//! (7.2 ms at PCIe Gen5 x16).  A caller that wants nothing on the host between steps uses `HipPipeline::call`, the
 //! one-call form of `LtxPipeline::call` that keeps latents, predictions and the video in HBM (`ltx_pipeline_call`).
 //!
 //! STATUS: an UNTESTED SKETCH on the Rust side.  This file has never been compiled or type-checked (the authoring
