@@ -749,23 +749,46 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
         }
     }
     const int nunits = (a.Sq + 31) / 32, ustride = groups * 4;
-    auto load_q = [&](int u, bf16x8 (&qf)[NKS]) {
+    // AttnArgs::q_rowsq: queries arrive un-normalised; the RMS-norm scalar of a query row multiplies its score row, i.e. it
+    // joins the factor c below (a lane owns one query column), and costs nothing per score.  The partial sums of squares come
+    // from the projection's epilogue (GemmArgs::rowsq), q_rowsq_n per row (a multiple of 4), summed in ascending order.
+    const float* RS = a.q_rowsq ? a.q_rowsq + (int64_t)b * a.Sq * a.q_rowsq_n : nullptr;
+    const float rs_invD = a.q_rowsq ? 1.0f / (float)a.q_rowsq_D : 0.f;
+    // (the partials are only LOADED here - up to 16 per row, launcher-checked - so that the prefetch of the next unit stays
+    // asynchronous; row_factor() folds them where the unit's scores are scaled)
+    auto load_q = [&](int u, bf16x8 (&qf)[NKS], f32x4 (&rs)[4]) {
         int qr = u * 32 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
         const bf16_t* qp = Q + (int64_t)qr * a.ldq + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+        if (RS) {
+            const float* rp = RS + (int64_t)qr * a.q_rowsq_n;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                rs[g4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (4 * g4 < a.q_rowsq_n) rs[g4] = *reinterpret_cast<const f32x4*>(rp + 4 * g4);
+            }
+        }
+    };
+    auto row_factor = [&](const f32x4 (&rs)[4]) {
+        if (!RS) return c;
+        float ss = 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) { ss += rs[g4][0]; ss += rs[g4][1]; ss += rs[g4][2]; ss += rs[g4][3]; }
+        return c * (1.0f / sqrtf(ss * rs_invD + a.q_rowsq_eps));
     };
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
     int u = grp * 4 + wave;
     bf16x8 qf[NKS], qn[NKS];
+    f32x4 rsq[4], rsn[4];
     XSTAMP(1);
-    if (u < nunits) load_q(u, qf);
+    if (u < nunits) load_q(u, qf, rsq);
     int xi = 2;
     for (; u < nunits; u += ustride) {
         if (xi < 8) { XSTAMP(xi); ++xi; }
-        if (u + ustride < nunits) load_q(u + ustride, qn);
+        if (u + ustride < nunits) load_q(u + ustride, qn, rsn);
         // S^T = K . Q^T for all keys
         f32x16 sacc[NKB];
 #pragma unroll
@@ -776,10 +799,11 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
             }
         float mt = -INFINITY;
+        const float cq = row_factor(rsq);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sacc[kb][i] = fmaf(sacc[kb][i], c, bias_t[kb][i]); mt = fmaxf(mt, sacc[kb][i]); }
+            for (int i = 0; i < 16; ++i) { sacc[kb][i] = fmaf(sacc[kb][i], cq, bias_t[kb][i]); mt = fmaxf(mt, sacc[kb][i]); }
         {
             unsigned mu = __float_as_uint(mt);
             auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
@@ -836,6 +860,8 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) rsq[g4] = rsn[g4];
     }
 #ifdef XTRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -923,6 +949,13 @@ static bool attn_pipe_enabled() {
     return !(e && e[0] == '0');
 }
 
+// Shape-only: whether cross attention may take its queries un-normalised (AttnArgs::q_rowsq; bf16, head_dim 64, a key set
+// that fits attn_cross64_kernel, at most 16 partials per row).  LTX_Q2_FOLD=0: the stand-alone q-norm pass (A/B aid).
+bool ltx_attention_rowsq_ok(int hd, int Sk, int D) {
+    const char* e = getenv("LTX_Q2_FOLD");
+    return hd == 64 && Sk <= XKV && attn_cross_enabled() && D % 512 == 0 && D / 128 <= 16 && !(e && e[0] == '0');
+}
+
 bool ltx_attention_prescale_ok(int hd) {
     const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
     return (hd == 64 || hd == 128) && !(e && e[0] == '0');
@@ -942,6 +975,8 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         const char* wo = getenv("LTX_ATTN_WIDE_O");          // "0": 8-byte output stores (A/B aid)
         ax.wide_o = (a.ldo % 8 == 0 && ((uintptr_t)a.o & 15) == 0 && a.hd % 8 == 0 && !(wo && wo[0] == '0')) ? 1 : 0;
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
+        if (a.q_rowsq && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled() && a.q_rowsq_n >= 4 && a.q_rowsq_n <= 16 && a.q_rowsq_n % 4 == 0 && a.q_rowsq_D > 0))
+            LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is served by the short-key-set head_dim-64 kernel only (4..16 partials per row, a multiple of 4)");
         if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
             const int nunits = cdiv(a.Sq, 32);
@@ -957,7 +992,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
             }
             if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
             if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
-            hipLaunchKernelGGL(attn_cross64_kernel, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
+            LTX_LAUNCH_TIMED(attn_cross64_kernel, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
             LTX_CHECK_LAUNCH();
             return LTX_OK;
         }
@@ -981,6 +1016,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
         }
     } else {
+        if (a.q_rowsq) LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is a bf16 path");
         if (a.ldq % 4 || a.ldk % 4 || a.ldv % 4 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         dim3 grid((unsigned)cdiv(a.Sq, 64), (unsigned)a.heads, (unsigned)a.B), block(64);
         switch (a.hd) {

@@ -214,7 +214,7 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
     if (const char* e = getenv("LTX_ATTN_Q128_BIG")) { const int v = atoi(e); if (v >= 0 && v <= a.Sq / 256) nbig = v; }   // tuning aid (0: 128-query blocks only)
     const int nsmall = (a.Sq - nbig * 256 + 127) / 128;
     const int blocks = a.B * a.heads * (nbig + nsmall);
-    hipLaunchKernelGGL(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, nbig, nsmall, flag, ticket);
+    LTX_LAUNCH_TIMED(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, nbig, nsmall, flag, ticket);
     LTX_CHECK_LAUNCH();
     *flag_out = flag; *ticket_out = ticket;
     return LTX_OK;

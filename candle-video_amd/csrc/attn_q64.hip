@@ -1098,7 +1098,7 @@ int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
     const int nsmall = (rest + 127) / 128;
     AttnArgs ax = a;
     dim3 grid((unsigned)(heads_total * (nbig + nsmall))), block(256);
-    hipLaunchKernelGGL(attn_q64_kernel, grid, block, 0, s, ax, nbig, nsmall);
+    LTX_LAUNCH_TIMED(attn_q64_kernel, grid, block, 0, s, ax, nbig, nsmall);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

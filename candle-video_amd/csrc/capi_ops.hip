@@ -15,6 +15,15 @@ extern "C" int ltx_op_linear(const void* x, const void* w, const void* bias, voi
     return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, ltx_stream stream) {
+    if (!x || !w || !y || !rowsq) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: null tensor");
+    GemmArgs g; g.A = x; g.W = w; g.C = y; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.rowsq = rowsq;
+    return ltx_launch_gemm(g, dtc(dtype), EPI_BIAS, (hipStream_t)stream);
+}
+extern "C" int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int dtype, ltx_stream stream) {
+    return ltx_launch_rowsq(x, dtc(dtype), rows, N, ld, rowsq, (hipStream_t)stream);
+}
+
 extern "C" int ltx_op_linear_segmented(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int seg_width,
                                        int dtype, ltx_stream stream) {
     if (!x || !w || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_segmented: null tensor");
@@ -91,6 +100,16 @@ extern "C" int ltx_op_attention(const void* q, const void* k, const void* v, voi
     AttnArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.B = B; a.Sq = Sq; a.Sk = Sk; a.heads = heads; a.hd = hd; a.scale = scale; a.bias = key_bias;
     return ltx_launch_attention(a, dtc(dtype), (hipStream_t)stream);
+}
+
+extern "C" int ltx_op_attention_rowsq(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                                      int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias,
+                                      const float* q_rowsq, int q_rowsq_n, int q_rowsq_D, float q_rowsq_eps, ltx_stream stream) {
+    if (!q || !k || !v || !o || !q_rowsq) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention_rowsq: null tensor");
+    AttnArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.heads = heads; a.hd = hd; a.scale = scale; a.bias = key_bias;
+    a.q_rowsq = q_rowsq; a.q_rowsq_n = q_rowsq_n; a.q_rowsq_D = q_rowsq_D; a.q_rowsq_eps = q_rowsq_eps;
+    return ltx_launch_attention(a, LTX_DT_BF16, (hipStream_t)stream);
 }
 
 extern "C" int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,

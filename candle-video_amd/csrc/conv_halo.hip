@@ -407,7 +407,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
                   (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.H * g.Wd * g.ldr * 2.0 < 2147483648.0));
     if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

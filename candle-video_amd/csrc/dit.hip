@@ -15,6 +15,7 @@ struct DitBlock {
 struct DitCtx {                      // cached text context (see ltx_dit_forward)
     const void* enc = nullptr; const float* mask = nullptr;
     int B = 0, K = 0, iodt = 0; bool valid = false;
+    bool fold_q2 = false;            // k additionally carries attn2.norm_q.weight (the q-norm folded into cross attention)
     DevBuf kv, bias;                 // [L][B*K][2D] (k already RMS-normed), [B*K]
 };
 
@@ -34,11 +35,11 @@ struct ltx_dit {
     bool ctx_mode = false;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
-    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT;
+    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq;
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT};
+        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq};
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); }
         ctxs.clear();
@@ -206,6 +207,12 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     LTX_TRY(m->cosb.ensure(M * (D / 2) * sizeof(float))); LTX_TRY(m->sinb.ensure(M * (D / 2) * sizeof(float)));
     LTX_TRY(m->bias.ensure(MK * sizeof(float)));
     LTX_TRY(m->outT.ensure(M * c.out_channels * esz));
+    // Cross-attention q-norm folded into the attention kernel (bf16, head_dim 64, <= 128 text keys): scores are linear in q, so
+    // rms_norm(q) . k = r_row * (q . (k * w_q)) - the q2 projection's epilogue leaves per-row partial sums of squares
+    // (GemmArgs::rowsq), w_q = attn2.norm_q.weight rides on the cached k, and the stand-alone pass over q (read + write of
+    // [M, D] per layer) disappears.  ltx_transformer.rs:671-678, 719-740.
+    const bool fold_q2 = dt == LTX_DT_BF16 && ltx_attention_rowsq_ok(hd, K, D);
+    if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
     if (skip_layer_mask) LTX_TRY(m->orig.ensure(M * D * esz));
 
     // inputs -> model dtype (:1045-1047)
@@ -227,12 +234,12 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     // K/V projections + k-RMSNorm (:667-672).  None of it depends on the timestep or the latents, so inside a
     // caching scope (ltx_dit_context_cache) it is computed once per (enc, mask) pair instead of once per forward.
     DitCtx* ctx = nullptr;
-    for (auto& e : m->ctxs) if (e.valid && e.enc == enc && e.mask == enc_mask && e.B == B && e.K == K && e.iodt == iodt) ctx = &e;
+    for (auto& e : m->ctxs) if (e.valid && e.enc == enc && e.mask == enc_mask && e.B == B && e.K == K && e.iodt == iodt && e.fold_q2 == fold_q2) ctx = &e;
     if (!ctx) {
         if (m->ctxs.size() >= 4 || !m->ctx_mode) { for (auto& e : m->ctxs) e.valid = false; }
         for (auto& e : m->ctxs) if (!e.valid) { ctx = &e; break; }
         if (!ctx) { m->ctxs.emplace_back(); ctx = &m->ctxs.back(); }
-        ctx->enc = enc; ctx->mask = enc_mask; ctx->B = B; ctx->K = K; ctx->iodt = iodt;
+        ctx->enc = enc; ctx->mask = enc_mask; ctx->B = B; ctx->K = K; ctx->iodt = iodt; ctx->fold_q2 = fold_q2;
         LTX_TRY(ctx->kv.ensure((size_t)L * MK * 2 * D * esz)); LTX_TRY(ctx->bias.ensure(MK * sizeof(float)));
         LTX_TRY(ltx_launch_cast(enc, iodt, m->encin.p, dt, MK * c.caption_channels, s));
         LTX_TRY(ltx_linear(m->cap1, m->encin.p, c.caption_channels, m->c1.p, D, (int)MK, dt, EPI_GELU, s));
@@ -242,6 +249,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             void* kvl = (char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
             LTX_TRY(ltx_linear(m->blocks[l].kv2, m->encp.p, D, kvl, 2 * D, (int)MK, dt, EPI_BIAS, s));
             QkNormRopeArgs k2; k2.x = kvl; k2.rows = MK; k2.D = D; k2.ld = 2 * D; k2.nseg = 1; k2.w0 = m->blocks[l].nk2; k2.eps = 1e-5f;
+            if (fold_q2) k2.w0b = m->blocks[l].nq2;
             LTX_TRY(ltx_launch_qknorm_rope(k2, dt, s));
         }
         ctx->valid = true;     // outside a caching scope the entry is invalidated again at the end of this forward
@@ -314,12 +322,20 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         // h = h + gate_msa * to_out(attn)     (gate_msa = row 2)
         LTX_TRY(ltx_linear(b.o1, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 2 * D, 6 * D, S));
         // cross attention (no pre-norm, no RoPE, q/k RMSNorm, additive key bias)
-        LTX_TRY(ltx_linear(b.q2, m->h.p, D, m->qkv.p, D, (int)M, dt, EPI_BIAS, s));
-        QkNormRopeArgs q2; q2.x = m->qkv.p; q2.rows = M; q2.D = D; q2.ld = D; q2.nseg = 1; q2.w0 = b.nq2; q2.eps = 1e-5f;
-        LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
         const char* kvl = (const char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
         AttnArgs ax; ax.q = m->qkv.p; ax.k = kvl; ax.v = kvl + (size_t)D * esz; ax.o = m->attn.p;
         ax.ldq = D; ax.ldk = ax.ldv = 2 * D; ax.ldo = D; ax.B = B; ax.Sq = S; ax.Sk = K; ax.heads = H; ax.hd = hd; ax.scale = attn_scale; ax.bias = bias;
+        if (fold_q2) {
+            GemmArgs g;
+            g.A = m->h.p; g.W = b.q2.w; g.C = m->qkv.p; g.bias = b.q2.b; g.M = (int)M; g.N = b.q2.out; g.K = b.q2.in; g.lda = D; g.ldc = D;
+            g.rowsq = m->rsq.as<float>();
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
+            ax.q_rowsq = m->rsq.as<float>(); ax.q_rowsq_n = D / 128; ax.q_rowsq_D = D; ax.q_rowsq_eps = 1e-5f;
+        } else {
+            LTX_TRY(ltx_linear(b.q2, m->h.p, D, m->qkv.p, D, (int)M, dt, EPI_BIAS, s));
+            QkNormRopeArgs q2; q2.x = m->qkv.p; q2.rows = M; q2.D = D; q2.ld = D; q2.nseg = 1; q2.w0 = b.nq2; q2.eps = 1e-5f;
+            LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
+        }
         LTX_TRY(ltx_launch_attention(ax, dt, s));
         LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
         // MLP (shift_mlp = row 3, scale_mlp = row 4, gate_mlp = row 5)

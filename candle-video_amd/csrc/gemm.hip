@@ -177,6 +177,9 @@ int launch_t(const GemmArgs& g, int epi, hipStream_t s) {
 
 }  // namespace
 
+static thread_local bool t_rowsq_done = false;
+void ltx_gemm_rowsq_done() { t_rowsq_done = true; }
+
 int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     const int ch = dtype == LTX_DT_BF16 ? 8 : 4;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) LTX_FAIL(LTX_ERR_ARG, "gemm: empty problem");
@@ -184,6 +187,8 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     if (g.N % 4 != 0) LTX_FAIL(LTX_ERR_ARG, "gemm: N must be a multiple of 4");
     if (!g.conv && g.lda % ch != 0) LTX_FAIL(LTX_ERR_ARG, "gemm: lda must be 16-byte aligned");
     if ((epi == EPI_D2S || epi == EPI_UNPATCH) && !g.conv) LTX_FAIL(LTX_ERR_ARG, "gemm: d2s/unpatch need conv mode");
+    if (g.rowsq && (g.conv || g.c_seg_shift || epi == EPI_D2S || epi == EPI_UNPATCH)) LTX_FAIL(LTX_ERR_ARG, "gemm: rowsq needs a dense linear output");
+    t_rowsq_done = false;
     void* tok = nullptr;
     ltx_prof_begin(g.conv ? LTX_PROF_CONV : LTX_PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * (g.conv ? g.ntaps : 1), s, &tok);
     int rc;
@@ -192,5 +197,7 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     else if (dtype == LTX_DT_BF16) rc = g.conv ? launch_t<bf16_t, true>(g, epi, s) : launch_t<bf16_t, false>(g, epi, s);
     else rc = g.conv ? launch_t<float, true>(g, epi, s) : launch_t<float, false>(g, epi, s);
     ltx_prof_end(tok, s);
+    // by-product not written by the kernel that ran (every kernel but gemm_asm16): the stand-alone pass, same canonical order
+    if (rc == LTX_OK && g.rowsq && !t_rowsq_done) rc = ltx_launch_rowsq(g.C, dtype, g.M, g.N, g.ldc, g.rowsq, s);
     return rc;
 }

@@ -167,7 +167,7 @@ template <> struct AsmLoop16<320, 256, 2, 2> {             // 320 accumulator re
 __device__ uint32_t g_asm16_trace[1024 * 4 * 16];   // per wave: 8 segment sums, then entry / loop start / loop end / exit (100 MHz clock) and HW_ID
 #endif
 
-template <int BM, int BN, int WGM, int WGN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int EPI, bool RSQ = false>
 __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, NT = MB * NB, AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 128;
@@ -365,6 +365,30 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                     const bf16x4 pA = {(bf16_t)oA[0], (bf16_t)oA[1], (bf16_t)oA[2], (bf16_t)oA[3]}, pB = {(bf16_t)oB[0], (bf16_t)oB[1], (bf16_t)oB[2], (bf16_t)oB[3]};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pA), rc, (int)(co + cA), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pB), rc, (int)(co + cB), 0, 0);
+                    if constexpr (RSQ) {
+                        // GemmArgs::rowsq: the leaves of this thread's two 4-column groups (values as stored) go into the first
+                        // dword of its OWN two 16-byte slots of the row, which it has just consumed - nobody else reads them
+                        const int row = r0 + 8 * (k0 + j);
+                        float* rowf = reinterpret_cast<float*>(asm_smem + row * 1024);
+                        rowf[(cg ^ (row & 15)) << 2] = okA ? ltx_rowsq_leaf((float)pA[0], (float)pA[1], (float)pA[2], (float)pA[3]) : 0.f;
+                        rowf[((cg + 32) ^ (row & 15)) << 2] = okB ? ltx_rowsq_leaf((float)pB[0], (float)pB[1], (float)pB[2], (float)pB[3]) : 0.f;
+                    }
+                }
+            }
+            if constexpr (RSQ) {
+                // one thread per (row, 128-column half): the 32 leaves summed in ascending column order (the canonical order of
+                // ltx_launch_rowsq, rownorm.hip: same bits whichever kernel produced the matrix)
+                __syncthreads();
+                const int ng = (g.N + 127) >> 7;
+#pragma unroll 1
+                for (int pi = tid; pi < RP * 2; pi += 256) {
+                    const int row = pi >> 1, half = pi & 1, sw = row & 15;
+                    const float* rowf = reinterpret_cast<const float*>(asm_smem + row * 1024);
+                    float sum = rowf[((32 * half) ^ sw) << 2];
+#pragma unroll
+                    for (int c2 = 1; c2 < 32; ++c2) sum += rowf[((c2 + 32 * half) ^ sw) << 2];
+                    const int trow = p * RP + row, ncol = n0 + 128 * half;
+                    if (m0 + trow < g.M && ncol < g.N) g.rowsq[(int64_t)(m0 + trow) * ng + (ncol >> 7)] = sum;
                 }
             }
         }
@@ -389,10 +413,14 @@ const AsmTile kAsmTiles[] = {{256, 256, "asm256x256"}, {320, 256, "asm320x256"},
 template <int BM, int BN, int WGM, int WGN, int EPI, bool MF16 = false>
 int launch_asm(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    static std::atomic<unsigned long long> attr_devs{0};
+    static std::atomic<unsigned long long> attr_devs{0}, attr_devs_rsq{0};      // one mask per kernel (the attribute is per kernel and device)
     void (*kern)(const GemmArgs);
     if constexpr (MF16) kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI>; else kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
-    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
+    bool wrote_rowsq = false;
+    if constexpr (MF16 && EPI == EPI_BIAS) {                // GemmArgs::rowsq as a by-product of the wide epilogue
+        if (g.rowsq) { kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, true>; wrote_rowsq = true; }
+    }
+    LTX_TRY(ltx_set_max_dyn_smem(wrote_rowsq ? attr_devs_rsq : attr_devs, reinterpret_cast<const void*>(kern), smem));
     GemmArgs ga = g;
     const char* xr = getenv("LTX_XCD_REMAP");
     ga.xcd_remap = xr ? (xr[0] == '1') : 1;
@@ -405,8 +433,9 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
         ga.group_m = gm < 2 ? 0 : gm;
     }
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(256), smem, s, ga);
     LTX_CHECK_LAUNCH();
+    if (wrote_rowsq) ltx_gemm_rowsq_done();
     return LTX_OK;
 }
 

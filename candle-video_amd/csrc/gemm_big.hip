@@ -498,7 +498,7 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
                       (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0)) && (double)g.M * g.ldr * 2.0 < 2147483648.0;
     }
     dim3 grid((unsigned)(ga.sk_sf > 1 ? ga.sk_full + (tiles - ga.sk_full) * ga.sk_sf : tiles)), block(64 * WGM * WGN);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, grid, block, smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
@@ -651,7 +651,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     GemmArgs g = g_in;                                   // plain bias epilogue into a scratch [M, N] output
     void* scratch = nullptr;
     if (hipMalloc(&scratch, (size_t)g.M * g.N * sizeof(bf16_t)) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
-    g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0;
+    g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0; g.rowsq = nullptr;
     struct Guard {                                           // events and scratch are released on every return path
         void* scratch; hipEvent_t e0 = nullptr, e1 = nullptr;
         ~Guard() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (scratch) (void)hipFree(scratch); }

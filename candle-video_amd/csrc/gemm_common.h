@@ -41,6 +41,14 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     *reinterpret_cast<bf16x4*>(p) = x;
 }
 
+// Canonical sum of squares of one 4-column group (GemmArgs::rowsq): a fixed fma chain on the values AS STORED.  A 128-column
+// partial is the sequential sum, in ascending column order, of its 32 leaves.
+__device__ __forceinline__ float ltx_rowsq_leaf(float v0, float v1, float v2, float v3) {
+    float s = v0 * v0;
+    s = __builtin_fmaf(v1, v1, s); s = __builtin_fmaf(v2, v2, s);
+    return __builtin_fmaf(v3, v3, s);
+}
+
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float* v) {
     T* C = reinterpret_cast<T*>(g.C);

@@ -264,7 +264,7 @@ int launch_one8(const GemmArgs& g, hipStream_t s) {
     auto kern = gemm_p8_kernel<BN, WGM, WGN, EPI, CONV>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     dim3 grid((unsigned)(cdiv(g.M, 256) * cdiv(g.N, BN))), block(512);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, g);
+    LTX_LAUNCH_TIMED(kern, grid, block, smem, s, g);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

@@ -2,6 +2,7 @@
 // pipeline.cpp / capi_ops.hip) and the HIP kernels.  Not part of the public C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 enum { LTX_DT_F32 = 0, LTX_DT_BF16 = 1 };
@@ -14,6 +15,16 @@ void ltx_prof_end(void* token, hipStream_t s);
 // which KERNEL served the launch being timed (set by the launcher that actually enqueues it; read by ltx_prof_end)
 enum { LTX_PROFK_GEMM128 = 0, LTX_PROFK_GEMM_BIG = 1, LTX_PROFK_GEMM_P8 = 2, LTX_PROFK_CONV_HALO = 3, LTX_PROFK_GEMM_ASM = 4, LTX_PROFK_GEMM_ASM16 = 5, LTX_PROFK_N = 6 };
 void ltx_prof_kernel(int which);
+// Kernel-level start / stop events for the launch being timed (the dispatch packet's own timestamps, what rocprofv3's kernel
+// trace reports): stream-level hipEventRecord brackets also count the dispatch latency and the end-of-kernel release that the
+// un-profiled pipeline overlaps with the neighbouring kernels (+5..10 us on a 180 us launch).  True at most ONCE per
+// ltx_prof_begin on this thread; a launch that enqueues more than one kernel keeps its stream-level bracket.
+bool ltx_prof_kernel_events(hipEvent_t* a, hipEvent_t* b);
+#define LTX_LAUNCH_TIMED(kernel, grid, block, shmem, stream, ...) do {                                           \
+        hipEvent_t _pa = nullptr, _pb = nullptr;                                                                   \
+        if (ltx_prof_kernel_events(&_pa, &_pb)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _pa, _pb, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                  \
+    } while (0)
 
 // ---------------- GEMM / implicit-GEMM conv (gemm.hip) ----------------
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE_RESID = 2, EPI_RESID = 3, EPI_D2S = 4, EPI_UNPATCH = 5 };
@@ -37,6 +48,12 @@ struct GemmArgs {
     // EPI_BIAS only: output split into column segments of width 1 << c_seg_shift, segment j a dense [M, ldc] matrix at
     // C + j * c_seg_stride elements (fused q|k|v projection -> three contiguous matrices); 0 = one [M, ldc] matrix
     int c_seg_shift = 0; int64_t c_seg_stride = 0;
+    // Optional by-product (linear layers): per-row partial sums of squares of the OUTPUT as stored (after the epilogue,
+    // rounded to T), one f32 per 128-column group: rowsq[m * ceil(N / 128) + g].  The consumer's row norm then needs no pass
+    // over the matrix (cross-attention q-norm, dit.hip).  Summation order is CANONICAL - a fixed function of (m, g) alone,
+    // ltx_rowsq_leaf / ltx_launch_rowsq - so the value does not depend on which kernel the plan picked: gemm_asm16's
+    // epilogue produces it in place, every other kernel is followed by the stand-alone pass (ltx_launch_gemm).
+    float* rowsq = nullptr;
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
     int group_m = 0;              // gemm_big: tile order inside that run: columns of group_m row-tiles (0/1: row-major)
     int wide_epi = 0;             // gemm_big (set by its launcher): result tile through LDS, 16-byte row-contiguous stores
@@ -51,6 +68,9 @@ struct GemmArgs {
     unsigned* sk_cnt = nullptr;   // arrival counters [tail tile], zeroed before the launch
 };
 int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s);
+// canonical per-row partial sums of squares of x [rows, N] (row stride ld elements): out[row * ceil(N / 128) + g] (rownorm.hip)
+int ltx_launch_rowsq(const void* x, int dtype, int64_t rows, int N, int ld, float* out, hipStream_t s);
+void ltx_gemm_rowsq_done();      // a GEMM kernel that wrote GemmArgs::rowsq itself tells ltx_launch_gemm so (thread-local)
 // large-tile LDS-DMA bf16 variant (gemm_big.hip); ltx_launch_gemm dispatches to it when eligible
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype);
 int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
@@ -90,6 +110,7 @@ struct QkNormRopeArgs {
     int64_t rows = 0; int D = 0; int ld = 0; int nseg = 1;
     int64_t seg_stride = 0;       // elements from segment j to j+1 (0: D, i.e. adjacent column blocks of one row)
     const void* w0 = nullptr; const void* w1 = nullptr;   // T [D]
+    const void* w0b = nullptr;    // optional second weight on segment 0: x * rinv * w0 * w0b (a consumer's weight folded in, dit.hip)
     float eps = 1e-5f;
     const float* cos = nullptr; const float* sin = nullptr;  // f32 [rows, D/2] or null (no RoPE)
     float out_scale0 = 1.f;       // extra factor on segment 0's output (q): lets attention fold scale*log2(e) into Q
@@ -116,6 +137,10 @@ struct AttnArgs {
     int q_prescaled = 0;                          // bf16, no bias: q already carries scale*log2(e) (qknorm_rope out_scale0)
     int xcd_heads = 0;                            // set by the launcher: whole heads per XCD (block order, speed only)
     int wide_o = 0;                               // set by the launcher: 16-byte output stores (ldo % 8 == 0, 16-byte aligned o)
+    // Queries that arrive UN-normalised (attn_cross64_kernel only): score row i is multiplied by
+    // 1 / sqrt(sum_g q_rowsq[i * q_rowsq_n + g] / q_rowsq_D + q_rowsq_eps), the RMS-norm scalar of query row i (GemmArgs::rowsq
+    // of the projection that produced q); the norm's weight vector is folded into k by the caller.
+    const float* q_rowsq = nullptr; int q_rowsq_n = 0, q_rowsq_D = 0; float q_rowsq_eps = 0.f;
     const int* gate_flag = nullptr; int gate_ticket = 0;   // attn_bf16_kernel<128>: run only if *gate_flag == gate_ticket (exact pass after attn_q128's overflow flag)
 };
 bool ltx_attention_q128_fits(const AttnArgs& a);           // attn_q128.hip: head_dim 128 one-wave-per-SIMD kernel
@@ -123,7 +148,8 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
 bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row offset below 2^31 (its 32-bit buffer arithmetic)
-bool ltx_attention_prescale_ok(int hd);           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
+bool ltx_attention_prescale_ok(int hd);
+bool ltx_attention_rowsq_ok(int hd, int Sk, int D);   // shape-only: cross attention can fold the q RMS-norm (AttnArgs::q_rowsq)           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
 constexpr int LTX_MAX_BATCH = 16;      // per-sample scalars a launch carries by value (API batches run as chunks of 8; tile batches use 16)

@@ -1,5 +1,6 @@
 // Optional per-kernel-class timing with HIP events on the launch stream (used by bench.py for the
 // `roofline` object).  Disabled by default: zero overhead on the product path.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -7,7 +8,7 @@
 #include "../../include/ltxhip.h"
 
 namespace {
-struct Rec { int kind; hipEvent_t a, b; double work; int kernel; };
+struct Rec { int kind; hipEvent_t a, b; double work; int kernel; hipEvent_t ka, kb; int nk; };
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 bool g_on = false;
@@ -16,16 +17,27 @@ long long g_cnt[LTX_PROF_NKINDS];
 double g_kms[LTX_PROF_NKINDS][LTX_PROFK_N], g_kwork[LTX_PROF_NKINDS][LTX_PROFK_N];
 long long g_kcnt[LTX_PROF_NKINDS][LTX_PROFK_N];
 thread_local int t_kernel = 0;
+thread_local Rec* t_cur = nullptr;
+bool g_kernel_events = true;            // LTX_PROF_KERNEL_EVENTS=0: stream-level brackets only (the rounds 1-3 measurement)
 }  // namespace
 
 bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token) {
     *token = nullptr;
     if (!g_on) return false;
-    Rec* r = new Rec{kind, nullptr, nullptr, work, 0};
+    Rec* r = new Rec{kind, nullptr, nullptr, work, 0, nullptr, nullptr, 0};
     t_kernel = 0;
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return false; }
     (void)hipEventRecord(r->a, s);
     *token = r;
+    t_cur = r;
+    return true;
+}
+bool ltx_prof_kernel_events(hipEvent_t* a, hipEvent_t* b) {
+    Rec* r = t_cur;
+    if (!r || !g_kernel_events) return false;
+    if (r->nk++ != 0) return false;                      // a second kernel inside one timed launch: the stream bracket stands
+    if (hipEventCreate(&r->ka) != hipSuccess || hipEventCreate(&r->kb) != hipSuccess) { r->nk = 2; return false; }
+    *a = r->ka; *b = r->kb;
     return true;
 }
 void ltx_prof_kernel(int which) { if (which >= 0 && which < LTX_PROFK_N) t_kernel = which; }
@@ -34,6 +46,7 @@ void ltx_prof_end(void* token, hipStream_t s) {
     Rec* r = reinterpret_cast<Rec*>(token);
     (void)hipEventRecord(r->b, s);
     r->kernel = t_kernel;
+    t_cur = nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(*r);
     delete r;
@@ -42,7 +55,8 @@ void ltx_prof_end(void* token, hipStream_t s) {
 extern "C" int ltx_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
-    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    { const char* e = getenv("LTX_PROF_KERNEL_EVENTS"); g_kernel_events = !(e && e[0] == '0'); }
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); if (r.ka) (void)hipEventDestroy(r.ka); if (r.kb) (void)hipEventDestroy(r.kb); }
     g_recs.clear();
     for (int i = 0; i < LTX_PROF_NKINDS; ++i) {
         g_ms[i] = 0; g_work[i] = 0; g_cnt[i] = 0;
@@ -55,7 +69,12 @@ int fold() {     // synchronises the device and folds all recorded launches into
     HIP_TRY(hipDeviceSynchronize());
     for (auto& r : g_recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        hipError_t e = hipErrorUnknown;
+        if (r.nk == 1 && r.ka && r.kb) e = hipEventElapsedTime(&ms, r.ka, r.kb);          // the kernel's own start -> end
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipEventElapsedTime(&ms, r.a, r.b); }
+        if (r.ka) (void)hipEventDestroy(r.ka);
+        if (r.kb) (void)hipEventDestroy(r.kb);
+        if (e == hipSuccess) {
             g_ms[r.kind] += ms; g_work[r.kind] += r.work; g_cnt[r.kind] += 1;
             g_kms[r.kind][r.kernel] += ms; g_kwork[r.kind][r.kernel] += r.work; g_kcnt[r.kind][r.kernel] += 1;
         }

@@ -21,6 +21,7 @@
 // Rows that do not fit NSLOT chunks per lane fall back to a re-reading variant (second read hits L2).
 #include "common.h"
 #include "kernels.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -237,12 +238,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
     const int nch = a.D / CH;
     const float* cs = a.cos ? a.cos + rr * (a.D / 2) : nullptr;
     const float* sn = a.sin ? a.sin + rr * (a.D / 2) : nullptr;
-    auto finish = [&](Chunk16 v, int c, float rinv, const T* w, T* x) {
+    auto finish = [&](Chunk16 v, int c, float rinv, const T* w, const T* wb, T* x) {
         float f[CH]; chunk_to_f32<T>(v, f);
         Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
         float wv[CH]; chunk_to_f32<T>(wc, wv);
 #pragma unroll
         for (int i = 0; i < CH; ++i) f[i] = f[i] * rinv * wv[i];
+        if (wb) {                                          // a consumer's weight folded in (QkNormRopeArgs::w0b)
+            Chunk16 wc2; wc2.u = *reinterpret_cast<const u32x4*>(wb + c * CH);
+            float wv2[CH]; chunk_to_f32<T>(wc2, wv2);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) f[i] *= wv2[i];
+        }
         if (cs) {
             float co[CH / 2], si[CH / 2];
             if constexpr (CH == 8) {
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
     for (int seg = 0; seg < a.nseg; ++seg) {
         T* x = reinterpret_cast<T*>(a.x) + rr * a.ld + (int64_t)seg * (a.seg_stride ? a.seg_stride : a.D);
         const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+        const T* wb = seg == 0 ? reinterpret_cast<const T*>(a.w0b) : nullptr;
         const float oscale = seg == 0 ? a.out_scale0 : 1.0f;
         if constexpr (CACHED) {
             Chunk16 v[NSLOT];
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
             ss = group_sum(ss, lpr);
             const float rinv = oscale / sqrtf(ss / (float)a.D + a.eps);
 #pragma unroll
-            for (int i = 0; i < NSLOT; ++i) { int c = sub + i * lpr; if (c < nch) finish(v[i], c, rinv, w, x); }
+            for (int i = 0; i < NSLOT; ++i) { int c = sub + i * lpr; if (c < nch) finish(v[i], c, rinv, w, wb, x); }
         } else {
             float ss = 0.f;
             for (int c = sub; c < nch; c += lpr) {
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
             }
             ss = group_sum(ss, lpr);
             const float rinv = oscale / sqrtf(ss / (float)a.D + a.eps);
-            for (int c = sub; c < nch; c += lpr) { Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH); finish(v, c, rinv, w, x); }
+            for (int c = sub; c < nch; c += lpr) { Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(x + c * CH); finish(v, c, rinv, w, wb, x); }
         }
     }
 }
@@ -350,6 +358,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
             float wv[CH]; chunk_to_f32<T>(wc, wv);
 #pragma unroll
             for (int j = 0; j < CH; ++j) f[j] = f[j] * rinv * wv[j];
+            if (seg == 0 && a.w0b) {                       // a consumer's weight folded in (QkNormRopeArgs::w0b)
+                Chunk16 wc2; wc2.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.w0b) + c * CH);
+                float wv2[CH]; chunk_to_f32<T>(wc2, wv2);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) f[j] *= wv2[j];
+            }
             if (rope) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -393,6 +407,42 @@ __global__ void rope_table_kernel(const RopeTableArgs a) {
     }
 }
 
+// Canonical per-row partial sums of squares (GemmArgs::rowsq) of a stored matrix: one f32 per (row, 128-column group) =
+// sequential sum over the group's 32 four-column leaves (ltx_rowsq_leaf), ascending.  The stand-alone form of what
+// gemm_asm16's epilogue writes as a by-product - same order, same bits.  A wave takes 64 (row, group) pairs: in step c lane L
+// would read leaf c of pair L (uncoalesced), so the roles are transposed through LDS: each half-wave reads ONE pair's 256
+// contiguous bytes (bf16) per step, writes its 32 leaves, and after 32 steps every lane sums one pair's leaves in order.
+template <typename T>
+__global__ __launch_bounds__(256) void rowsq_kernel(const T* x, int64_t rows, int N, int ld, float* out) {
+    __shared__ float leaves[4][64][33];                    // [wave][pair][leaf] (+1: conflict-free column reads)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, cg = lane & 31;
+    const int ng = (N + 127) / 128;
+    const int64_t npairs = rows * ng;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+#pragma unroll 4
+    for (int st = 0; st < 32; ++st) {
+        const int64_t pr = p0 + 2 * st + half;
+        float leaf = 0.f;
+        if (pr < npairs) {
+            const int64_t row = pr / ng; const int g = (int)(pr - row * ng);
+            const int n = g * 128 + 4 * cg;
+            if (n < N) {                                   // N % 4 == 0: a leaf is inside or outside as a whole
+                float v[4]; load4<T>(x + row * ld + n, v);
+                leaf = ltx_rowsq_leaf(v[0], v[1], v[2], v[3]);
+            }
+        }
+        leaves[wave][2 * st + half][cg] = leaf;
+    }
+    __syncthreads();
+    const int64_t pr = p0 + lane;
+    if (pr < npairs) {
+        float s = leaves[wave][lane][0];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) s += leaves[wave][lane][c];
+        out[pr] = s;
+    }
+}
+
 int pick_lpr(int nch) {
     int lpr = 1;
     while (lpr < nch && lpr < 64) lpr <<= 1;
@@ -404,15 +454,15 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
     const int rpw = 64 / lpr;
     if (nch <= lpr && a.rows >= (int64_t)rpw * NSLOT * 4 * 64) {       // narrow rows, enough of them: NSLOT rows per lane group
         const int64_t rows_per_block = (int64_t)4 * rpw * NSLOT;
-        hipLaunchKernelGGL((rownorm_kernel<T, 1>), dim3((unsigned)cdiv64(a.rows, rows_per_block)), dim3(256), 0, s, a, lpr);
+        LTX_LAUNCH_TIMED((rownorm_kernel<T, 1>), dim3((unsigned)cdiv64(a.rows, rows_per_block)), dim3(256), 0, s, a, lpr);
     } else {
         // (measured and left out, round 3: four rows per wave with the scale / shift operands cached in registers - 312 blocks
         // instead of 1248 - ran the DiT's 4992 x 2048 rows in 15.9 us against 12.8 us: the pass is bound by how many row loads are
         // in flight across the chip, not by the operand traffic through the vector-memory path)
         const int64_t rows_per_block = 4 * rpw;
         dim3 grid((unsigned)cdiv64(a.rows, rows_per_block));
-        if (nch <= NSLOT * lpr) hipLaunchKernelGGL((rownorm_kernel<T, 0>), grid, dim3(256), 0, s, a, lpr);
-        else hipLaunchKernelGGL((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
+        if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), 0, s, a, lpr);
+        else LTX_LAUNCH_TIMED((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
     }
 }
 
@@ -450,6 +500,17 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
         if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<float, true>), grid, block, 0, s, a, lpr);
         else hipLaunchKernelGGL((qknorm_rope_kernel<float, false>), grid, block, 0, s, a, lpr);
     }
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
+int ltx_launch_rowsq(const void* x, int dtype, int64_t rows, int N, int ld, float* out, hipStream_t s) {
+    if (rows <= 0 || N <= 0) return LTX_OK;
+    if (!x || !out || N % 4 != 0 || ld % 4 != 0 || ((uintptr_t)x & 7)) LTX_FAIL(LTX_ERR_ARG, "rowsq: N and ld must be multiples of 4 and x 8-byte aligned");
+    const int64_t npairs = rows * ((N + 127) / 128);
+    dim3 grid((unsigned)cdiv64(npairs, 256)), block(256);
+    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(rowsq_kernel<bf16_t>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(x), rows, N, ld, out);
+    else hipLaunchKernelGGL(rowsq_kernel<float>, grid, block, 0, s, reinterpret_cast<const float*>(x), rows, N, ld, out);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }

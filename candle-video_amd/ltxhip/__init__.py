@@ -112,6 +112,8 @@ _SIGS = {
     "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp], "ltx_prof_report_kernel": [_i, _i, _vp, _vp, _vp],
     "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_linear_segmented": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
+    "ltx_op_attention_rowsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
     "ltx_op_rope_table": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
@@ -939,6 +941,33 @@ class ops:
         _check(lib.ltx_op_linear(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), M, N, K, _dt(x.dtype), epi,
                                  _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
         return y
+
+    @staticmethod
+    def linear_rowsq(x, w, bias):
+        """-> (x @ w^T + bias, per-row partial sums of squares of that output per 128-column group [M, ceil(N/128)] f32)"""
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        rs = torch.empty(M, (N + 127) // 128, dtype=torch.float32, device=x.device)
+        _check(lib.ltx_op_linear_rowsq(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), _ptr(rs), M, N, K, _dt(x.dtype), _stream()))
+        return y, rs
+
+    @staticmethod
+    def rowsq(x):
+        """the stand-alone form of linear_rowsq's by-product on a stored matrix (same values, bit for bit)"""
+        M, N = x.shape
+        rs = torch.empty(M, (N + 127) // 128, dtype=torch.float32, device=x.device)
+        _check(lib.ltx_op_rowsq(_ptr(x.contiguous()), C.c_int64(M), N, N, _ptr(rs), _dt(x.dtype), _stream()))
+        return rs
+
+    @staticmethod
+    def attention_rowsq(q, k, v, heads, scale, key_bias, q_rowsq, eps=1e-5):
+        """cross attention on UN-normalised queries: the RMS-norm scalar of each query row comes from q_rowsq [B*Sq, D/128]"""
+        B, Sq, D = q.shape
+        o = torch.empty_like(q)
+        _check(lib.ltx_op_attention_rowsq(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, k.shape[1], heads, D // heads,
+                                          D, D, D, D, C.c_float(scale), _ptr(key_bias), _ptr(q_rowsq), q_rowsq.shape[-1], D, C.c_float(eps), _stream()))
+        return o
 
     @staticmethod
     def linear_segmented(x, w, bias, seg_width):

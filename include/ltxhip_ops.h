@@ -18,6 +18,13 @@ extern "C" {
 int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, int epi,
                   const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);
 
+/* nn::Linear (epi 0) that also leaves the per-row partial sums of squares of its stored output, one f32 per 128-column
+ * group: rowsq[m * ceil(N/128) + g].  The summation order is canonical (independent of the kernel the plan picks), so a
+ * consumer can fold an RMS norm of the output rows without a pass over them: the cross-attention q-norm,
+ * ltx_transformer.rs:671-678.  ltx_op_rowsq is the stand-alone form on a stored matrix: same values, bit for bit. */
+int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, ltx_stream stream);
+int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int dtype, ltx_stream stream);
+
 /* The fused q|k|v projection of LtxAttention (ltx_transformer.rs:655-662: to_q, to_k, to_v on the same input) with the
  * output written as N/seg_width DENSE matrices: y[j][M][seg_width] = (x @ w^T + bias)[:, j*seg_width:(j+1)*seg_width].
  * seg_width a power of two dividing N. */
@@ -49,6 +56,12 @@ int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F,
 /* LtxAttention core (ltx_transformer.rs:699-741): o = softmax(scale q k^T + bias) v, q [B,Sq,heads*hd] etc. */
 int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                      int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias, int dtype, ltx_stream stream);
+/* Cross attention on UN-normalised queries (bf16, head_dim 64, Sk <= 128): softmax(r_i * scale * q_i . k_j + bias_j) v_j with
+ * r_i = 1 / sqrt(sum_g q_rowsq[i*n + g] / D + eps), the RMS-norm scalar of query row i; the norm's weight is expected folded
+ * into k by the caller (LtxAttention::forward with norm_q, ltx_transformer.rs:671-678, 719-740). */
+int ltx_op_attention_rowsq(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                           int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias,
+                           const float* q_rowsq, int q_rowsq_n, int q_rowsq_D, float q_rowsq_eps, ltx_stream stream);
 /* Same core for bf16, head_dim 64 or 128, no key bias, with q ALREADY multiplied by scale*log2(e) (the DiT self-attention
  * path folds that factor into the q RMSNorm+RoPE kernel): o = softmax_base2(q' k^T) v. */
 int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,

@@ -1,0 +1,131 @@
+"""GPU suite: the cross-attention q-norm folded into the attention kernel (round 4).
+
+LtxAttention::forward normalises q with an RMSNorm over the FULL model width before the heads are split
+(ltx_transformer.rs:671-678), then runs manual softmax attention over the <= 128 text keys (:719-740).  Scores are linear
+in q, so   rms_norm(q)_i . k_j = r_i * (q_i . (k_j * w_q)),  r_i = 1 / sqrt(mean(q_i^2) + eps):
+  * the q2 projection's epilogue leaves per-row partial sums of squares of its stored output (GemmArgs::rowsq), in a
+    CANONICAL summation order, so that the value does not depend on the kernel the plan cache picked;
+  * w_q rides on the cached k (QkNormRopeArgs::w0b), r_i joins the per-lane score factor of attn_cross64_kernel;
+  * the stand-alone q-norm pass (read + write of [S, D] per layer) disappears.
+Checked: the by-product against its stand-alone form bit for bit and against f32 torch; the folded attention against an f32
+reference of norm -> attention and against the un-folded HIP path; the whole DiT forward with the fold on and off against
+the oracle."""
+import ast
+import math
+import os
+
+import pytest
+import torch
+
+import ltx_oracle as O
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    assert torch.cuda.is_available()
+    return ltxhip
+
+
+def env(**kw):
+    class E:
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in kw}
+            for k, v in kw.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        def __exit__(self, *a):
+            for k, v in self.old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    return E()
+
+
+@pytest.mark.parametrize("M,N,K", [(4992, 2048, 2048), (384, 2048, 2048), (1000, 640, 256), (3001, 1032, 192), (600, 4096, 512)])
+def test_rowsq_byproduct_is_canonical_and_exact(hip, M, N, K):
+    """linear_rowsq (whatever kernel the plan picks: gemm_asm16's epilogue writes the partials itself, the others are followed by
+    the stand-alone pass) == rowsq(stored output) bit for bit, with every plan family forced in turn; and == an f64 sum of the
+    squares of the stored bf16 values to f32 rounding."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV); w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV)
+    y0, rs0 = hip.ops.linear_rowsq(x, w, b)
+    ref = hip.ops.rowsq(y0)
+    assert torch.equal(rs0, ref)
+    ng = (N + 127) // 128
+    yp = torch.zeros(M, ng * 128, dtype=torch.float64, device=DEV); yp[:, :N] = y0.double()
+    want = (yp ** 2).view(M, ng, 128).sum(-1)
+    assert (rs0.double() - want).abs().max() <= 2e-6 * want.abs().max()
+    for e in (dict(LTX_GEMM_ASM16="0", LTX_GEMM_TUNE="0"), dict(LTX_GEMM_ASM="16"), dict(LTX_GEMM_BIG="0")):
+        with env(**e):
+            y1, rs1 = hip.ops.linear_rowsq(x, w, b)
+        assert torch.equal(y1, y0) and torch.equal(rs1, rs0), e       # same output bits (plan independence), same partials
+    xf, wf, bf = x.float(), w.float(), b.float()
+    y32, rs32 = hip.ops.linear_rowsq(xf, wf, bf)                     # f32 mode: stand-alone pass on the f32 output
+    assert torch.equal(rs32, hip.ops.rowsq(y32))
+    assert (rs32.double() - (torch.nn.functional.pad(y32.double(), (0, ng * 128 - N)) ** 2).view(M, ng, 128).sum(-1)).abs().max() <= 2e-6 * want.abs().max()
+
+
+def ref_cross(q, k, v, wq, heads, scale, bias, eps):
+    """f32 torch: rms_norm(q) * wq -> softmax(q k^T scale + bias) v  (ltx_transformer.rs:671-678, 719-740)"""
+    qn = q.float() * torch.rsqrt(q.float().pow(2).mean(-1, keepdim=True) + eps) * wq.float()
+    B, Sq, D = q.shape
+    hd = D // heads
+    qh = qn.view(B, Sq, heads, hd).transpose(1, 2); kh = k.float().view(B, -1, heads, hd).transpose(1, 2); vh = v.float().view(B, -1, heads, hd).transpose(1, 2)
+    att = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None: att = att + bias[:, None, None, :]
+    return (torch.softmax(att, -1) @ vh).transpose(1, 2).reshape(B, Sq, D)
+
+
+@pytest.mark.parametrize("B,Sq,Sk,heads,nvalid", [(1, 4992, 128, 32, 32), (2, 333, 128, 8, 128), (1, 384, 77, 32, 5)])
+def test_folded_cross_attention_vs_f32_reference_and_unfolded_path(hip, B, Sq, Sk, heads, nvalid):
+    D = heads * 64
+    g = torch.Generator().manual_seed(Sq)
+    q = (torch.randn(B, Sq, D, generator=g) * 1.7 + 0.1).bfloat16().to(DEV)              # un-normalised projection output
+    k = torch.randn(B, Sk, D, generator=g).bfloat16().to(DEV); v = torch.randn(B, Sk, D, generator=g).bfloat16().to(DEV)
+    wq = (1 + 0.2 * torch.randn(D, generator=g)).bfloat16().to(DEV)
+    bias = torch.zeros(B, Sk); bias[:, nvalid:] = -10000.0; bias = bias.to(DEV)
+    eps, scale = 1e-5, 0.125
+    rs = hip.ops.rowsq(q.view(B * Sq, D))
+    kf = (k.float() * wq.float()).bfloat16()                                              # w_q folded into k (one rounding here; dit.hip folds in f32 inside the k-norm)
+    o_fold = hip.ops.attention_rowsq(q, kf, v, heads, scale, bias, rs, eps)
+    # the un-folded HIP path: stand-alone q-norm pass, then the same kernel
+    qn = hip.ops.qknorm_rope(q.view(B * Sq, D).clone(), wq, eps).view(B, Sq, D)
+    o_old = hip.ops.attention(qn, k, v, heads, scale, bias)
+    ref = ref_cross(q, k, v, wq, heads, scale, bias, eps)
+    e_fold, e_old = rel_l2(o_fold.float().cpu(), ref.cpu()), rel_l2(o_old.float().cpu(), ref.cpu())
+    print(f"cross attention B={B} Sq={Sq} Sk={Sk}: rel-L2 vs f32: folded {e_fold:.5f}, un-folded {e_old:.5f}")
+    assert torch.isfinite(o_fold.float()).all()
+    assert e_fold <= 5e-3 and e_fold <= 1.25 * e_old + 1e-4, (e_fold, e_old)
+
+
+@pytest.mark.parametrize("name", ["C"])
+def test_dit_forward_with_and_without_the_fold_vs_oracle(hip, golden, name):
+    """Fixture C (head_dim 64, K = 128 with 32 valid tokens: the fold's shape class) through ltx_dit_forward in bf16 with
+    LTX_Q2_FOLD=0 / default: both within the bf16 bar of the f32 oracle, and close to each other."""
+    from safetensors import safe_open
+    from conftest import GOLDEN
+    g = golden(f"oracle_dit_{name}.safetensors")
+    with safe_open(os.path.join(GOLDEN, f"oracle_dit_{name}.safetensors"), "pt") as f:
+        md = f.metadata()
+    cfgd = ast.literal_eval(md["cfg"]); Fr, H, W = ast.literal_eval(md["grid"])
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    outs = {}
+    for fold in ("0", None):
+        with env(LTX_Q2_FOLD=fold):
+            model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, torch.bfloat16)
+            model.set_skip_block_list(ast.literal_eval(md["skip_blocks"]))
+            outs[fold] = model.forward(g["hidden"].to(DEV), g["enc"].to(DEV), g["timestep"], g["mask"].to(DEV), Fr, H, W,
+                                       ast.literal_eval(md["rope_scale"]), g["coords"].to(DEV), g.get("skip_layer_mask")).float().cpu()
+    cfg = O.DitConfig(**cfgd)
+    wr = {k: v.bfloat16().float() for k, v in w.items()}
+    ref = O.dit_forward(wr, cfg, g["hidden"].bfloat16().float(), g["enc"].bfloat16().float(), g["timestep"].bfloat16().float(), g.get("mask"), Fr, H, W,
+                        ast.literal_eval(md["rope_scale"]), g.get("coords"), g.get("skip_layer_mask"), ast.literal_eval(md["skip_blocks"]))
+    e_old, e_new = rel_l2(outs["0"], ref), rel_l2(outs[None], ref)
+    print(f"dit {name} bf16 vs f32 oracle: stand-alone q-norm {e_old:.5f}, folded {e_new:.5f}; between them {rel_l2(outs[None], outs['0']):.5f}")
+    assert not torch.equal(outs[None], outs["0"])                      # the fold really ran
+    assert e_new <= 2e-2 and e_new <= 1.25 * e_old + 1e-3
