@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         constexpr int RP = BM == 256 ? 128 : 80;           // tile rows per pass: RP KiB of f32 must fit the two stages
         static_assert(RP * 1024 <= 2 * STAGE && BM % RP == 0 && RP % 16 == 0 && RP % 8 == 0, "pass geometry");
         constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
+        constexpr bool RSQ_COMPACT = RSQ && 2 * STAGE - RP * 1024 >= RP * 2 * 144;   // GemmArgs::rowsq leaves in the LDS behind a pass
         const int r0 = tid >> 5, cg = tid & 31;
         int nA = n0 + 4 * cg, nB = nA + 128;
         const bool okA = nA < g.N, okB = nB < g.N;         // N % 8 == 0: a 4-column group is inside or outside as a whole
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
             (int)(g.resid ? ((uint32_t)(rows_valid - 1) * (uint32_t)g.ldr + 256u) * 2u : 0u), 0x00020000);
         const uint32_t cA = okA ? (uint32_t)(8 * cg) : 0x80000000u, cB = okB ? (uint32_t)(8 * cg + 256) : 0x80000000u;
         const int m_last = m0 + rows_valid - 1;
+        const float fA = okA ? 1.f : 0.f, fB = okB ? 1.f : 0.f;
         bool one_batch = true;
         f32x4 gA = {}, gB = {};
         if constexpr (EPI == EPI_GATE_RESID) {
@@ -369,9 +371,15 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                         // GemmArgs::rowsq: the leaves of this thread's two 4-column groups (values as stored) go into the first
                         // dword of its OWN two 16-byte slots of the row, which it has just consumed - nobody else reads them
                         const int row = r0 + 8 * (k0 + j);
-                        float* rowf = reinterpret_cast<float*>(asm_smem + row * 1024);
-                        rowf[(cg ^ (row & 15)) << 2] = okA ? ltx_rowsq_leaf((float)pA[0], (float)pA[1], (float)pA[2], (float)pA[3]) : 0.f;
-                        rowf[((cg + 32) ^ (row & 15)) << 2] = okB ? ltx_rowsq_leaf((float)pB[0], (float)pB[1], (float)pB[2], (float)pB[3]) : 0.f;
+                        const float lA = ltx_rowsq_leaf(pA) * fA, lB = ltx_rowsq_leaf(pB) * fB;   // fA / fB: 1, or 0 for a column group beyond N (no branch)
+                        if constexpr (RSQ_COMPACT) {       // LDS left over behind the pass: 36-dword rows of 32 leaves per (row, half)
+                            float* lf = reinterpret_cast<float*>(asm_smem + RP * 1024) + (2 * row) * 36 + cg;
+                            lf[0] = lA; lf[36] = lB;
+                        } else {                           // no room (256 x 256 tile): first dword of the thread's own two consumed slots
+                            float* rowf = reinterpret_cast<float*>(asm_smem + row * 1024);
+                            rowf[(cg ^ (row & 15)) << 2] = lA;
+                            rowf[((cg + 32) ^ (row & 15)) << 2] = lB;
+                        }
                     }
                 }
             }
@@ -383,10 +391,21 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #pragma unroll 1
                 for (int pi = tid; pi < RP * 2; pi += 256) {
                     const int row = pi >> 1, half = pi & 1, sw = row & 15;
-                    const float* rowf = reinterpret_cast<const float*>(asm_smem + row * 1024);
-                    float sum = rowf[((32 * half) ^ sw) << 2];
+                    float sum;
+                    if constexpr (RSQ_COMPACT) {
+                        const f32x4* lf = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(asm_smem + RP * 1024) + pi * 36);
+                        f32x4 t[8];
 #pragma unroll
-                    for (int c2 = 1; c2 < 32; ++c2) sum += rowf[((c2 + 32 * half) ^ sw) << 2];
+                        for (int c4 = 0; c4 < 8; ++c4) t[c4] = lf[c4];
+                        sum = t[0][0]; sum += t[0][1]; sum += t[0][2]; sum += t[0][3];
+#pragma unroll
+                        for (int c4 = 1; c4 < 8; ++c4) { sum += t[c4][0]; sum += t[c4][1]; sum += t[c4][2]; sum += t[c4][3]; }
+                    } else {
+                        const float* rowf = reinterpret_cast<const float*>(asm_smem + row * 1024);
+                        sum = rowf[((32 * half) ^ sw) << 2];
+#pragma unroll
+                        for (int c2 = 1; c2 < 32; ++c2) sum += rowf[((c2 + 32 * half) ^ sw) << 2];
+                    }
                     const int trow = p * RP + row, ncol = n0 + 128 * half;
                     if (m0 + trow < g.M && ncol < g.N) g.rowsq[(int64_t)(m0 + trow) * ng + (ncol >> 7)] = sum;
                 }

@@ -41,12 +41,19 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     *reinterpret_cast<bf16x4*>(p) = x;
 }
 
-// Canonical sum of squares of one 4-column group (GemmArgs::rowsq): a fixed fma chain on the values AS STORED.  A 128-column
-// partial is the sequential sum, in ascending column order, of its 32 leaves.
-__device__ __forceinline__ float ltx_rowsq_leaf(float v0, float v1, float v2, float v3) {
-    float s = v0 * v0;
-    s = __builtin_fmaf(v1, v1, s); s = __builtin_fmaf(v2, v2, s);
-    return __builtin_fmaf(v3, v3, s);
+// Canonical sum of squares of one 4-column group (GemmArgs::rowsq) of the values AS STORED: for bf16 two v_dot2c_f32_bf16
+// (columns 0,1 then 2,3 on top), for f32 a fixed fma chain.  A 128-column partial is the sequential sum, in ascending column
+// order, of its 32 leaves.  Every producer (gemm_asm16's epilogue, rowsq_kernel) goes through these two functions.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ltx_rowsq_leaf(const bf16x4& p) {
+    const bf16x2_t lo = {p[0], p[1]}, hi = {p[2], p[3]};
+    float s = __builtin_amdgcn_fdot2_f32_bf16(lo, lo, 0.f, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(hi, hi, s, false);
+}
+__device__ __forceinline__ float ltx_rowsq_leaf(const f32x4& v) {
+    float s = v[0] * v[0];
+    s = __builtin_fmaf(v[1], v[1], s); s = __builtin_fmaf(v[2], v[2], s);
+    return __builtin_fmaf(v[3], v[3], s);
 }
 
 template <typename T, int EPI>

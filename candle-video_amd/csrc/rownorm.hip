@@ -19,6 +19,7 @@
 //   NARROW rows (<= LPR chunks, e.g. the VAE's 128..1024-channel voxels): NSLOT different rows per
 //          lane group, one chunk each.
 // Rows that do not fit NSLOT chunks per lane fall back to a re-reading variant (second read hits L2).
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "gemm_common.h"
@@ -427,8 +428,8 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const T* x, int64_t rows, in
             const int64_t row = pr / ng; const int g = (int)(pr - row * ng);
             const int n = g * 128 + 4 * cg;
             if (n < N) {                                   // N % 4 == 0: a leaf is inside or outside as a whole
-                float v[4]; load4<T>(x + row * ld + n, v);
-                leaf = ltx_rowsq_leaf(v[0], v[1], v[2], v[3]);
+                if constexpr (std::is_same<T, float>::value) leaf = ltx_rowsq_leaf(*reinterpret_cast<const f32x4*>(x + row * ld + n));
+                else leaf = ltx_rowsq_leaf(*reinterpret_cast<const bf16x4*>(x + row * ld + n));
             }
         }
         leaves[wave][2 * st + half][cg] = leaf;

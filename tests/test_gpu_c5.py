@@ -186,7 +186,7 @@ def test_c5_width_one_layer_vs_oracle():
     enc = torch.randn(1, K, 4096, generator=g)
     mask = torch.zeros(1, K); mask[:, :45] = 1
     coords = O.build_video_coords(1, F, H, W)
-    t = torch.tensor([938.0])                                   # exact in bf16: both modes see the same timestep
+    t = torch.tensor([896.0])                                   # exact in bf16 (938 is not: it rounds to 936, ltx_transformer.rs:1051): both modes see the same timestep
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     want = O.dit_forward(w, cfg, hidden, enc, t, mask, F, H, W, None, coords)
     wr = {k: v.bfloat16().float() for k, v in w.items()}
