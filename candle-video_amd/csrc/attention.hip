@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
         float ss = 0.f;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) { ss += rs[g4][0]; ss += rs[g4][1]; ss += rs[g4][2]; ss += rs[g4][3]; }
-        return c * (1.0f / sqrtf(ss * rs_invD + a.q_rowsq_eps));
+        return c * __builtin_amdgcn_rsqf(ss * rs_invD + a.q_rowsq_eps);     // one v_rsq (1 ulp): this is the bf16 path
     };
     f32x16 zero16;
 #pragma unroll

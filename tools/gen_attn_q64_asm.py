@@ -194,6 +194,10 @@ def gen(QB, opt=None, full=False, part=False):
             emit("s_add_u32 %[koff], %[koff], %[kstep]")
             emit("s_add_u32 %[voff], %[voff], %[vstep]")
         if int(o_["stamp"]): emit("s_memtime %[sa1]")
+        # O^T and the row sums are zeroed HERE, under the flight of the loads (round 4; they used to sit behind the S^T(0) MFMAs,
+        # on the exposed path of every block): 72 independent writes, no result changes
+        for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
+        for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
         emit("s_waitcnt vmcnt(8)")                           # Q^T and tiles 0, 1 landed; tiles 2, 3 stay in flight
         if int(o_["stamp"]): emit("s_memtime %[sa2]")
         emit("s_barrier")
@@ -208,8 +212,6 @@ def gen(QB, opt=None, full=False, part=False):
                 emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {'0' if ks == 0 else d}")
         for i in range(8):                                   # K(1) fragments (the MFMAs above have read theirs long before these land)
             emit(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + (i & 3)} offset:{TILE + (i >> 2) * 32 * KROW}")
-        for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
-        for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
         for qb in range(QB):                                 # row maxima: 32 scores in the lane, then the other lane half
             s0 = S(0, qb, 0); m = 200 + qb
             emit(f"v_max3_f32 v{m}, v{s0}, v{s0 + 1}, v{s0 + 2}")
