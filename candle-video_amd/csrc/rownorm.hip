@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
 // segment are issued before the first reduction (memory-level parallelism; the slow kernel read the tables twice and
 // serialised the segments).
 template <typename T, int NS>
-__global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRopeArgs a, int lpr) {
+__global__ __launch_bounds__(256, 5) void qknorm_rope_fused_kernel(const QkNormRopeArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     static_assert(CH == 8, "bf16 rows only");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -339,26 +339,36 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
         if (in && a.nseg == 2) v[1][i].u = *reinterpret_cast<const u32x4*>(x0 + sst + c * CH);
         if (in && rope) { co[i] = *reinterpret_cast<const f32x4*>(cs + c * 4); si[i] = *reinterpret_cast<const f32x4*>(sn + c * 4); }
     }
+    // both row statistics first, then chunk-major: chunk i of q and of k are finished together with ONE copy of its cos / sin
+    // in registers, which then die (seg-major order kept all four table chunks and both rows alive: 118 VGPRs = 4 waves per SIMD
+    // = 4096 wave slots for the DiT's 4992 row-waves, i.e. a second, mostly empty round; chunk-major fits 5 per SIMD)
+    float rinv[2] = {0.f, 0.f};
 #pragma unroll
     for (int seg = 0; seg < 2; ++seg) {
         if (seg >= a.nseg) break;
-        const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NS; ++i) { float f[CH]; chunk_to_f32<T>(v[seg][i], f);
 #pragma unroll
             for (int j = 0; j < CH; ++j) ss += f[j] * f[j]; }
         ss = group_sum(ss, lpr);
-        const float rinv = (seg == 0 ? a.out_scale0 : 1.0f) / sqrtf(ss / (float)a.D + a.eps);
+        rinv[seg] = (seg == 0 ? a.out_scale0 : 1.0f) / sqrtf(ss / (float)a.D + a.eps);
+    }
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int c = sub + i * lpr;
-            if (c >= nch) continue;
+    for (int i = 0; i < NS; ++i) {
+        const int c = sub + i * lpr;
+        if (c >= nch) continue;
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            if (seg >= a.nseg) break;
+            const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+            // (opaque copy: without it the f32 expansion of all eight chunks made for the row statistics is kept alive - 64 registers)
+            asm volatile("" : "+v"(v[seg][i].u));
             float f[CH]; chunk_to_f32<T>(v[seg][i], f);
             Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
             float wv[CH]; chunk_to_f32<T>(wc, wv);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) f[j] = f[j] * rinv * wv[j];
+            for (int j = 0; j < CH; ++j) f[j] = f[j] * rinv[seg] * wv[j];
             if (seg == 0 && a.w0b) {                       // a consumer's weight folded in (QkNormRopeArgs::w0b)
                 Chunk16 wc2; wc2.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.w0b) + c * CH);
                 float wv2[CH]; chunk_to_f32<T>(wc2, wv2);
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fused_kernel(const QkNormRope
             }
             Chunk16 o; f32_to_chunk<T>(f, o);
             if (active) *reinterpret_cast<u32x4*>(x0 + seg * sst + c * CH) = o.u;
+            __builtin_amdgcn_sched_barrier(0);             // one (chunk, segment) at a time: the scheduler's interleave of all eight costs 30 registers
         }
     }
 }
