@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""What bounds the DiT's row norm pass ([4992, 2048] bf16, 41 MB): the pass with and without its modulation operands, against a
+plain device copy of the same bytes and a pure elementwise map (torch), back to back in one process."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "candle-video_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch, ltxhip
+from microbench import timeit
+S, D = 4992, 2048
+x = torch.randn(S, D, device="cuda").bfloat16(); y = torch.empty_like(x)
+sc = torch.randn(1, D, device="cuda"); sh = torch.randn(1, D, device="cuda")
+res = {}
+def t(name, fn):
+    res[name] = round(min(timeit(fn, iters=200, warm=10) for _ in range(3)) * 1e3, 2)
+t("rownorm_mod_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0))
+t("rownorm_plain_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, None, None, S, 0))
+t("copy_us", lambda: y.copy_(x))
+t("map_mul_us", lambda: torch.mul(x, 1.5, out=y))
+w = torch.randn(D, device="cuda").bfloat16()
+t("qknorm_noRope_us", lambda: ltxhip.ops.qknorm_rope(x, w, 1e-5))
+print(json.dumps(res))

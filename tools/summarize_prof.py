@@ -84,6 +84,20 @@ def main():
     summary = {"window": "last video period of the run" if ok else "whole run (no video delimiter found)", "kernel_busy_ms": tot / 1e6, "wall_span_ms": span / 1e6,
                "launches": len(win),
                "classes": {k: {"ms_per_video": v[0] / 1e6, "launches_per_video": v[1], "avg_us": v[0] / 1e3 / max(v[1], 1)} for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}}
+    # the VAE decode launch by launch (conv class, launch order): duration, workgroups, rounds of the 256 CUs at one block per CU
+    dec = []
+    for r in win:
+        if classify(r["Kernel_Name"]) != "conv3d implicit GEMM":
+            continue
+        wg = None
+        try:
+            gx, wx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)))
+            wg = gx // wx if wx else None
+        except (TypeError, ValueError):
+            pass
+        dec.append({"kernel": short(r["Kernel_Name"])[:60], "us": round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1),
+                    "workgroups": wg, "rounds_of_256": round(wg / 256.0, 2) if wg else None})
+    summary["decode_launches"] = dec
     for name, d in pmc.items():
         fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not fs:
@@ -131,6 +145,10 @@ def main():
           f"kernel busy time {tot/1e6:.1f} ms over a wall span of {span/1e6:.1f} ms, {len(win)} launches\n\n" + "\n".join(lines) +
           "\n\n## by class (per video)\n\n" +
           "\n".join(f"- {k}: {v['ms_per_video']:.2f} ms, {v['launches_per_video']} launches, avg {v['avg_us']:.1f} us" for k, v in summary["classes"].items()) + "\n")
+    if summary.get("decode_launches"):
+        md += "\n## VAE decode, launch by launch (conv class)\n\n| # | kernel | us | workgroups | rounds of 256 CUs |\n|---|---|---|---|---|\n"
+        for i, r in enumerate(summary["decode_launches"]):
+            md += f"| {i} | `{r['kernel']}` | {r['us']} | {r['workgroups']} | {r['rounds_of_256']} |\n"
     if "pmc" in summary:
         md += "\n## PMC (raw counter value x 1024 B, per launch; FETCH_SIZE must be doubled on gfx950)\n\n"
         for name, d in summary["pmc"].items():
