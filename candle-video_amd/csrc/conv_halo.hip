@@ -25,6 +25,9 @@
 #ifndef HALO_LOADERS
 #define HALO_LOADERS 4
 #endif
+#ifndef HALO_PABL         // timing ablations of the PIPELINED form (wrong results; tools/conv_variants.py): 1 = no barrier, 2 = no LDS-DMA in the loop,
+#define HALO_PABL 0       // 4 = fragments read once (no LDS reads in the loop), 8 = no vmcnt wait at the step barrier
+#endif
 #ifndef HALO_ABL          // timing ablations (wrong results; tools/conv_variants.py): 1 = one A fragment read per k half, 2 = one W fragment read, 4 = no LDS-DMA in the loop
 #define HALO_ABL 0
 #endif
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);
             const uint32_t soff = (uint32_t)(tt - tt0) * frame_bytes + (uint32_t)kc * 128u;
             const bool live = grp < G && piece < A_PIECES;
+            if ((HALO_PABL & 2) && grp > 0) return;
             dma(ra, live ? a_voff[j] : OOB, live ? soff : 0u, Abuf + (grp & 1) * A_ST + piece * 1024);
         };
         auto issue_b_p = [&](int grp, int hw) {               // weight tile of step (grp, hw) into ring slot hw % 3 (9 steps per group)
@@ -168,11 +172,22 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             const int it = grp / KC, kc = grp - it * KC;
             const bool live = grp < G;
             const uint32_t soff = live ? ((uint32_t)(it * 9 + hw) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u : 0u;
+            if ((HALO_PABL & 2) && (grp > 0 || hw > 1)) return;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) dma(rw, live ? b_voff[j] : OOB, soff, Bbuf + (hw % 3) * B_STAGE + (j * NL + lwave) * 1024);
         };
         Chunk16 w0[FN], a0[FM], w1[FN], a1[FM];
+        bool frags_once = false;
         auto read_frags = [&](int grp, int hw, int kb, Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
+            if (HALO_PABL & 4) {                               // timing ablation: the registers keep their first contents (made opaque)
+                if (frags_once) {
+#pragma unroll
+                    for (int f = 0; f < FN; ++f) asm volatile("" : "+v"(wf[f].u));
+#pragma unroll
+                    for (int f = 0; f < FM; ++f) asm volatile("" : "+v"(af[f].u));
+                    return;
+                }
+            }
             const int ih = hw / 3, iw = hw % 3;
             const unsigned char* As = Abuf + (grp & 1) * A_ST;
             const unsigned char* Bs = Bbuf + (hw % 3) * B_STAGE;
@@ -200,6 +215,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         read_frags(0, 0, 0, w0, a0);
+        if (HALO_PABL & 4) { read_frags(0, 0, 1, w1, a1); frags_once = true; }
         auto step_p = [&](int grp, auto hw_tag) {
             constexpr int hw = decltype(hw_tag)::value;
             constexpr int RPS = (AJ + 5) / 6;                 // halo piece rounds per step, over the first six steps of a group
@@ -212,6 +228,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             interleave();
             // everything issued before this step has landed (tile of step + 1, halo rounds); a raw barrier: __syncthreads() would
             // add a fence, i.e. vmcnt(0), and wait for the tile of step + 2 as well
+            if ((HALO_PABL & 9) == 9 || (HALO_PABL & 3) == 3) {}                                     // neither wait nor barrier
+            else if (HALO_PABL & 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BJ + na) : "memory");
+            else if (HALO_PABL & (8 | 2)) asm volatile("s_barrier" ::: "memory");
+            else
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BJ + na) : "memory");
             if (hw + 1 < 9) read_frags(grp, hw + 1, 0, w0, a0); else read_frags(grp + 1, 0, 0, w0, a0);
             mma_all(w1, a1);

@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "measure":
     print(json.dumps(res), flush=True)
 else:
     for lib in sorted(f for f in os.listdir(VAR) if f.startswith("libltxhip_halo")):
-        shutil.copyfile(os.path.join(VAR, lib), os.path.join(PKG, "libltxhip.so"))
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "measure"], capture_output=True, text=True)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "measure"], capture_output=True, text=True,
+                           env=dict(os.environ, LTXHIP_LIB=os.path.join(VAR, lib), LTX_GEMM_TUNE="0", LTX_CONV_HALO="128"))
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         print(lib, line[-1] if line else ("FAILED " + p.stderr[-300:]), flush=True)
