@@ -211,7 +211,15 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     // rms_norm(q) . k = r_row * (q . (k * w_q)) - the q2 projection's epilogue leaves per-row partial sums of squares
     // (GemmArgs::rowsq), w_q = attn2.norm_q.weight rides on the cached k, and the stand-alone pass over q (read + write of
     // [M, D] per layer) disappears.  ltx_transformer.rs:671-678, 719-740.
-    const bool fold_q2 = dt == LTX_DT_BF16 && ltx_attention_rowsq_ok(hd, K, D);
+    // Only where the projection can emit the partials from its own epilogue (a shape-only test: gemm_asm16's fit): behind any
+    // other kernel they cost a stand-alone pass, which at small M (C1: 384 tokens) is dearer than the q-norm pass it replaces.
+    bool fold_q2 = dt == LTX_DT_BF16 && ltx_attention_rowsq_ok(hd, K, D);
+    if (fold_q2) {
+        GemmArgs gq; gq.A = m->h.p; gq.W = m->blocks[0].q2.w; gq.C = m->qkv.p; gq.bias = m->blocks[0].q2.b;
+        gq.M = (int)M; gq.N = m->blocks[0].q2.out; gq.K = m->blocks[0].q2.in; gq.lda = D; gq.ldc = D;
+        const char* force = getenv("LTX_Q2_FOLD");           // "2": fold whatever the shape (tests of the stand-alone partials)
+        fold_q2 = ltx_gemm_asm16_fits(gq, EPI_BIAS) || (force && force[0] == '2');
+    }
     if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
     if (skip_layer_mask) LTX_TRY(m->orig.ensure(M * D * esz));
 

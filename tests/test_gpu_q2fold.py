@@ -129,7 +129,7 @@ def test_dit_forward_with_and_without_the_fold_vs_oracle(hip):
     wr = {k: v.bfloat16().float() for k, v in w.items()}
     ref = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords)
     outs = {}
-    for tag, fold, dt in (("off", "0", torch.bfloat16), ("on", None, torch.bfloat16), ("f32", None, torch.float32)):
+    for tag, fold, dt in (("off", "0", torch.bfloat16), ("on", "2", torch.bfloat16), ("f32", None, torch.float32)):   # "2": fold whatever M (the default folds from M = 512 up)
         with env(LTX_Q2_FOLD=fold):
             model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, dt)
             outs[tag] = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV)).float().cpu()
