@@ -39,6 +39,9 @@ constexpr int PH = 16, PW = 16, HW = PW + 2, HROWS = (PH + 2) * HW;      // 18 x
 constexpr int A_PIECES = (HROWS + 7) / 8;                                  // 41 pieces of 8 rows (1 KiB)
 constexpr int A_STAGE = A_PIECES * 1024;
 constexpr uint32_t OOB = 0x80000000u;
+template <int I, int N, typename F> __device__ __forceinline__ void sfor_h(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor_h<I + 1, N>(f); }
+}
 
 __device__ __forceinline__ int swz_h(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -49,10 +52,17 @@ extern __shared__ __attribute__((aligned(16))) unsigned char halo_smem[];
 // two waves per SIMD both wait at the same barrier, then both wait for their first fragments); the weight tiles run three
 // deep (tile of step s + 2 issued in step s, counted vmcnt at the barrier of step s covers tile s + 1).  LDS-DMA counts per
 // step are made static: out-of-range dummy pieces (zeros into padding / free buffers) where the plain form issues nothing.
+// ONE WAVE PER SIMD (WGM x WGN = 4 waves, round 4): the pipelined form with per-wave tiles of 128 x 64 - a fragment serves twice
+// the MFMAs (12 reads per 32 instead of 8 per 16), the accumulators move to the AGPR half of the 512-register file, and the
+// step's LDS-DMA pieces are issued one at a time BETWEEN chunks of MFMAs (pinned with sched_barrier) instead of back to back
+// at the top of the step: the timing ablations of the two-waves-per-SIMD form (HALO_PABL, tools/conv_variants.py) put 13 %
+// of it on the DMA issue and 14 % on the fragment reads, and the one-wave-per-SIMD GEMM (gemm_asm.hip) showed that a burst
+// of pieces stalls the only instruction stream of a SIMD while the same pieces spread over the step cost almost nothing.
 template <int BN, int WGM, int WGN, int EPI, bool PIPE>
-__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArgs g) {
     constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
-    static_assert(NW == 8 && WM % 16 == 0 && WN % 16 == 0, "wave layout");
+    static_assert((NW == 8 || (NW == 4 && PIPE)) && WM % 16 == 0 && WN % 16 == 0, "wave layout");
+    constexpr int NTHR = NW * 64;
     // loader waves: the first wave of every SIMD issues all LDS-DMA pieces, its partner (wave + 4) starts on its MFMAs at
     // once (see gemm_big.hip)
     constexpr int NL = (HALO_LOADERS == 4 && BN == 128) ? 4 : NW;      // measured: +3..9 % at BN = 128, -4 % at BN = 256
@@ -220,12 +230,39 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             constexpr int hw = decltype(hw_tag)::value;
             constexpr int RPS = (AJ + 5) / 6;                 // halo piece rounds per step, over the first six steps of a group
             constexpr int na = (hw + 1) * RPS <= AJ ? RPS : (hw * RPS < AJ ? AJ - hw * RPS : 0);
+            if constexpr (NW == 4) {
+                // one wave per SIMD: fragment reads of the second half first (they are waited for at its first MFMA), then the
+                // first half's MFMAs in BJ + na chunks with ONE LDS-DMA piece in front of each chunk
+                read_frags(grp, hw, 1, w1, a1);
+                constexpr int NP = BJ + na, NM = FM * FN;
+                auto piece_p = [&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    if constexpr (i < BJ) {
+                        const int g2 = hw + 2 < 9 ? grp : grp + 1, h2 = hw + 2 < 9 ? hw + 2 : hw + 2 - 9;
+                        const int it = g2 / KC, kc = g2 - it * KC;
+                        const bool live = g2 < G;
+                        const uint32_t soff = live ? ((uint32_t)(it * 9 + h2) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u : 0u;
+                        if (!((HALO_PABL & 2) && (g2 > 0 || h2 > 1))) dma(rw, live ? b_voff[i] : OOB, soff, Bbuf + (h2 % 3) * B_STAGE + (i * NL + lwave) * 1024);
+                    } else issue_a_p(grp + 1, hw * RPS + (i - BJ));
+                };
+                sfor_h<0, NP>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    constexpr int lo = i * NM / NP, hi = (i + 1) * NM / NP;
+                    piece_p(i_tag);
+                    sfor_h<lo, hi>([&](auto m_tag) {
+                        constexpr int mi = decltype(m_tag)::value, fm = mi / FN, fn = mi % FN;
+                        acc[fm][fn] = Mma<bf16_t>::run(w0[fn], a0[fm], acc[fm][fn]);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
             if (hw + 2 < 9) issue_b_p(grp, hw + 2); else issue_b_p(grp + 1, hw + 2 - 9);
 #pragma unroll
             for (int rr = 0; rr < na; ++rr) issue_a_p(grp + 1, hw * RPS + rr);
             read_frags(grp, hw, 1, w1, a1);                   // second k half of this step: its tiles are long visible
             mma_all(w0, a0);
             interleave();
+            }
             // everything issued before this step has landed (tile of step + 1, halo rounds); a raw barrier: __syncthreads() would
             // add a fence, i.e. vmcnt(0), and wait for the tile of step + 2 as well
             if ((HALO_PABL & 9) == 9 || (HALO_PABL & 3) == 3) {}                                     // neither wait nor barrier
@@ -358,7 +395,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             }
             __syncthreads();
             bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
-            // a thread's chunk column is the same in every iteration (512 % CPR == 0): its modulation values load once
+            // a thread's chunk column is the same in every iteration (NTHR % CPR == 0): its modulation values load once
             float pn_sc[8], pn_sh[8];
             bool pn_mod = false;
             if constexpr (EPI == EPI_BIAS) {
@@ -372,7 +409,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                     for (int j = 0; j < 4; ++j) { pn_sc[j] = 1.0f + s0[j]; pn_sc[4 + j] = 1.0f + s1[j]; pn_sh[j] = h0[j]; pn_sh[4 + j] = h1[j]; }
                 }
             }
-            for (int id = tid; id < BM * CPR; id += 512) {
+            for (int id = tid; id < BM * CPR; id += NTHR) {
                 const int row = id / CPR, c = id - row * CPR;
                 bool inside; const int m = row_m(row, inside);
                 Chunk16 cc; cc.u = *reinterpret_cast<const u32x4*>(halo_smem + row * (CPR * 16) + ((c ^ (row & XM)) << 4));
@@ -427,7 +464,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
                   (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.H * g.Wd * g.ldr * 2.0 < 2147483648.0));
     if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
-    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(512), smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(WGM * WGN * 64), smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
@@ -461,6 +498,8 @@ int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
 #if HALO_LOADERS == 4
     const char* pe = getenv("LTX_CONV_HALO_PIPE");          // "0": the barrier-per-step form (A/B)
+    const char* w4 = getenv("LTX_CONV_HALO_W4");            // "1": one wave per SIMD (four waves of 128 x 64), round 4 experiment
+    if (w4 && w4[0] == '1' && !(pe && pe[0] == '0')) return launch_halo_epi<128, 2, 2, true>(g, epi, s);
     if (!(pe && pe[0] == '0')) return launch_halo_epi<128, 4, 2, true>(g, epi, s);
 #endif
     return launch_halo_epi<128, 4, 2>(g, epi, s);
