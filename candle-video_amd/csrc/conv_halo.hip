@@ -230,39 +230,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             constexpr int hw = decltype(hw_tag)::value;
             constexpr int RPS = (AJ + 5) / 6;                 // halo piece rounds per step, over the first six steps of a group
             constexpr int na = (hw + 1) * RPS <= AJ ? RPS : (hw * RPS < AJ ? AJ - hw * RPS : 0);
-            if constexpr (NW == 4) {
-                // one wave per SIMD: fragment reads of the second half first (they are waited for at its first MFMA), then the
-                // first half's MFMAs in BJ + na chunks with ONE LDS-DMA piece in front of each chunk
-                read_frags(grp, hw, 1, w1, a1);
-                constexpr int NP = BJ + na, NM = FM * FN;
-                auto piece_p = [&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value;
-                    if constexpr (i < BJ) {
-                        const int g2 = hw + 2 < 9 ? grp : grp + 1, h2 = hw + 2 < 9 ? hw + 2 : hw + 2 - 9;
-                        const int it = g2 / KC, kc = g2 - it * KC;
-                        const bool live = g2 < G;
-                        const uint32_t soff = live ? ((uint32_t)(it * 9 + h2) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc * 64u) * 2u : 0u;
-                        if (!((HALO_PABL & 2) && (g2 > 0 || h2 > 1))) dma(rw, live ? b_voff[i] : OOB, soff, Bbuf + (h2 % 3) * B_STAGE + (i * NL + lwave) * 1024);
-                    } else issue_a_p(grp + 1, hw * RPS + (i - BJ));
-                };
-                sfor_h<0, NP>([&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value;
-                    constexpr int lo = i * NM / NP, hi = (i + 1) * NM / NP;
-                    piece_p(i_tag);
-                    sfor_h<lo, hi>([&](auto m_tag) {
-                        constexpr int mi = decltype(m_tag)::value, fm = mi / FN, fn = mi % FN;
-                        acc[fm][fn] = Mma<bf16_t>::run(w0[fn], a0[fm], acc[fm][fn]);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            } else {
             if (hw + 2 < 9) issue_b_p(grp, hw + 2); else issue_b_p(grp + 1, hw + 2 - 9);
 #pragma unroll
             for (int rr = 0; rr < na; ++rr) issue_a_p(grp + 1, hw * RPS + rr);
             read_frags(grp, hw, 1, w1, a1);                   // second k half of this step: its tiles are long visible
             mma_all(w0, a0);
             interleave();
-            }
             // everything issued before this step has landed (tile of step + 1, halo rounds); a raw barrier: __syncthreads() would
             // add a fence, i.e. vmcnt(0), and wait for the tile of step + 2 as well
             if ((HALO_PABL & 9) == 9 || (HALO_PABL & 3) == 3) {}                                     // neither wait nor barrier
@@ -274,6 +247,83 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             mma_all(w1, a1);
             interleave();
         };
+        if constexpr (NW == 4) {
+            // ---- one wave per SIMD.  (1) MFMAs as inline asm with the accumulator tied in place in the AGPR file: left to itself
+            // hipcc renames the 128 accumulator registers from MFMA to MFMA and pays ~190 v_accvgpr_mov per group to put them back.
+            // (2) The scalars of a step's DMA pieces (weight tile of step + 2, halo image of the next group) are carried from group
+            // to group instead of being derived from the group number by a division in front of every piece.  (3) The pieces sit
+            // between chunks of MFMAs, one per chunk.
+            auto mfma = [&](f32x4& c, const Chunk16& w, const Chunk16& a_) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w.u), "v"(a_.u));
+            };
+            const uint32_t nk2 = (uint32_t)g.N * (uint32_t)g.K * 2u;
+            auto a_soff_of = [&](int it, int kc) {
+                int tt = t + it - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);
+                return (uint32_t)(tt - tt0) * frame_bytes + (uint32_t)kc * 128u;
+            };
+            int it_n = KC > 1 ? 0 : 1, kc_n = KC > 1 ? 1 : 0;       // (frame tap, slice) of group grp + 1
+            uint32_t w_cur = 0u;                                      // weight offset of (grp, tap 0)
+            for (int grp = 0; grp < G; ++grp) {
+                const bool live_n = grp + 1 < G;
+                const uint32_t a_next = live_n ? a_soff_of(it_n, kc_n) : 0u;
+                const uint32_t w_next = live_n ? ((uint32_t)(it_n * 9) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc_n * 64u) * 2u : 0u;
+                unsigned char* const a_dst = Abuf + ((grp + 1) & 1) * A_ST;
+                sfor_h<0, 9>([&](auto hw_tag) {
+                    constexpr int hw = decltype(hw_tag)::value;
+                    constexpr int RPS = (AJ + 5) / 6;
+                    constexpr int na = (hw + 1) * RPS <= AJ ? RPS : (hw * RPS < AJ ? AJ - hw * RPS : 0);
+                    constexpr int NP = BJ + na, NM = FM * FN;
+                    constexpr int h2 = hw + 2 < 9 ? hw + 2 : hw + 2 - 9;
+                    const bool w_live = hw + 2 < 9 ? true : live_n;
+                    const uint32_t w_soff = (hw + 2 < 9 ? w_cur : w_next) + (uint32_t)h2 * nk2;
+                    // one fragment read (of the NEXT half) in front of every second MFMA, the step's NP DMA pieces spread over the
+                    // first half; everything in program order, pinned by sched_barrier
+                    auto read_one = [&](int rg, int rh, int kb, auto idx_tag, Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
+                        constexpr int idx = decltype(idx_tag)::value;
+                        if (HALO_PABL & 4) return;
+                        const int ih = rh / 3, iw = rh % 3;
+                        if constexpr (idx < FN) wf[idx].u = *reinterpret_cast<const u32x4*>(Bbuf + (rh % 3) * B_STAGE + swz_h(wn * WN + idx * 16 + frow, kb * 4 + fq));
+                        else af[idx - FN].u = *reinterpret_cast<const u32x4*>(Abuf + (rg & 1) * A_ST + rowbase[idx - FN] + colpart[iw][kb] + ih * HW * ROWB);
+                    };
+                    auto piece = [&](auto i_tag) {
+                        constexpr int i = decltype(i_tag)::value;
+                        if constexpr (i < BJ) {
+                            if (!((HALO_PABL & 2) && (grp > 0 || hw > 1)))
+                                dma(rw, w_live ? b_voff[i] : OOB, w_live ? w_soff : 0u, Bbuf + (h2 % 3) * B_STAGE + (i * NL + lwave) * 1024);
+                        } else {
+                            constexpr int j = hw * RPS + (i - BJ);
+                            const bool live = live_n && j * NL + lwave < A_PIECES;
+                            if (!(HALO_PABL & 2)) dma(ra, live ? a_voff[j] : OOB, live ? a_next : 0u, a_dst + (j * NL + lwave) * 1024);
+                        }
+                    };
+                    sfor_h<0, NM>([&](auto m_tag) {                 // first k half on (w0, a0); reads of this step's second half into (w1, a1)
+                        constexpr int mi = decltype(m_tag)::value;
+                        if constexpr (mi % 2 == 0 && mi / 2 < FN + FM) read_one(grp, hw, 1, std::integral_constant<int, mi / 2>{}, w1, a1);
+                        if constexpr (mi % 2 == 1 && (mi / 2) % (16 / NP > 0 ? 16 / NP : 1) == 0 && (mi / 2) / (16 / NP > 0 ? 16 / NP : 1) < NP)
+                            piece(std::integral_constant<int, (mi / 2) / (16 / NP > 0 ? 16 / NP : 1)>{});
+                        mfma(acc[mi / FN][mi % FN], w0[mi % FN], a0[mi / FN]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if ((HALO_PABL & 9) == 9 || (HALO_PABL & 3) == 3) {}
+                    else if (HALO_PABL & 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BJ + na) : "memory");
+                    else if (HALO_PABL & (8 | 2)) asm volatile("s_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BJ + na) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    sfor_h<0, NM>([&](auto m_tag) {                 // second k half on (w1, a1); reads of the next step's first half into (w0, a0)
+                        constexpr int mi = decltype(m_tag)::value;
+                        if constexpr (mi % 2 == 0 && mi / 2 < FN + FM) {
+                            if (hw + 1 < 9) read_one(grp, hw + 1, 0, std::integral_constant<int, mi / 2>{}, w0, a0);
+                            else read_one(grp + 1, 0, 0, std::integral_constant<int, mi / 2>{}, w0, a0);
+                        }
+                        mfma(acc[mi / FN][mi % FN], w1[mi % FN], a1[mi / FN]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+                w_cur = w_next;
+                if (++kc_n == KC) { kc_n = 0; ++it_n; }
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results before the epilogue reads the accumulators
+        } else
         for (int grp = 0; grp < G; ++grp) {
             step_p(grp, std::integral_constant<int, 0>{}); step_p(grp, std::integral_constant<int, 1>{}); step_p(grp, std::integral_constant<int, 2>{});
             step_p(grp, std::integral_constant<int, 3>{}); step_p(grp, std::integral_constant<int, 4>{}); step_p(grp, std::integral_constant<int, 5>{});
