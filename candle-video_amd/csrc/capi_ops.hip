@@ -15,10 +15,15 @@ extern "C" int ltx_op_linear(const void* x, const void* w, const void* bias, voi
     return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
 }
 
-extern "C" int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, ltx_stream stream) {
+extern "C" int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, int epi,
+                                   const void* resid, const float* gate, int rows_per_batch, ltx_stream stream) {
     if (!x || !w || !y || !rowsq) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: null tensor");
-    GemmArgs g; g.A = x; g.W = w; g.C = y; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.rowsq = rowsq;
-    return ltx_launch_gemm(g, dtc(dtype), EPI_BIAS, (hipStream_t)stream);
+    if (epi != 0 && epi != 2 && epi != 3) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: epi must be 0, 2 or 3");
+    if (epi >= 2 && !resid) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: residual epilogue needs resid");
+    if (epi == 2 && (!gate || rows_per_batch < 1)) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: gated epilogue needs gate");
+    GemmArgs g; g.A = x; g.W = w; g.C = y; g.bias = bias; g.resid = resid; g.gate = gate; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
+    g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.gate_stride = N; g.rowsq = rowsq;
+    return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
 }
 extern "C" int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int dtype, ltx_stream stream) {
     return ltx_launch_rowsq(x, dtc(dtype), rows, N, ld, rowsq, (hipStream_t)stream);
@@ -40,6 +45,16 @@ extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int k
     if (!x || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_rownorm: null tensor");
     RowNormArgs a; a.x = x; a.y = y; a.rows = rows; a.D = D; a.ldx = D; a.ldy = D; a.kind = kind; a.eps = eps; a.weight = weight;
     a.scale = scale; a.shift = shift; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; a.mod_stride = mod_stride; a.act = act;
+    return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
+}
+
+extern "C" int ltx_op_rownorm_presum(const void* x, void* y, int64_t rows, int D, float eps, const void* weight,
+                                     const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
+                                     const float* presum, int presum_n, int dtype, ltx_stream stream) {
+    if (!x || !y || !presum) LTX_FAIL(LTX_ERR_ARG, "ltx_op_rownorm_presum: null tensor");
+    RowNormArgs a; a.x = x; a.y = y; a.rows = rows; a.D = D; a.ldx = D; a.ldy = D; a.kind = 0; a.eps = eps; a.weight = weight;
+    a.scale = scale; a.shift = shift; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; a.mod_stride = mod_stride; a.act = act;
+    a.presum = presum; a.presum_n = presum_n;
     return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
 }
 

@@ -35,11 +35,11 @@ struct ltx_dit {
     bool ctx_mode = false;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
-    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq;
+    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq, hsq;
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq};
+        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq, &hsq};
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); }
         ctxs.clear();
@@ -221,6 +221,20 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         fold_q2 = ltx_gemm_asm16_fits(gq, EPI_BIAS) || (force && force[0] == '2');
     }
     if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
+    // The two RMS norms of a block take their rows' sums of squares from the epilogue of the GEMM that wrote h (ff2 of the block
+    // before, attn2.to_out of this block: GemmArgs::rowsq) and run as a pure elementwise map; same shape-only condition as the
+    // fold above (the partials must come from gemm_asm16's epilogue).  LTX_NORM_PRESUM=0: the one-row-per-wave pass (A/B aid).
+    bool presum = dt == LTX_DT_BF16 && D % 512 == 0;
+    if (presum) {
+        const char* pe = getenv("LTX_NORM_PRESUM");
+        GemmArgs gp; gp.A = m->attn.p; gp.W = m->blocks[0].o2.w; gp.C = m->h.p; gp.bias = m->blocks[0].o2.b; gp.resid = m->h.p;
+        gp.M = (int)M; gp.N = m->blocks[0].o2.out; gp.K = m->blocks[0].o2.in; gp.lda = D; gp.ldc = D; gp.ldr = D;
+        GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D;
+        gf.gate = m->ada.as<float>(); gf.gate_stride = 6 * D; gf.rows_per_batch = S;
+        presum = !(pe && pe[0] == '0') && ((ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || (pe && pe[0] == '2'));   // "2": whatever the shape (tests)
+    }
+    if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
+    bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h
     if (skip_layer_mask) LTX_TRY(m->orig.ensure(M * D * esz));
 
     // inputs -> model dtype (:1045-1047)
@@ -301,6 +315,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         // norm1 + AdaLN (shift_msa = row 0, scale_msa = row 1)
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
+        if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         // self attention
         // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
@@ -329,6 +344,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         LTX_TRY(ltx_launch_attention(at, dt, s));
         // h = h + gate_msa * to_out(attn)     (gate_msa = row 2)
         LTX_TRY(ltx_linear(b.o1, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 2 * D, 6 * D, S));
+        hsq_valid = false;
         // cross attention (no pre-norm, no RoPE, q/k RMSNorm, additive key bias)
         const char* kvl = (const char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
         AttnArgs ax; ax.q = m->qkv.p; ax.k = kvl; ax.v = kvl + (size_t)D * esz; ax.o = m->attn.p;
@@ -345,13 +361,17 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
         }
         LTX_TRY(ltx_launch_attention(ax, dt, s));
-        LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D));
+        LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D, nullptr, 0, 1, presum ? m->hsq.as<float>() : nullptr));
+        hsq_valid = presum;
         // MLP (shift_mlp = row 3, scale_mlp = row 4, gate_mlp = row 5)
         rn.shift = ada + 3 * D; rn.scale = ada + 4 * D;
+        rn.presum = nullptr; rn.presum_n = 0;
+        if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         LTX_TRY(ltx_linear(b.ff1, m->n.p, D, m->ff.p, 4 * D, (int)M, dt, EPI_GELU, s));
-        LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S));
-        if (skip_layer_mask && any) LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s));
+        LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S, presum ? m->hsq.as<float>() : nullptr));
+        hsq_valid = presum;
+        if (skip_layer_mask && any) { LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s)); hsq_valid = false; }
     }
 
     // final LayerNorm (no affine) + modulation (:1126-1161), proj_out (:1163)

@@ -436,7 +436,7 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
     void (*kern)(const GemmArgs);
     if constexpr (MF16) kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI>; else kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
     bool wrote_rowsq = false;
-    if constexpr (MF16 && EPI == EPI_BIAS) {                // GemmArgs::rowsq as a by-product of the wide epilogue
+    if constexpr (MF16 && (EPI == EPI_BIAS || EPI == EPI_GATE_RESID || EPI == EPI_RESID)) {   // GemmArgs::rowsq as a by-product of the wide epilogue
         if (g.rowsq) { kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, true>; wrote_rowsq = true; }
     }
     LTX_TRY(ltx_set_max_dyn_smem(wrote_rowsq ? attr_devs_rsq : attr_devs, reinterpret_cast<const void*>(kern), smem));

@@ -102,6 +102,9 @@ struct RowNormArgs {
     const float* shift = nullptr;
     int64_t rows_per_batch = 1; int mod_stride = 0;
     int act = 0;                  // 0 none, 1 SiLU
+    // RMS rows whose sum of squares is already known (GemmArgs::rowsq of the GEMM that produced x): presum[row * presum_n + g],
+    // summed in ascending g.  The pass is then a pure elementwise map - no wave waits for a row (rownorm_presum_kernel).
+    const float* presum = nullptr; int presum_n = 0;
 };
 int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 

@@ -61,7 +61,8 @@ inline void ltx_sinusoid_table(int vae_flavour, float tab[128]) {
 
 // y[M,N] = epi(x[M,K] @ W^T + b)
 int ltx_linear(const LinearW& l, const void* x, int lda, void* y, int ldc, int M, int dtype, int epi, hipStream_t s,
-               const void* resid = nullptr, int ldr = 0, const float* gate = nullptr, int gate_stride = 0, int rows_per_batch = 1);
+               const void* resid = nullptr, int ldr = 0, const float* gate = nullptr, int gate_stride = 0, int rows_per_batch = 1,
+               float* rowsq = nullptr);
 
 // conv weight repack [O,I,kt,kh,kw] -> [tap][n'][I] with output-channel permutation (vae.hip)
 enum { LTX_PERM_NONE = 0, LTX_PERM_D2S = 1, LTX_PERM_UNPATCH = 2 };

@@ -48,10 +48,10 @@ int ltx_load_linear(const WeightMap& wm, const std::string& prefix, int in, int 
 }
 
 int ltx_linear(const LinearW& l, const void* x, int lda, void* y, int ldc, int M, int dtype, int epi, hipStream_t s,
-               const void* resid, int ldr, const float* gate, int gate_stride, int rows_per_batch) {
+               const void* resid, int ldr, const float* gate, int gate_stride, int rows_per_batch, float* rowsq) {
     GemmArgs g;
     g.A = x; g.W = l.w; g.C = y; g.bias = l.b; g.resid = resid; g.gate = gate;
     g.M = M; g.N = l.out; g.K = l.in; g.lda = lda; g.ldc = ldc; g.ldr = ldr;
-    g.rows_per_batch = rows_per_batch; g.gate_stride = gate_stride;
+    g.rows_per_batch = rows_per_batch; g.gate_stride = gate_stride; g.rowsq = rowsq;
     return ltx_launch_gemm(g, dtype, epi, s);
 }

@@ -226,6 +226,113 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int l
     }
 }
 
+// Wide rows, several per wave, software-pipelined (round 4).  The one-row-per-wave form (MODE 0 above) has every wave of the launch
+// resident at once and therefore in the same phase: the chip first reads the whole matrix, then writes the whole result - 41 MB
+// of the DiT's [4992, 2048] pass take 12.7 us where a pure elementwise map of the same bytes takes 6.6 us (tools/norm_probe.py).
+// Here a wave walks R rows (row = wave + k * waves) with the loads of the next PD rows in flight while it reduces, modulates and
+// stores the current one, so reads and writes overlap; each lane keeps the modulation operands of its NS chunks in registers when
+// all rows of the wave share a batch element (they do for B = 1; otherwise they are re-loaded per row).  Per row the arithmetic is
+// MODE 0's, expression for expression: same bits.
+template <typename T, int NS, int R, int PD>
+__global__ __launch_bounds__(256) void rownorm_rows_kernel(const RowNormArgs a, int total_waves) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    static_assert(PD >= 1 && PD < R, "prefetch depth");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * 4 + wave;
+    const int nch = a.D / CH;
+    const float invD = 1.0f / (float)a.D;
+    auto row_of = [&](int k) { return w0 + (int64_t)k * total_waves; };
+    Chunk16 v[PD + 1][NS];
+    auto load_row = [&](int k, Chunk16 (&dst)[NS]) {
+        const int64_t row = row_of(k);
+        const bool in = row < a.rows;
+        const T* x = reinterpret_cast<const T*>(a.x) + (in ? row : a.rows - 1) * a.ldx;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane + i * 64;
+            dst[i].u = (u32x4){0u, 0u, 0u, 0u};
+            if (in && c < nch) dst[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
+        }
+    };
+    // operands of this lane's chunks for the batch element of the wave's first row
+    const int64_t b_first = (row_of(0) < a.rows ? row_of(0) : a.rows - 1) / a.rows_per_batch;
+    const int64_t last_row = row_of(R - 1) < a.rows ? row_of(R - 1) : a.rows - 1;
+    const bool one_batch = last_row / a.rows_per_batch == b_first;
+    float wv[NS][CH], scv[NS][CH], shv[NS][CH];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) if (lane + i * 64 < nch) load_chunk_operands<T>(a, lane + i * 64, b_first, wv[i], scv[i], shv[i]);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) load_row(k, v[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (k + PD < R) load_row(k + PD, v[(k + PD) % (PD + 1)]);
+        Chunk16 (&cur)[NS] = v[k % (PD + 1)];
+        const int64_t row = row_of(k);
+        const bool active = row < a.rows;
+        float mean = 0.f;
+        if (a.kind == 1) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { float f[CH]; chunk_to_f32<T>(cur[i], f);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) s += f[j]; }
+            mean = group_sum(s, 64) * invD;
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (lane + i * 64 < nch) {
+                float f[CH]; chunk_to_f32<T>(cur[i], f);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) { float d = f[j] - mean; ss += d * d; }
+            }
+        }
+        ss = group_sum(ss, 64);
+        const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
+        T* y = reinterpret_cast<T*>(a.y) + (active ? row : a.rows - 1) * a.ldy;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane + i * 64;
+            if (c >= nch) continue;
+            asm volatile("" : "+v"(cur[i].u));              // (keeps the f32 expansion of the statistics from living on: registers)
+            float f[CH]; chunk_to_f32<T>(cur[i], f);
+            if (one_batch) finish_chunk_regs<T>(a, f, mean, rinv, c, a.weight != nullptr, a.scale != nullptr, wv[i], scv[i], shv[i], y, active);
+            else {
+                const int64_t b = (active ? row : a.rows - 1) / a.rows_per_batch;
+                const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+                const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+                finish_chunk<T>(a, f, mean, rinv, c, sc, sh, y, active);
+            }
+        }
+    }
+}
+
+// RMS norm (+ weight, modulation, activation) of rows whose sums of squares are already known (RowNormArgs::presum, the
+// by-product of the GEMM that wrote x): one thread per 16-byte chunk, no reduction, no wave waiting for a row - where the
+// one-row-per-wave kernel takes 12.6 us for the DiT's [4992, 2048] pass, a pure map of the same bytes takes 6.5 us
+// (tools/norm_probe.py).  rinv is formed exactly as in rownorm_kernel; the partials are summed in ascending order.
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = id / nch;
+    if (row >= a.rows) return;
+    const int c = (int)(id - row * nch);
+    const float* ps = a.presum + row * a.presum_n;
+    float ss = 0.f;
+    for (int g4 = 0; g4 < a.presum_n; g4 += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ps + g4);
+        ss += t[0]; ss += t[1]; ss += t[2]; ss += t[3];
+    }
+    const float rinv = 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
+    Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
+    float f[CH]; chunk_to_f32<T>(v, f);
+    const int64_t b = row / a.rows_per_batch;
+    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+    finish_chunk<T>(a, f, 0.f, rinv, c, sc, sh, reinterpret_cast<T*>(a.y) + row * a.ldy, true);
+}
+
 // CACHED: the (<= NSLOT chunks per lane) segment stays in registers between the two passes
 template <typename T, bool CACHED>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a, int lpr) {
@@ -473,7 +580,24 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
         // in flight across the chip, not by the operand traffic through the vector-memory path)
         const int64_t rows_per_block = 4 * rpw;
         dim3 grid((unsigned)cdiv64(a.rows, rows_per_block));
-        if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), 0, s, a, lpr);
+        // wide rows (one wave per row, <= 4 chunks per lane), enough of them: four rows per wave, two in flight (LTX_ROWNORM_ROWS=0: one row per wave)
+        const char* re = getenv("LTX_ROWNORM_ROWS");
+        if (lpr == 64 && nch <= 4 * 64 && a.rows >= 2048 && re && re[0] == '1') {       // opt-in: measured 17.3 us against 12.7 us (DESIGN / lab notes)
+            constexpr int R = 4;
+            const int waves = (int)cdiv64(a.rows, R);
+            const int blocks = (waves + 3) / 4;
+            LTX_LAUNCH_TIMED((rownorm_rows_kernel<T, 4, R, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a, blocks * 4);
+            return;
+        }
+        // LTX_ROWNORM_OCC=n (experiment): at most n blocks per CU, by asking for 160 KiB / n of LDS the kernel never touches -
+        // several generations of blocks instead of one, so that the stores of one overlap the loads of the next
+        int shm = 0;
+        if (const char* oe = getenv("LTX_ROWNORM_OCC")) { const int n = atoi(oe); if (n >= 1 && n <= 8) shm = 163840 / n - 1024; }
+        if (shm > 65536) {
+            static std::atomic<unsigned long long> occ_devs{0};
+            (void)ltx_set_max_dyn_smem(occ_devs, reinterpret_cast<const void*>(&rownorm_kernel<T, 0>), 163840);
+        }
+        if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), shm, s, a, lpr);
         else LTX_LAUNCH_TIMED((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
     }
 }
@@ -488,7 +612,12 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     const int nch = a.D / ch, lpr = pick_lpr(nch);
     void* tok = nullptr;
     ltx_prof_begin(LTX_PROF_ROWNORM, 2.0 * (double)a.rows * a.D * (dtype == LTX_DT_BF16 ? 2 : 4), s, &tok);
-    if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
+    if (a.presum) {
+        if (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows with a multiple of 4 partials");
+        const int64_t chunks = a.rows * nch;
+        if (dtype == LTX_DT_BF16) LTX_LAUNCH_TIMED(rownorm_presum_kernel<bf16_t>, dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, s, a, nch);
+        else LTX_LAUNCH_TIMED(rownorm_presum_kernel<float>, dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, s, a, nch);
+    } else if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
     else launch_rownorm_t<float>(a, lpr, nch, s);
     ltx_prof_end(tok, s);
     LTX_CHECK_LAUNCH();

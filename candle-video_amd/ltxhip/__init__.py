@@ -112,7 +112,8 @@ _SIGS = {
     "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp], "ltx_prof_report_kernel": [_i, _i, _vp, _vp, _vp],
     "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_linear_segmented": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
+    "ltx_op_rownorm_presum": [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp],
+    "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
     "ltx_op_attention_rowsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
@@ -943,13 +944,14 @@ class ops:
         return y
 
     @staticmethod
-    def linear_rowsq(x, w, bias):
+    def linear_rowsq(x, w, bias, epi=0, resid=None, gate=None, rows_per_batch=1):
         """-> (x @ w^T + bias, per-row partial sums of squares of that output per 128-column group [M, ceil(N/128)] f32)"""
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         rs = torch.empty(M, (N + 127) // 128, dtype=torch.float32, device=x.device)
-        _check(lib.ltx_op_linear_rowsq(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), _ptr(rs), M, N, K, _dt(x.dtype), _stream()))
+        _check(lib.ltx_op_linear_rowsq(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), _ptr(rs), M, N, K, _dt(x.dtype), epi,
+                                       _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
         return y, rs
 
     @staticmethod
@@ -986,6 +988,16 @@ class ops:
         ms = scale.shape[-1] if scale is not None else 0
         _check(lib.ltx_op_rownorm(_ptr(x.contiguous()), _ptr(y), C.c_int64(rows), D, kind, C.c_float(eps), _ptr(weight),
                                   _ptr(scale), _ptr(shift), C.c_int64(rows_per_batch), ms, act, _dt(x.dtype), _stream()))
+        return y
+
+    @staticmethod
+    def rownorm_presum(x, presum, eps=1e-6, weight=None, scale=None, shift=None, rows_per_batch=1, act=0):
+        """RMS rownorm of rows whose sums of squares are known (presum [rows, D/128] from linear_rowsq / rowsq): a pure map"""
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        ms = scale.shape[-1] if scale is not None else 0
+        _check(lib.ltx_op_rownorm_presum(_ptr(x.contiguous()), _ptr(y), C.c_int64(rows), D, C.c_float(eps), _ptr(weight), _ptr(scale), _ptr(shift),
+                                         C.c_int64(rows_per_batch), ms, act, _ptr(presum), presum.shape[-1], _dt(x.dtype), _stream()))
         return y
 
     @staticmethod

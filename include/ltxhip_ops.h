@@ -18,11 +18,12 @@ extern "C" {
 int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, int epi,
                   const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);
 
-/* nn::Linear (epi 0) that also leaves the per-row partial sums of squares of its stored output, one f32 per 128-column
+/* nn::Linear (epi 0, or the residual forms 2 / 3) that also leaves the per-row partial sums of squares of its stored output, one f32 per 128-column
  * group: rowsq[m * ceil(N/128) + g].  The summation order is canonical (independent of the kernel the plan picks), so a
  * consumer can fold an RMS norm of the output rows without a pass over them: the cross-attention q-norm,
  * ltx_transformer.rs:671-678.  ltx_op_rowsq is the stand-alone form on a stored matrix: same values, bit for bit. */
-int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, ltx_stream stream);
+int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, int epi,
+                        const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);   /* epi 0, 2, 3 as ltx_op_linear */
 int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int dtype, ltx_stream stream);
 
 /* The fused q|k|v projection of LtxAttention (ltx_transformer.rs:655-662: to_q, to_k, to_v on the same input) with the
@@ -30,6 +31,12 @@ int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int d
  * seg_width a power of two dividing N. */
 int ltx_op_linear_segmented(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int seg_width,
                             int dtype, ltx_stream stream);
+
+/* The RMS form of ltx_op_rownorm for rows whose sums of squares are already known (presum [rows, presum_n], the by-product of
+ * ltx_op_linear_rowsq / ltx_op_rowsq on x): a pure elementwise map, no row reduction. */
+int ltx_op_rownorm_presum(const void* x, void* y, int64_t rows, int D, float eps, const void* weight,
+                          const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
+                          const float* presum, int presum_n, int dtype, ltx_stream stream);
 
 /* RmsNorm / LayerNormNoParams + AdaLN modulate (+SiLU) on rows (ltx_transformer.rs:72-119, 874-889;
  * vae.rs:148-153, 711-739): y = act(norm(x)[*weight]*(1+scale_b)+shift_b). kind 0 RMS / 1 LN. */

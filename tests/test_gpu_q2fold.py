@@ -140,3 +140,56 @@ def test_dit_forward_with_and_without_the_fold_vs_oracle(hip):
     assert rel_max(outs["f32"], want32) <= 1e-3
     assert not torch.equal(outs["on"], outs["off"])
     assert e_new <= 2e-2 and e_new <= 1.25 * e_old + 1e-3
+
+
+def test_rownorm_from_presums_matches_the_row_reducing_pass(hip):
+    """The block's two RMS norms as a pure elementwise map on sums of squares that the producing GEMM's epilogue left behind
+    (RowNormArgs::presum): against the one-row-per-wave pass on the same rows (bf16: at most one bf16 ulp apart - the two sum
+    the squares in different orders) and against f32 torch (rel-L2 at the bf16 rounding floor); residual epilogues emit the
+    partials too (asm16 plans forced), bit-identical to the stand-alone pass on the stored h."""
+    S, D = 4992, 2048
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(S, D, generator=g) * 1.3).bfloat16().to(DEV)
+    sc = torch.randn(1, D, generator=g).to(DEV); sh = torch.randn(1, D, generator=g).to(DEV)
+    rs = hip.ops.rowsq(x)
+    y_map = hip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S, 0)
+    y_row = hip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0)
+    ref = O.rms_norm(x.float().cpu()[None], None, 1e-6)[0] * (1 + sc.cpu()) + sh.cpu()
+    e_map, e_row = rel_l2(y_map.float().cpu(), ref), rel_l2(y_row.float().cpu(), ref)
+    ulp = (y_map.view(torch.int16).int() - y_row.view(torch.int16).int()).abs().max().item()
+    print(f"rownorm presum: rel-L2 vs f32 {e_map:.5f} (row-reducing pass {e_row:.5f}); max distance {ulp} bf16 ulp; differing elements {(y_map != y_row).float().mean().item():.2e}")
+    assert e_map <= 3e-3 and e_map <= 1.1 * e_row + 1e-5 and ulp <= 1
+    # the residual epilogues leave the partials as well
+    K = 2048
+    a = torch.randn(S, K, generator=g).bfloat16().to(DEV); w = (torch.randn(D, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV); b = torch.randn(D, generator=g).bfloat16().to(DEV)
+    gate = torch.randn(1, D, generator=g).to(DEV)
+    for epi in (2, 3):
+        h, hs = hip.ops.linear_rowsq(a, w, b, epi=epi, resid=x, gate=gate if epi == 2 else None, rows_per_batch=S)
+        h0 = hip.ops.linear(a, w, b, epi=epi, resid=x, gate=gate if epi == 2 else None, rows_per_batch=S)
+        assert torch.equal(h, h0) and torch.equal(hs, hip.ops.rowsq(h))
+
+
+def test_dit_with_presum_norms_vs_oracle(hip):
+    """The same two-layer DiT as above with LTX_NORM_PRESUM=0 / 2 (forced: at M = 252 the partials come from the stand-alone pass,
+    which is the same canonical sum): both within the bf16 bar of the f32 oracle, neither worse than the other by more than noise."""
+    cfgd = dict(in_channels=32, out_channels=32, num_attention_heads=8, attention_head_dim=64, cross_attention_dim=512, num_layers=2, caption_channels=64)
+    cfg = O.DitConfig(**cfgd)
+    w = O.synth_weights(O.dit_weight_shapes(cfg), seed=79)
+    Fr, H, W, K = 2, 7, 9, 128
+    S = Fr * H * W
+    g = torch.Generator().manual_seed(80)
+    hidden = torch.randn(2, S, 32, generator=g); enc = torch.randn(2, K, 64, generator=g)
+    mask = torch.zeros(2, K); mask[0, :40] = 1; mask[1, :128] = 1
+    coords = O.build_video_coords(2, Fr, H, W)
+    t = torch.tensor([896.0, 640.0])
+    slm = torch.tensor([[0.0, 1.0], [0.0, 0.0]])            # layer 0 blended away for batch row 1: the partials of h are stale after the blend
+    wr = {k: v.bfloat16().float() for k, v in w.items()}
+    ref = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords, slm)
+    outs = {}
+    for tag, v in (("off", "0"), ("on", "2")):
+        with env(LTX_NORM_PRESUM=v):
+            model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: x.to(DEV) for k, x in w.items()}, torch.bfloat16)
+            outs[tag] = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV), slm).float().cpu()
+    e_off, e_on = rel_l2(outs["off"], ref), rel_l2(outs["on"], ref)
+    print(f"dit D=512 bf16 vs f32 oracle: row-reducing norms {e_off:.5f}, presum norms {e_on:.5f}; between them {rel_l2(outs['on'], outs['off']):.5f}")
+    assert e_on <= 2e-2 and e_on <= 1.25 * e_off + 1e-3 and not torch.equal(outs["on"], outs["off"])

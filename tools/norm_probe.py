@@ -12,8 +12,23 @@ sc = torch.randn(1, D, device="cuda"); sh = torch.randn(1, D, device="cuda")
 res = {}
 def t(name, fn):
     res[name] = round(min(timeit(fn, iters=200, warm=10) for _ in range(3)) * 1e3, 2)
+os.environ["LTX_ROWNORM_ROWS"] = "0"
 t("rownorm_mod_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0))
 t("rownorm_plain_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, None, None, S, 0))
+y_old = ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0); y_old_ln = ltxhip.ops.rownorm(x, 1, 1e-6, None, sc, sh, S, 0)
+del os.environ["LTX_ROWNORM_ROWS"]
+for occ in ("1", "2", "3", "4", "6"):
+    os.environ["LTX_ROWNORM_OCC"] = occ
+    t(f"rownorm_mod_occ{occ}_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0))
+del os.environ["LTX_ROWNORM_OCC"]
+os.environ["LTX_ROWNORM_ROWS"] = "1"
+t("rownorm_rows_mod_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0))
+t("rownorm_rows_plain_us", lambda: ltxhip.ops.rownorm(x, 0, 1e-6, None, None, None, S, 0))
+res["rows_bit_identical"] = bool(torch.equal(y_old, ltxhip.ops.rownorm(x, 0, 1e-6, None, sc, sh, S, 0)) and torch.equal(y_old_ln, ltxhip.ops.rownorm(x, 1, 1e-6, None, sc, sh, S, 0)))
+x3 = torch.randn(3 * S - 5, D, device="cuda").bfloat16(); sc3 = torch.randn(3, D, device="cuda"); sh3 = torch.randn(3, D, device="cuda")
+os.environ["LTX_ROWNORM_ROWS"] = "0"; y3 = ltxhip.ops.rownorm(x3, 0, 1e-6, None, sc3, sh3, S, 0); os.environ["LTX_ROWNORM_ROWS"] = "1"
+res["rows_bit_identical_3_batches_ragged"] = bool(torch.equal(y3, ltxhip.ops.rownorm(x3, 0, 1e-6, None, sc3, sh3, S, 0)))
+os.environ.pop("LTX_ROWNORM_ROWS", None)
 t("copy_us", lambda: y.copy_(x))
 t("map_mul_us", lambda: torch.mul(x, 1.5, out=y))
 w = torch.randn(D, device="cuda").bfloat16()
