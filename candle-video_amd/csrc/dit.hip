@@ -223,15 +223,17 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
     // The two RMS norms of a block take their rows' sums of squares from the epilogue of the GEMM that wrote h (ff2 of the block
     // before, attn2.to_out of this block: GemmArgs::rowsq) and run as a pure elementwise map; same shape-only condition as the
-    // fold above (the partials must come from gemm_asm16's epilogue).  LTX_NORM_PRESUM=0: the one-row-per-wave pass (A/B aid).
-    bool presum = dt == LTX_DT_BF16 && D % 512 == 0;
+    // fold above (the partials must come from gemm_asm16's epilogue).  OPT-IN (LTX_NORM_PRESUM=1; "2" forces it whatever the shape):
+    // measured on C2 the map takes the same 13.5 us per launch in the pipeline as the row-reducing kernel (7.37 vs 7.46 ms per video)
+    // and the epilogues pay +0.4 ms for the partials - the pass is not bound by its reduction (docs/lab_notes.md).
+    bool presum = dt == LTX_DT_BF16 && D % 512 == 0 && (D & (D - 1)) == 0 && D <= 2048;
     if (presum) {
         const char* pe = getenv("LTX_NORM_PRESUM");
         GemmArgs gp; gp.A = m->attn.p; gp.W = m->blocks[0].o2.w; gp.C = m->h.p; gp.bias = m->blocks[0].o2.b; gp.resid = m->h.p;
         gp.M = (int)M; gp.N = m->blocks[0].o2.out; gp.K = m->blocks[0].o2.in; gp.lda = D; gp.ldc = D; gp.ldr = D;
         GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D;
         gf.gate = m->ada.as<float>(); gf.gate_stride = 6 * D; gf.rows_per_batch = S;
-        presum = !(pe && pe[0] == '0') && ((ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || (pe && pe[0] == '2'));   // "2": whatever the shape (tests)
+        presum = pe && ((pe[0] == '1' && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || pe[0] == '2');
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h

@@ -312,12 +312,13 @@ __global__ __launch_bounds__(256) void rownorm_rows_kernel(const RowNormArgs a, 
 // one-row-per-wave kernel takes 12.6 us for the DiT's [4992, 2048] pass, a pure map of the same bytes takes 6.5 us
 // (tools/norm_probe.py).  rinv is formed exactly as in rownorm_kernel; the partials are summed in ascending order.
 template <typename T>
-__global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch) {
+__global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch, int rpb) {
+    // block = rpb whole rows (rpb = 256 / nch, nch a power of two <= 256): the row index, its batch element and its 1 / rms are
+    // wave-uniform (scalar loads and a handful of VALU ops per wave, not a 64-bit division and a square root per thread)
     constexpr int CH = ElemTraits<T>::CHUNK;
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = id / nch;
+    const int sub = threadIdx.x / nch, c = threadIdx.x - sub * nch;
+    const int64_t row = (int64_t)blockIdx.x * rpb + sub;
     if (row >= a.rows) return;
-    const int c = (int)(id - row * nch);
     const float* ps = a.presum + row * a.presum_n;
     float ss = 0.f;
     for (int g4 = 0; g4 < a.presum_n; g4 += 4) {
@@ -327,9 +328,9 @@ __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a
     const float rinv = 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
     Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
     float f[CH]; chunk_to_f32<T>(v, f);
-    const int64_t b = row / a.rows_per_batch;
-    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
-    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+    const uint32_t b = (uint32_t)row / (uint32_t)a.rows_per_batch;
+    const float* sc = a.scale ? a.scale + (int64_t)b * a.mod_stride : nullptr;
+    const float* sh = a.shift ? a.shift + (int64_t)b * a.mod_stride : nullptr;
     finish_chunk<T>(a, f, 0.f, rinv, c, sc, sh, reinterpret_cast<T*>(a.y) + row * a.ldy, true);
 }
 
@@ -613,10 +614,11 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     void* tok = nullptr;
     ltx_prof_begin(LTX_PROF_ROWNORM, 2.0 * (double)a.rows * a.D * (dtype == LTX_DT_BF16 ? 2 : 4), s, &tok);
     if (a.presum) {
-        if (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows with a multiple of 4 partials");
-        const int64_t chunks = a.rows * nch;
-        if (dtype == LTX_DT_BF16) LTX_LAUNCH_TIMED(rownorm_presum_kernel<bf16_t>, dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, s, a, nch);
-        else LTX_LAUNCH_TIMED(rownorm_presum_kernel<float>, dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, s, a, nch);
+        if (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0 || nch > 256 || (nch & (nch - 1)) || a.rows >= 2147483647LL || a.rows_per_batch >= 2147483647LL)
+            LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows of a power-of-two number (<= 256) of 16-byte chunks with a multiple of 4 partials");
+        const int rpb = 256 / nch;
+        if (dtype == LTX_DT_BF16) LTX_LAUNCH_TIMED(rownorm_presum_kernel<bf16_t>, dim3((unsigned)cdiv64(a.rows, rpb)), dim3(256), 0, s, a, nch, rpb);
+        else LTX_LAUNCH_TIMED(rownorm_presum_kernel<float>, dim3((unsigned)cdiv64(a.rows, rpb)), dim3(256), 0, s, a, nch, rpb);
     } else if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
     else launch_rownorm_t<float>(a, lpr, nch, s);
     ltx_prof_end(tok, s);

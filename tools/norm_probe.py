@@ -29,6 +29,8 @@ x3 = torch.randn(3 * S - 5, D, device="cuda").bfloat16(); sc3 = torch.randn(3, D
 os.environ["LTX_ROWNORM_ROWS"] = "0"; y3 = ltxhip.ops.rownorm(x3, 0, 1e-6, None, sc3, sh3, S, 0); os.environ["LTX_ROWNORM_ROWS"] = "1"
 res["rows_bit_identical_3_batches_ragged"] = bool(torch.equal(y3, ltxhip.ops.rownorm(x3, 0, 1e-6, None, sc3, sh3, S, 0)))
 os.environ.pop("LTX_ROWNORM_ROWS", None)
+rs = ltxhip.ops.rowsq(x)
+t("rownorm_presum_mod_us", lambda: ltxhip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S, 0))
 t("copy_us", lambda: y.copy_(x))
 t("map_mul_us", lambda: torch.mul(x, 1.5, out=y))
 w = torch.randn(D, device="cuda").bfloat16()
