@@ -156,18 +156,37 @@ bool ltx_attention_q128_fits(const AttnArgs& a) {
     return ((double)a.Sk + 4 * 64) * a.ldk * 2.0 < lim && ((double)a.Sk + 4 * 64) * a.ldv * 2.0 < lim && (double)a.Sq * a.ldq * 2.0 < lim && (double)a.Sq * a.ldo * 2.0 < lim;
 }
 
+// The overflow flags of a device: 64 words, allocated and zeroed ONCE.  ltx_dit_create (head_dim 128) and ltx_warmup call
+// ltx_attention_q128_prepare, so that the launch path neither allocates nor runs a synchronous memset (both would break a
+// stream capture and stall other streams); a launch on a device nobody prepared still works, paying that cost once.  A failed
+// memset frees the buffer and leaves nothing cached.
+static int q128_flags_locked(int dev, int** out) {
+    auto it = g_q128_flag.find(dev);
+    if (it != g_q128_flag.end()) { *out = it->second; return LTX_OK; }
+    int* f = nullptr;
+    HIP_TRY(hipMalloc(&f, 64 * sizeof(int)));
+    if (hipMemset(f, 0, 64 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(f); LTX_FAIL(LTX_ERR_HIP, "attn_q128: cannot zero the overflow flags"); }
+    g_q128_flag[dev] = f;
+    *out = f;
+    return LTX_OK;
+}
+int ltx_attention_q128_prepare() {
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_q128_mu);
+    int* f = nullptr;
+    return q128_flags_locked(dev, &f);
+}
+
 // Launches the kernel; *flag_out / *ticket_out identify the overflow flag the caller gates its exact pass on.
+// Flag words rotate by ticket (64 of them): a launch finds its word untouched unless 64 later launches have been ISSUED before
+// its gated exact pass has RUN, and one of those overflowed into the same word - i.e. two overflows (never seen on the DiT's
+// normed q / k) 64 launches apart on different streams; the exact pass of the earlier launch would then be skipped.
 int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, int* ticket_out) {
     int dev = 0; HIP_TRY(hipGetDevice(&dev));
     int* flag = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_q128_mu);
-        auto it = g_q128_flag.find(dev);
-        if (it == g_q128_flag.end()) {
-            HIP_TRY(hipMalloc(&flag, 64 * sizeof(int)));
-            HIP_TRY(hipMemset(flag, 0, 64 * sizeof(int)));
-            g_q128_flag[dev] = flag;
-        } else flag = it->second;
+        LTX_TRY(q128_flags_locked(dev, &flag));
     }
     const int ticket = g_q128_ticket.fetch_add(1) | 0x40000000;       // never 0 (the flags' initial value)
     flag += ticket & 63;                                               // 64 flag words in rotation: launches in flight on other streams keep their own

@@ -152,6 +152,7 @@ extern "C" int ltx_dit_create(const ltx_dit_config* cfg, const ltx_weight* weigh
     ltx_dit* m = new ltx_dit();
     m->cfg = *cfg; m->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32; m->device = device; m->D = D;
     int rc = build(m, weights, n_weights);
+    if (rc == LTX_OK && cfg->attention_head_dim == 128 && m->dtype == LTX_DT_BF16) rc = ltx_attention_q128_prepare();
     if (rc != LTX_OK) { m->free_all(); delete m; return rc; }
     *out = m;
     return LTX_OK;

@@ -148,6 +148,7 @@ struct AttnArgs {
 };
 bool ltx_attention_q128_fits(const AttnArgs& a);           // attn_q128.hip: head_dim 128 one-wave-per-SIMD kernel
 int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, int* ticket_out);
+int ltx_attention_q128_prepare();   // allocate + zero the current device's overflow flags outside any launch path (create / warm-up)
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
 bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row offset below 2^31 (its 32-bit buffer arithmetic)

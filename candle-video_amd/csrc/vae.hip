@@ -37,6 +37,7 @@ struct ltx_vae {
     std::vector<void*> owned;
     DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats, predec;
     std::deque<DevBuf> tilebufs;   // deque: growing it must not move DevBufs that Tile.buf points at
+    size_t act_bytes_reserved() const { return X.bytes + Y.bytes + N.bytes + C.bytes; }   // activation buffers a decoder call re-uses
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
@@ -454,16 +455,30 @@ int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, c
     size_t total = 0;
     for (const Leaf& l : leaves) total += elems(l);
     LTX_TRY(v->predec.ensure(total * sizeof(float)));
+    // Leaves per decoder call.  The reference tiles to CAP memory (vae.rs:2225-2290), so the batch must not undo that: it is
+    // bounded by a share of the memory that is free now, against a generous estimate of one leaf's activations (six tensors
+    // of the largest, 128-channel stage + its f32 output), and a call that still fails to allocate is retried with half as
+    // many leaves, down to one.  LTX_VAE_TILE_BATCH=0: one leaf per call; =n: at most n.
     const char* be = getenv("LTX_VAE_TILE_BATCH");
-    int max_n = (be && be[0] == '0') ? 1 : LTX_MAX_BATCH / B; if (max_n < 1) max_n = 1;
+    int max_n = LTX_MAX_BATCH / B; if (max_n < 1) max_n = 1;
+    if (be) { const int n_env = atoi(be); max_n = n_env <= 0 ? 1 : std::min(max_n, n_env); }
     std::vector<char> done(leaves.size(), 0);
     float* cursor = v->predec.as<float>();
     for (size_t a = 0; a < leaves.size(); ++a) {
         if (done[a]) continue;
         const Leaf& la = leaves[a];
         const int nf = la.t1 - la.t0, th = la.h1 - la.h0, tw = la.w1 - la.w0;
+        int cap = max_n;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const double act = 6.0 * (double)B * ((double)(nf - 1) * tr + 1) * (th * r / 4.0) * (tw * r / 4.0) * 128.0 * (double)esz + (double)elems(la) * 4.0;
+                const double fit = 0.5 * ((double)free_b + (double)v->act_bytes_reserved()) / (act > 1.0 ? act : 1.0);
+                if (fit < (double)cap) cap = fit < 1.0 ? 1 : (int)fit;
+            } else (void)hipGetLastError();
+        }
         std::vector<size_t> grp;
-        for (size_t b = a; b < leaves.size() && (int)grp.size() < max_n; ++b) {
+        for (size_t b = a; b < leaves.size() && (int)grp.size() < cap; ++b) {
             const Leaf& lb = leaves[b];
             if (!done[b] && lb.t1 - lb.t0 == nf && lb.h1 - lb.h0 == th && lb.w1 - lb.w0 == tw) { grp.push_back(b); done[b] = 1; }
         }
@@ -478,7 +493,16 @@ int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, c
             per_window[l.li][l.slot] = cursor + leaf_out * k;
             if (tv) for (int b = 0; b < B; ++b) tvb.t[k * B + b] = tv->t[b];
         }
-        LTX_TRY(decoder_forward(v, v->tile_lat.p, n * B, nf, th, tw, tv ? &tvb : nullptr, 0, cursor, s));
+        const int rc = decoder_forward(v, v->tile_lat.p, n * B, nf, th, tw, tv ? &tvb : nullptr, 0, cursor, s);
+        if (rc != LTX_OK) {
+            if (n == 1) return rc;
+            // (most likely an allocation: give this group's leaves back and go on with smaller calls)
+            (void)hipGetLastError();
+            for (size_t k : grp) done[k] = 0;
+            max_n = n / 2 < 1 ? 1 : n / 2;
+            --a;
+            continue;
+        }
         cursor += leaf_out * n;
     }
     return LTX_OK;

@@ -28,10 +28,15 @@ def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
     w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
     b = torch.randn(N, device="cuda", generator=g).bfloat16()
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == 3 else None
-    old = {k: os.environ.get(k) for k in ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE")}
+    old = {k: os.environ.get(k) for k in ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_ASM16", "LTX_GEMM_TUNE")}
     try:
+        # the reference arm must be gemm_big: asm16 is the default plan family of these shapes since round 3, so it is taken
+        # out of the static choice (LTX_GEMM_ASM16=0) and the plan cache bypassed (LTX_GEMM_TUNE=0: gemm_big.hip cached_or_tuned_plan
+        # returns before it looks at the cache, which may hold an asm16 plan of this shape from an earlier test)
         os.environ.pop("LTX_GEMM_ASM", None); os.environ.pop("LTX_GEMM_ASM_TILE", None)
+        os.environ["LTX_GEMM_ASM16"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"
         ref = hip.ops.linear(x, w, b, epi=epi, resid=resid)
+        os.environ.pop("LTX_GEMM_ASM16"); os.environ.pop("LTX_GEMM_TUNE")
         os.environ["LTX_GEMM_ASM"] = mode; os.environ["LTX_GEMM_ASM_TILE"] = tile
         got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
     finally:
@@ -58,16 +63,17 @@ def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16()
     gate = torch.randn(2, N, device="cuda", generator=g)
     w3 = (torch.randn(3 * N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16(); b3 = torch.randn(3 * N, device="cuda", generator=g).bfloat16()
-    keys = ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_WIDE_EPI")
+    keys = ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_WIDE_EPI", "LTX_GEMM_ASM16", "LTX_GEMM_TUNE")
     old = {k: os.environ.get(k) for k in keys}
     def run():
         return hip.ops.linear(x, w, b, epi=2, resid=resid, gate=gate, rows_per_batch=1531), hip.ops.linear_segmented(x, w3, b3, N)
     try:
         for k in keys: os.environ.pop(k, None)
+        os.environ["LTX_GEMM_ASM16"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"      # reference arms: gemm_big (asm16 out of the plans, static tile)
         ref = run()
         os.environ["LTX_GEMM_WIDE_EPI"] = "0"
         narrow = run()
-        os.environ.pop("LTX_GEMM_WIDE_EPI")
+        os.environ.pop("LTX_GEMM_WIDE_EPI"); os.environ.pop("LTX_GEMM_ASM16"); os.environ.pop("LTX_GEMM_TUNE")
         os.environ["LTX_GEMM_ASM"] = "16"; os.environ["LTX_GEMM_ASM_TILE"] = tile
         wide = run()
     finally:
