@@ -67,7 +67,7 @@ def measure():
         os.environ.pop("LTX_ATTN_Q64_BIG")
     # in-kernel stamps of the last launch (diagnostic builds): cycles per key tile and the clock inside the loop
     import ctypes
-    lib = ctypes.CDLL(os.path.join(PKG, "libltxhip.so"))
+    lib = ctypes.CDLL(os.environ.get("LTXHIP_LIB") or os.path.join(PKG, "libltxhip.so"))
     if hasattr(lib, "ltx_dbg_q64_stamps"):
         import numpy as np
         for kind, env in (("big", "16"), ("small", "0")):
@@ -92,8 +92,8 @@ def run(names):
     libs = sorted(f for f in os.listdir(VAR) if f.startswith("libltxhip_") and f.endswith(".so"))
     if names: libs = [f"libltxhip_{n}.so" for n in names]
     for lib in libs:
-        shutil.copyfile(os.path.join(VAR, lib), os.path.join(PKG, "libltxhip.so"))
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "measure"], capture_output=True, text=True)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "measure"], capture_output=True, text=True,
+                           env=dict(os.environ, LTXHIP_LIB=os.path.join(VAR, lib)))
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         print(lib[len("libltxhip_"):-3], line[-1] if line else ("FAILED " + p.stderr[-400:]), flush=True)
 
