@@ -1,7 +1,7 @@
 // DiT self-attention, head_dim 64, q prescaled by scale*log2(e), no key bias (candle-flash-attn at
 // ltx_transformer.rs:699-712): one wave per SIMD, 64 queries per wave.
 //
-// Why this shape (attention): at d = 64 the SIMD's vector issue port, not the matrix pipe, bounds the
+// Why this shape (docs/lab_notes.md, attention): at d = 64 the SIMD's vector issue port, not the matrix pipe, bounds the
 // kernel - per 64-key tile a wave must issue one v_exp per score, one v_cvt_pk per two, the K/V fragment reads and its
 // share of the LDS-DMA pieces.  Per FLOP, a wave that owns 64 queries (two 32-query MFMA column blocks) reads each K
 // and V^T fragment once for both blocks and issues half the DMA pieces of a 32-query wave.  That needs the whole

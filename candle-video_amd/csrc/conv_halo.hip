@@ -3,7 +3,7 @@
 //
 // gemm_big / gemm_p8 in conv mode re-stage the M-tile's activation rows for every one of the 27 taps; their loads
 // (global -> LDS by LDS-DMA) cost 35-50 % of the kernel on the 128..512-channel VAE stages (timing ablations in
-// DESIGN.md).  Here the output tile is a 16 x 16 patch of voxels of one frame and LDS holds the patch plus its one-voxel
+// docs/lab_notes.md).  Here the output tile is a 16 x 16 patch of voxels of one frame and LDS holds the patch plus its one-voxel
 // rim (18 x 18 "halo rows" of 64 channels, 41 KiB): the 3 x 3 in-plane taps of that frame tap and channel slice are
 // nine shifted fragment-read patterns over the same LDS image.  Per nine taps a block stages 41.5 KiB of activation
 // (was 9 x 32 KiB for a 256-row tile) plus the nine weight tiles: 2.5 x fewer LDS-DMA instructions per MFMA.

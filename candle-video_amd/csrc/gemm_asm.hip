@@ -12,7 +12,7 @@
 //     that gemm_big.hip's plan measurement tries beside the gemm_big tiles, and the default on every large DiT shape since
 //     the DMA pieces of K-step t + 2 were spread over the whole iteration (s_memtime trace: packed into a third of the
 //     K-step they queued on the CU's address path and stalled the only instruction stream of the SIMD) and the epilogue
-//     was rebuilt around an f32 pass through LDS ("Linear GEMMs, round 3");
+//     was rebuilt around an f32 pass through LDS (docs/lab_notes.md section 4, "Linear GEMMs, round 3");
 //   * gemm_asm_kernel (round 1; v_mfma_f32_32x32x16_bf16): the first attempt at this structure, kept behind LTX_GEMM_ASM=1
 //     as a measured reference (4-12 % behind gemm_big on the DiT shapes: its DMA pieces are still issued in a burst).
 #include <atomic>
