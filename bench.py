@@ -57,7 +57,8 @@ CONFIGS = {
 }
 DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232 (the CPU baseline's C1 run)
 # the one full oracle run of the headline workload (10 minutes of 8 host cores; too long for the default bench run)
-FULL_C2_RUN = {"seconds": 622.57, "frames_per_sec": 97 / 622.57, "cores": 8, "cpu": "Intel Xeon @ 2.60GHz (build container)", "record": "profiles/r3_oracle_cpu_runs.json"}
+FULL_C2_RUN = {"seconds": 622.57, "frames_per_sec": 97 / 622.57, "cores": 8, "machine": "the 8-core build container (Intel Xeon @ 2.60GHz), NOT the GPU box of this run",
+               "record": "profiles/r3_oracle_cpu_runs.json"}
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -103,9 +104,21 @@ def synth_on_device(shapes, dev, seed):
     return out
 
 
+def host_machine():
+    """Which machine a host-side number was taken on: the CPU model string, logical CPUs, hostname."""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"hostname": socket.gethostname(), "cpu_model": model, "logical_cpus": os.cpu_count()}
+
+
 def cpu_baseline(cfg, fl_job):
     """The oracle (a torch-CPU port of the reference's CPU path - oneDNN / MKL kernels under an op-for-op restatement: f32,
-    un-fused, materialised attention scores, conv3d as per-frame sums of conv2d; `kind: "torch-port"`, NOT the reference binary
+    un-fused, materialised attention scores, conv3d as per-frame sums of conv2d; `kind: "port"` + `port_of`, NOT the reference binary
     and not the plain C++ backend SURVEY 8d sketched) timed on this box's host cores, two ways:
       * MEASURED: BASELINE config C1 in full and end to end - the 28-layer 2B DiT x 7 distilled steps + the full VAE decode
         at 256x384x25 (12.8 TFLOP; the run tests/golden/oracle_c1.safetensors comes from), ~20-40 s;
@@ -140,7 +153,8 @@ def cpu_baseline(cfg, fl_job):
     if cfg["preset"] != "0.9.8-2b-distilled" or cfg["mode"] != "replicas" or cfg["num_frames"] == 25:
         # c1 itself: the measured run IS the baseline; other workloads: scaled by algorithmic FLOPs at the measured CPU rate
         total = fl_job / (fl_c1 / t_c1)
-        return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "torch-port", "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
+        return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "port_of": "torch-CPU (oneDNN / MKL) op-for-op restatement of the reference's CPU path (oracle/ltx_oracle.py)",
+                "machine": host_machine(), "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
                 "sample": f"oracle f32 on host: C1 run in full ({t_c1:.1f} s, {fl_c1 / t_c1 / 1e12:.2f} TFLOP/s); this workload's {fl_job / 1e12:.0f} TFLOP "
                           f"at that rate = {total:.0f} s per video" + (" (measured, not scaled)" if cfg["num_frames"] == 25 else " (estimate)")}
     # ---- estimate for C2 from a bounded sample of C2 itself
@@ -168,7 +182,8 @@ def cpu_baseline(cfg, fl_job):
     t_crop = time.time() - t0
     t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
     total = 7 * t_fwd + t_vae
-    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "torch-port", "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
+    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "port_of": "torch-CPU (oneDNN / MKL) op-for-op restatement of the reference's CPU path (oracle/ltx_oracle.py)",
+            "machine": host_machine(), "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
             "sample": f"ESTIMATE for this workload from a bounded sample of it ({t_n[1] + t_n[3] + t_crop:.1f} s of CPU work): oracle f32 DiT forwards with 1 and 3 of 28 "
                       f"layers at S={S} ({t_n[1]:.2f} s, {t_n[3]:.2f} s -> {t_fixed:.2f} s + 28 x {t_layer:.2f} s per forward, x7 steps) + VAE decode of a {cf}x{chh}x{cww} "
                       f"latent crop ({t_crop:.2f} s, scaled by conv FLOPs to {F}x{H}x{W}) = {total:.0f} s per video; MEASURED beside it: C1 in full, {t_c1:.1f} s "
