@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
 
     // ---- tile: (batch*frame, patch row, patch column, n tile); each XCD gets a contiguous run (neighbouring patches
     // share their rims and every patch's n tiles share the whole halo image through one L2)
-    const int ntn = g.N / BN, pwn = (g.Wd + PW - 1) / PW, phn = (g.H + PH - 1) / PH;
+    const int ntn = (g.N + BN - 1) / BN, pwn = (g.Wd + PW - 1) / PW, phn = (g.H + PH - 1) / PH;
     int bid = blockIdx.x;
     {
         const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
     for (int j = 0; j < BJ; ++j) {
         const int row = (j * NL + lwave) * 8 + lr;
         const int lc = pc ^ ((row >> 1) & 7);
-        b_voff[j] = (uint32_t)((((n0 + row) * g.K) + lc * 8) * 2);
+        b_voff[j] = n0 + row < g.N ? (uint32_t)((((n0 + row) * g.K) + lc * 8) * 2) : OOB;      // weight rows beyond N (BN = 64 on conv_out's 48): zeros
     }
     const int KC = g.Cin / 64;                              // 64-channel slices
     const int KT = g.ntaps / 9;                             // frame taps (3)
@@ -496,6 +496,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
             const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+            if (nb >= g.N) continue;                        // N % 4 == 0: a 4-column group is inside or outside as a whole
             float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
             epilogue<bf16_t, EPI>(g, m, nb, v);
         }
@@ -508,7 +509,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     static std::atomic<unsigned long long> attr_devs{0};
     auto kern = conv_halo_kernel<BN, WGM, WGN, EPI, PIPE>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
-    const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * (g.N / BN);
+    const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * cdiv(g.N, BN);
     GemmArgs ga = g;
     const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
@@ -534,8 +535,13 @@ int launch_halo_epi(const GemmArgs& g, int epi, hipStream_t s) {
 // whether the halo-staged kernel can run this conv with tile width bn (128 / 256)
 bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
     if (!g.conv || g.ntaps != 27 || g.kh != 3 || g.kw != 3) return false;
-    if (g.Cin % 64 != 0 || g.K != g.Cin || g.N % bn != 0) return false;
-    if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
+    if (g.Cin % 64 != 0 || g.K != g.Cin) return false;
+    if (bn == 64) {                                         // the narrow tile: conv_out (N = 48, unpatchify epilogue), one n tile
+        if (epi != EPI_UNPATCH || g.N > 64 || g.N % 4 != 0) return false;
+    } else {
+        if (g.N % bn != 0) return false;
+        if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
+    }
     if (g.c_seg_shift) return false;
     // a tile addresses the three frames around it: those (not the tensor) and the weights must stay below 2 GiB
     const double frame_bytes = (double)g.H * g.Wd * g.Cin * 2.0, w_bytes = 27.0 * g.N * g.K * 2.0;
@@ -545,6 +551,7 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     ltx_prof_kernel(LTX_PROFK_CONV_HALO);
     if (!ltx_conv_halo_eligible(g, epi, bn)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: shape not eligible");
+    if (bn == 64) return launch_halo<64, 8, 1, EPI_UNPATCH, false>(g, s);      // conv_out: eight waves of 32 x 64
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
 #if HALO_LOADERS == 4
     const char* pe = getenv("LTX_CONV_HALO_PIPE");          // "0": the barrier-per-step form (A/B)

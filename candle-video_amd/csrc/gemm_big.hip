@@ -802,6 +802,12 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
         if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)
         return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
     }
+    {   // conv_out (N = 48, unpatchify): the halo-staged kernel on its 64-wide tile - one staging of the 128-channel activation
+        // per nine taps instead of one per tap (the per-tap 192 x 64 tile moves 27 x 610 MB through L2 -> LDS at C2).  Same K order:
+        // same bits.  LTX_CONV_OUT_HALO=0: the per-tap tile (A/B aid).
+        const char* oe = getenv("LTX_CONV_OUT_HALO");
+        if (g.conv && epi == EPI_UNPATCH && !(oe && oe[0] == '0') && ltx_conv_halo_eligible(g, epi, 64)) return ltx_launch_conv_halo(g, epi, 64, s);
+    }
     if (const char* he = getenv("LTX_CONV_HALO")) {        // "128" / "256" force the halo-staged conv kernel where eligible (tests, A/B)
         const int bn = atoi(he);
         if ((bn == 128 || bn == 256) && ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);

@@ -212,6 +212,26 @@ def test_conv_out_unpatchify_postprocess(hip, dt):
     assert (yp.cpu() - O.postprocess_video(y.cpu())).abs().max() < 1e-3
 
 
+def test_conv_out_on_the_halo_tile_vs_oracle_and_per_tap_tile(hip):
+    """conv_out at the decoder's real channel count (128 -> 48, unpatchify epilogue, vae.rs:1626-1654) on a ragged plane
+    (19 x 37: partial patches on both edges, three frames: first / middle / last frame taps): the 64-wide halo-staged tile
+    (round 4 default) against the f32 oracle at the bf16 bar and BIT-IDENTICAL to the per-tap 192 x 64 tile it replaced
+    (LTX_CONV_OUT_HALO=0; same K order), with and without the post-processing epilogue."""
+    import os
+    dt = torch.bfloat16
+    x, w, b = rnd(dt, 1, 128, 3, 19, 37), rnd(dt, 48, 128, 3, 3, 3, scale=0.02), rnd(dt, 48, scale=0.1)
+    ref = O.unpatchify(O.causal_conv3d(x.float(), w.float(), b.float(), False), 4, 1)
+    outs = {}
+    for arm in ("0", None):
+        if arm is None: os.environ.pop("LTX_CONV_OUT_HALO", None)
+        else: os.environ["LTX_CONV_OUT_HALO"] = arm
+        outs[arm] = (hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda()), hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda(), postprocess=True))
+    os.environ.pop("LTX_CONV_OUT_HALO", None)
+    check(outs[None][0], ref, dt)
+    assert torch.equal(outs[None][0], outs["0"][0]) and torch.equal(outs[None][1], outs["0"][1])
+    assert (outs[None][1].cpu() - O.postprocess_video(outs[None][0].cpu())).abs().max() < 1e-3
+
+
 def test_guidance_and_scheduler_step_reference_vectors(hip, golden):
     g = golden("ref_guidance.safetensors")           # produced by the reference's scripts/gen_guidance_ref.py
     t, u, p = g["noise_pred_text"].cuda(), g["noise_pred_uncond"].cuda(), g["noise_pred_perturb"].cuda()
