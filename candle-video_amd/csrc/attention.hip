@@ -690,7 +690,10 @@ extern "C" int ltx_dbg_xtrace(unsigned* out, int n) { return hipMemcpyFromSymbol
 #else
 #define XSTAMP(i)
 #endif
-__global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, int groups) {
+#ifndef XATTN_WPS
+#define XATTN_WPS 3          // waves per SIMD the kernel is compiled for (blocks per CU): 2 = round 3's build (254 registers)
+#endif
+__global__ __launch_bounds__(256, XATTN_WPS) void attn_cross64_kernel(const AttnArgs a, int groups) {
     constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2, NKB = XKV / 32;
     __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
     __shared__ __attribute__((aligned(16))) float sbias[XKV];
@@ -727,15 +730,9 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // per-lane bias tuples in accumulator order: key = kb*32 + (i&3) + 8*(i>>2) + 4h
-    f32x16 bias_t[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(&sbias[kb * 32 + 8 * g4 + 4 * h]);
-            bias_t[kb][4 * g4] = bq[0]; bias_t[kb][4 * g4 + 1] = bq[1]; bias_t[kb][4 * g4 + 2] = bq[2]; bias_t[kb][4 * g4 + 3] = bq[3];
-        }
+    // the key bias stays in LDS and is read in accumulator order (key = kb*32 + (i&3) + 8*(i>>2) + 4h) where the scores are
+    // scaled: 64 registers less than keeping the tuples (round 4: three blocks per CU instead of two)
+    auto bias4 = [&](int kb, int g4) { return *reinterpret_cast<const f32x4*>(&sbias[kb * 32 + 8 * g4 + 4 * h]); };
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint32_t k_base[NKS], tr_base[NDB];
 #pragma unroll
@@ -803,7 +800,11 @@ __global__ __launch_bounds__(256, 2) void attn_cross64_kernel(const AttnArgs a, 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sacc[kb][i] = fmaf(sacc[kb][i], cq, bias_t[kb][i]); mt = fmaxf(mt, sacc[kb][i]); }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bq = bias4(kb, g4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sacc[kb][4 * g4 + i] = fmaf(sacc[kb][4 * g4 + i], cq, bq[i]); mt = fmaxf(mt, sacc[kb][4 * g4 + i]); }
+            }
         {
             unsigned mu = __float_as_uint(mt);
             auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
@@ -980,15 +981,21 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
             const int nunits = cdiv(a.Sq, 32);
-            int groups = cdiv(512, a.B * a.heads);
-            {   // among the group counts that keep ~1.5-2 blocks per CU, the one whose four waves waste the fewest 32-query units
-                // (S = 4992: 156 units per head; 16 groups = 9.75 per group -> 3 rounds of the waves for 2.44 of work; 13 groups = 12 = 3 x 4)
-                int best = groups, best_waste = 1 << 30;
-                for (int gq = groups; gq >= (groups * 3 + 3) / 4 && gq >= 1; --gq) {
-                    const int waste = cdiv(cdiv(nunits, gq), 4) * 4 * gq - nunits;
-                    if (waste < best_waste) { best_waste = waste; best = gq; }
+            // Blocks: (batch, head) x groups; a block's four waves step through 32-query units.  The kernel is a latency chain per
+            // unit (q load -> S -> max -> 64 exps -> PV -> store), so what matters is how many units a wave walks: as many groups as
+            // keep every block resident at once (XATTN_WPS blocks per CU since round 4: the key bias moved from 64 registers to
+            // LDS), and among those the MOST groups that reach the smallest units-per-wave.  Measured in the pipeline (S = 4992, 32
+            // heads, kernel durations): 13 groups 18.9 us, 16: 19.4, 20: 18.6, 24: 17.4; round 3's build (two blocks per CU, 13
+            // groups) 18.6 - the kernel is not bound by the length of a wave's unit chain (docs/lab_notes.md R4.6).
+            int groups = 1;
+            {
+                const int slots = 256 * XATTN_WPS;
+                int gmax = slots / (a.B * a.heads); if (gmax < 1) gmax = 1;
+                int best_upw = 1 << 30;
+                for (int gq = 1; gq <= gmax; ++gq) {
+                    const int upw = cdiv(cdiv(nunits, gq), 4);
+                    if (upw <= best_upw) { best_upw = upw; groups = gq; }
                 }
-                groups = best;
             }
             if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
             if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
