@@ -224,9 +224,11 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
     // The two RMS norms of a block take their rows' sums of squares from the epilogue of the GEMM that wrote h (ff2 of the block
     // before, attn2.to_out of this block: GemmArgs::rowsq) and run as a pure elementwise map; same shape-only condition as the
-    // fold above (the partials must come from gemm_asm16's epilogue).  OPT-IN (LTX_NORM_PRESUM=1; "2" forces it whatever the shape):
-    // measured on C2 the map takes the same 13.5 us per launch in the pipeline as the row-reducing kernel (7.37 vs 7.46 ms per video)
-    // and the epilogues pay +0.4 ms for the partials - the pass is not bound by its reduction (docs/lab_notes.md).
+    // fold above (the partials must come from gemm_asm16's epilogue).  LTX_NORM_PRESUM=0: the row-reducing pass (A/B aid); "2" forces
+    // the map whatever the shape (tests).  What it buys is not the missing reduction (a first map, one chunk per thread, took the same
+    // 13.5 us per launch) but operand re-use: with four rows per thread the 64 B of f32 modulation per 16-byte chunk are loaded once
+    // per four chunks - 13.7 -> 11.0 us per launch, 7.3 -> 6.3 ms of norm passes per video against +0.5 ms in the two epilogues
+    // (docs/lab_notes.md R4.4 / R4.7).
     bool presum = dt == LTX_DT_BF16 && D % 512 == 0 && (D & (D - 1)) == 0 && D <= 2048;
     if (presum) {
         const char* pe = getenv("LTX_NORM_PRESUM");
@@ -234,7 +236,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         gp.M = (int)M; gp.N = m->blocks[0].o2.out; gp.K = m->blocks[0].o2.in; gp.lda = D; gp.ldc = D; gp.ldr = D;
         GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D;
         gf.gate = m->ada.as<float>(); gf.gate_stride = 6 * D; gf.rows_per_batch = S;
-        presum = pe && ((pe[0] == '1' && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || pe[0] == '2');
+        presum = (!(pe && pe[0] == '0') && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || (pe && pe[0] == '2');
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h

@@ -311,27 +311,62 @@ __global__ __launch_bounds__(256) void rownorm_rows_kernel(const RowNormArgs a, 
 // by-product of the GEMM that wrote x): one thread per 16-byte chunk, no reduction, no wave waiting for a row - where the
 // one-row-per-wave kernel takes 12.6 us for the DiT's [4992, 2048] pass, a pure map of the same bytes takes 6.5 us
 // (tools/norm_probe.py).  rinv is formed exactly as in rownorm_kernel; the partials are summed in ascending order.
-template <typename T>
+template <typename T, int R>
 __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch, int rpb) {
-    // block = rpb whole rows (rpb = 256 / nch, nch a power of two <= 256): the row index, its batch element and its 1 / rms are
-    // wave-uniform (scalar loads and a handful of VALU ops per wave, not a 64-bit division and a square root per thread)
+    // block = rpb * R whole rows: thread (sub, c) owns 16-byte chunk c of rows row0 + sub * R .. + R - 1 (nch a power of two
+    // <= 256, rpb = 256 / nch).  What bounds the row-reducing kernel is not its reduction but the vector-memory instruction
+    // count: 64 B of f32 modulation operands per 16 B of data, re-loaded for every row (9 - 20 loads per 16 B chunk).  Here a
+    // thread loads its chunk's operands ONCE for R rows, all R data chunks are in flight together, and 1 / rms comes from the
+    // R lanes of each wave that sum the rows' partials (broadcast with readlane): 4 R + 8 memory instructions per R chunks.
     constexpr int CH = ElemTraits<T>::CHUNK;
+    const int lane = threadIdx.x & 63;
     const int sub = threadIdx.x / nch, c = threadIdx.x - sub * nch;
-    const int64_t row = (int64_t)blockIdx.x * rpb + sub;
-    if (row >= a.rows) return;
-    const float* ps = a.presum + row * a.presum_n;
-    float ss = 0.f;
-    for (int g4 = 0; g4 < a.presum_n; g4 += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(ps + g4);
-        ss += t[0]; ss += t[1]; ss += t[2]; ss += t[3];
+    const int64_t row0 = ((int64_t)blockIdx.x * rpb + sub) * R;
+    if (row0 >= a.rows) return;
+    // 1 / rms of the R rows of this thread: lanes 0 .. R-1 of the wave each sum one row's partials (a wave lies inside one sub
+    // when nch >= 64; for narrower rows every lane does its own rows' sums)
+    float rinv[R];
+    auto rinv_of = [&](int64_t row) {
+        const float* ps = a.presum + (row < a.rows ? row : a.rows - 1) * a.presum_n;
+        float ss = 0.f;
+        for (int g4 = 0; g4 < a.presum_n; g4 += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ps + g4);
+            ss += t[0]; ss += t[1]; ss += t[2]; ss += t[3];
+        }
+        return 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
+    };
+    if (nch >= 64) {
+        float mine = 0.f;
+        if (lane < R) mine = rinv_of(row0 + lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) rinv[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), r));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rinv[r] = rinv_of(row0 + r);
     }
-    const float rinv = 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
-    Chunk16 v; v.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
-    float f[CH]; chunk_to_f32<T>(v, f);
-    const uint32_t b = (uint32_t)row / (uint32_t)a.rows_per_batch;
-    const float* sc = a.scale ? a.scale + (int64_t)b * a.mod_stride : nullptr;
-    const float* sh = a.shift ? a.shift + (int64_t)b * a.mod_stride : nullptr;
-    finish_chunk<T>(a, f, 0.f, rinv, c, sc, sh, reinterpret_cast<T*>(a.y) + row * a.ldy, true);
+    Chunk16 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < a.rows ? row0 + r : a.rows - 1;
+        v[r].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
+    }
+    const uint32_t b0 = (uint32_t)row0 / (uint32_t)a.rows_per_batch;
+    const int64_t last = row0 + R - 1 < a.rows ? row0 + R - 1 : a.rows - 1;
+    const bool one_batch = (uint32_t)last / (uint32_t)a.rows_per_batch == b0;
+    float wv[CH], scv[CH], shv[CH];
+    load_chunk_operands<T>(a, c, (int64_t)b0, wv, scv, shv);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        const bool active = row < a.rows;
+        float f[CH]; chunk_to_f32<T>(v[r], f);
+        T* y = reinterpret_cast<T*>(a.y) + (active ? row : a.rows - 1) * a.ldy;
+        if (one_batch) finish_chunk_regs<T>(a, f, 0.f, rinv[r], c, a.weight != nullptr, a.scale != nullptr, wv, scv, shv, y, active);
+        else if (active) {
+            const uint32_t b = (uint32_t)row / (uint32_t)a.rows_per_batch;
+            finish_chunk<T>(a, f, 0.f, rinv[r], c, a.scale ? a.scale + (int64_t)b * a.mod_stride : nullptr, a.shift ? a.shift + (int64_t)b * a.mod_stride : nullptr, y, true);
+        }
+    }
 }
 
 // CACHED: the (<= NSLOT chunks per lane) segment stays in registers between the two passes
@@ -617,8 +652,14 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
         if (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0 || nch > 256 || (nch & (nch - 1)) || a.rows >= 2147483647LL || a.rows_per_batch >= 2147483647LL)
             LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows of a power-of-two number (<= 256) of 16-byte chunks with a multiple of 4 partials");
         const int rpb = 256 / nch;
-        if (dtype == LTX_DT_BF16) LTX_LAUNCH_TIMED(rownorm_presum_kernel<bf16_t>, dim3((unsigned)cdiv64(a.rows, rpb)), dim3(256), 0, s, a, nch, rpb);
-        else LTX_LAUNCH_TIMED(rownorm_presum_kernel<float>, dim3((unsigned)cdiv64(a.rows, rpb)), dim3(256), 0, s, a, nch, rpb);
+        int R = 4;                                           // rows per thread (LTX_NORM_PRESUM_R = 2 / 4 / 8: tuning aid)
+        if (const char* re = getenv("LTX_NORM_PRESUM_R")) { const int v = atoi(re); if (v == 2 || v == 4 || v == 8) R = v; }
+        const dim3 grid((unsigned)cdiv64(a.rows, (int64_t)rpb * R));
+        if (dtype == LTX_DT_BF16) {
+            if (R == 2) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2>), grid, dim3(256), 0, s, a, nch, rpb);
+            else if (R == 4) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4>), grid, dim3(256), 0, s, a, nch, rpb);
+            else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, a, nch, rpb);
+        } else LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);
     } else if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
     else launch_rownorm_t<float>(a, lpr, nch, s);
     ltx_prof_end(tok, s);
