@@ -248,20 +248,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
 
     if (split) {
         // In-launch reduction of a tile's parts: every part stores its f32 accumulators to its slab (fragment-major,
-        // 16 B per lane: fully coalesced), publishes with ONE agent-scope release + a relaxed counter increment; the part
-        // that draws the last ticket acquires once, adds the other slabs to its registers and runs the epilogue.
+        // 16 B per lane: fully coalesced) and takes a ticket; the part that draws the last one acquires once, adds the other
+        // slabs to its registers and runs the epilogue.  Round 4 experiment (LTX_GEMM_SPLIT_SC1=1, off by default): the slab as
+        // WRITE-THROUGH (sc1) stores, drained with vmcnt(0) in every storing wave before the workgroup barrier, no agent-scope
+        // release on the publishing side (MI355X guide, valid forms; publish-large row), the reader keeps its acquire and loads
+        // sc1.  Measured on the small-M shapes (tools/small_m_probe.py, M = 384 / 128): within +-3 % of the fenced protocol on
+        // seven shapes, 16 % slower on ff2 at M = 128 - the publish is not what these launches wait for (docs/lab_notes.md R4.8).
         constexpr int SLAB = BM * BN;                                  // floats
         const int tt = bid - g.sk_full;
         float* slab = g.sk_ws + ((int64_t)tt * g.sk_sf + part) * SLAB;
+        // the tile's sk_sf slabs through one buffer descriptor (aux 16 = sc1 on gfx950: write-through stores, L1-bypassing loads)
+        const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(g.sk_ws + (int64_t)tt * g.sk_sf * SLAB, 0, g.sk_sf * SLAB * 4, 0x00020000);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) *reinterpret_cast<f32x4*>(slab + ((fm * FN + fn) * (64 * NW) + tid) * 4) = acc[fm][fn];
+            for (int fn = 0; fn < FN; ++fn) {
+                const int so = ((fm * FN + fn) * (64 * NW) + tid) * 16;          // byte offset inside the slab
+                if (g.sk_plain) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(slab) + so) = acc[fm][fn];
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[fm][fn]), rslab, part * (SLAB * 4) + so, 0, 16 /* sc1: write-through */);
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(big_smem);       // all LDS tile reads are behind the barrier above
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (g.sk_plain) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned ticket = __hip_atomic_fetch_add(g.sk_cnt + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = ticket == (unsigned)g.sk_sf - 1u;
@@ -278,11 +288,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
         // (its own slab is re-read from memory when it is not part 0; two parts need no re-read, a + b == b + a)
         const float* base = g.sk_ws + (int64_t)tt * g.sk_sf * SLAB;
         const bool reread_own = g.sk_sf > 2 && part != 0;
+        auto ld_slab = [&](const float* p) {
+            if (g.sk_plain) return *reinterpret_cast<const f32x4*>(p);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rslab, (int)((p - base) * 4), 0, 16 /* sc1 */));
+        };
         if (reread_own) {
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = *reinterpret_cast<const f32x4*>(base + ((fm * FN + fn) * (64 * NW) + tid) * 4);
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = ld_slab(base + ((fm * FN + fn) * (64 * NW) + tid) * 4);
         }
         for (int p = (reread_own || part == 0) ? 1 : 0; p < g.sk_sf; ++p) {
             if (p == part && !reread_own) continue;
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(other + ((fm * FN + fn) * (64 * NW) + tid) * 4);
+                    const f32x4 o = ld_slab(other + ((fm * FN + fn) * (64 * NW) + tid) * 4);
                     acc[fm][fn] += o;
                 }
         }
@@ -433,10 +447,15 @@ int ltx_gemm_split_factor(const GemmArgs& g) {
         // long), keep >= 16 K-steps per part, and at most 4 parts once there are more than 16 tiles.  The area rule below cut
         // qkv at M = 384 (144 tiles of 128 x 128) into 4 parts: 36 us against 25 unsplit; M = 1152: 55 against 31.
         const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-        const int target = nk >= 96 ? 512 : 256;
+        // (round 4: with write-through slab stores a part publishes in 3 us instead of 8; LTX_GEMM_SPLIT_SMALL = "target,mink,maxsf"
+        // re-tunes the rule - the defaults are the measured best of tools/small_m_probe.py)
+        static const int t0 = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return a; }();
+        static const int mk = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return b; }();
+        static const int mx = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return c; }();
+        const int target = nk >= 96 ? 2 * t0 : t0;
         int sf = 1;
-        while (sf * 2 <= 8 && tiles * sf * 2 <= target && nk / (sf * 2) >= 16) sf *= 2;
-        if (tiles > 16 && sf > 4) sf = 4;
+        while (sf * 2 <= 8 && tiles * sf * 2 <= target && nk / (sf * 2) >= mk) sf *= 2;
+        if (tiles > 16 && sf > mx) sf = mx;
         return sf;
     }
     const double area = (double)g.M * (double)g.N, chip = 256.0 * 256.0 * 256.0;
@@ -466,6 +485,7 @@ int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int sme
         HIP_TRY(hipMemsetAsync(w.cnt, 0, nb, s));      // once: every reducer hands its counter back at zero
     }
     g->sk_sf = sf; g->sk_full = full; g->sk_ws = reinterpret_cast<float*>(w.slabs); g->sk_cnt = reinterpret_cast<unsigned*>(w.cnt);
+    { const char* pe = getenv("LTX_GEMM_SPLIT_SC1"); g->sk_plain = !(pe && pe[0] == '1'); }      // default: round 3's protocol (see the kernel)
     return LTX_OK;
 }
 }  // namespace

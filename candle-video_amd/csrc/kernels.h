@@ -63,7 +63,7 @@ struct GemmArgs {
     int pn_on = 0; float pn_eps = 0.f; int pn_act = 0; int pn_mod_stride = 0;
     const float* pn_scale = nullptr; const float* pn_shift = nullptr;   // f32 [B, pn_mod_stride] or null
     // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
-    int sk_full = 0, sk_sf = 1;
+    int sk_full = 0, sk_sf = 1, sk_plain = 0;     // sk_plain: round 3's publish protocol (plain stores + agent release), A/B aid
     float* sk_ws = nullptr;       // f32 slabs [tail tile][part][BM*BN]
     unsigned* sk_cnt = nullptr;   // arrival counters [tail tile], zeroed before the launch
 };

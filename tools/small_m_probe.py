@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "candle-video_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch, ltxhip
 from microbench import timeit
-for M in (384, 768, 1152, 128):
+for M in [int(v) for v in os.environ.get("SMALLM_MS", "384,768,1152,128").split(",")]:
     for name, N, K, epi in [("qkv", 6144, 2048, 0), ("to_out", 2048, 2048, 2), ("ff1", 8192, 2048, 1), ("ff2", 2048, 8192, 2)]:
         # rotate through 8 weight copies so that the weights come from HBM as in the model (28 layers x 117 MB >> the 256 MB cache)
         ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16() for _ in range(8)]
