@@ -40,6 +40,92 @@ extern "C" int ltx_sched_set_timesteps(const float* sigmas_in, int n, float mu, 
     return LTX_OK;
 }
 
+namespace {
+// Regularised incomplete beta function I_x(a, b) (continued fraction, modified Lentz) and its inverse by bisection + Newton, f64:
+// what statrs' Beta::inverse_cdf / scipy.stats.beta.ppf compute (scheduler.rs:247-272 calls the former).
+double betacf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
+    if (std::fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 500; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((a + m2 - 1.0) * (a + m2));
+        d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (a + b + m) * x / ((a + m2) * (a + m2 + 1.0));
+        d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (std::fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+double betai(double a, double b, double x) {
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const double lbt = std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log1p(-x);
+    if (x < (a + 1.0) / (a + b + 2.0)) return std::exp(lbt) * betacf(a, b, x) / a;
+    return 1.0 - std::exp(lbt) * betacf(b, a, 1.0 - x) / b;
+}
+double beta_ppf(double p, double a, double b) {
+    if (p <= 0.0) return 0.0;
+    if (p >= 1.0) return 1.0;
+    double lo = 0.0, hi = 1.0, x = 0.5;
+    for (int it = 0; it < 200; ++it) {
+        const double f = betai(a, b, x) - p;
+        if (f > 0.0) hi = x; else lo = x;
+        // Newton step from the density; kept only if it stays inside the bracket
+        const double lpdf = std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + (a - 1.0) * std::log(x) + (b - 1.0) * std::log1p(-x);
+        double xn = x - f / std::exp(lpdf);
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (std::fabs(xn - x) < 1e-15) { x = xn; break; }
+        x = xn;
+    }
+    return x;
+}
+std::vector<float> linspace_f32(float start, float end, int steps) {     // scheduler.rs:209-220
+    std::vector<float> v((size_t)(steps > 0 ? steps : 0));
+    if (steps == 1) v[0] = start;
+    else for (int i = 0; i < steps; ++i) v[i] = start + (end - start) * (float)i / (float)(steps - 1);
+    return v;
+}
+}  // namespace
+
+extern "C" int ltx_sched_set_timesteps_ex(const float* sigmas_in, int n, float mu, int use_mu, float shift,
+                                          float shift_terminal, int use_shift_terminal, int sigma_kind, int invert_sigmas,
+                                          float* sigmas_out, int64_t* timesteps_out) {
+    if (sigma_kind < 0 || sigma_kind > 3) LTX_FAIL(LTX_ERR_ARG, "ltx_sched_set_timesteps_ex: sigma_kind must be 0 (none), 1 (karras), 2 (exponential) or 3 (beta)");
+    LTX_TRY(ltx_sched_set_timesteps(sigmas_in, n, mu, use_mu, shift, shift_terminal, use_shift_terminal, sigmas_out, timesteps_out));
+    std::vector<float> s(sigmas_out, sigmas_out + n);
+    const float smin = s[n - 1], smax = s[0];
+    if (sigma_kind == 1) {                           // convert_to_karras (:222-235)
+        const float rho = 7.0f, mn = std::pow(smin, 1.0f / rho), mx = std::pow(smax, 1.0f / rho);
+        const std::vector<float> ramp = linspace_f32(0.0f, 1.0f, n);
+        for (int i = 0; i < n; ++i) s[i] = std::pow(mx + ramp[i] * (mn - mx), rho);
+    } else if (sigma_kind == 2) {                    // convert_to_exponential (:237-245)
+        const std::vector<float> logs = linspace_f32(std::log(smax), std::log(smin), n);
+        for (int i = 0; i < n; ++i) s[i] = std::exp(logs[i]);
+    } else if (sigma_kind == 3) {                    // convert_to_beta (:247-272), alpha = beta = 0.6 (:369)
+        const std::vector<float> lin = linspace_f32(0.0f, 1.0f, n);
+        for (int i = 0; i < n; ++i) {
+            const double t = 1.0 - (double)lin[i];
+            s[i] = (float)((double)smin + beta_ppf(t, 0.6, 0.6) * (double)(smax - smin));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (invert_sigmas) s[i] = 1.0f - s[i];
+        sigmas_out[i] = s[i];
+        if (timesteps_out) timesteps_out[i] = (int64_t)(s[i] * 1000.0f);
+    }
+    sigmas_out[n] = invert_sigmas ? 1.0f : 0.0f;     // terminal sigma (:389-399)
+    return LTX_OK;
+}
+
 // ---- PCG32 (deterministic_rng.rs) ----
 namespace {
 struct Pcg32 {

@@ -99,6 +99,7 @@ _SIGS = {
     "ltx_guidance_step": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp, _vp],
     "ltx_guidance_step_stochastic": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _vp, _vp, _vp],
     "ltx_sched_set_timesteps": [_vp, _i, _f, _i, _f, _f, _i, _vp, _vp],
+    "ltx_sched_set_timesteps_ex": [_vp, _i, _f, _i, _f, _f, _i, _i, _i, _vp, _vp],
     "ltx_calculate_shift": [_i, _i, _i, _f, _f],
     "ltx_pcg32_randn": [C.c_uint64, C.c_uint64, _sz, _vp],
     "ltx_pcg32_u32": [C.c_uint64, C.c_uint64, _sz, _vp],
@@ -611,10 +612,15 @@ def calculate_shift(seq_len: int, base_seq_len: int = 256, max_seq_len: int = 40
 class FlowMatchEulerDiscreteScheduler:
     """Scheduler trait (t2v_pipeline.rs:28-37) as implemented at scheduler.rs:646-668."""
 
-    def __init__(self, shift: float = 1.0, shift_terminal: Optional[float] = 0.1, stochastic_sampling: bool = False):
+    def __init__(self, shift: float = 1.0, shift_terminal: Optional[float] = 0.1, stochastic_sampling: bool = False,
+                 use_karras_sigmas: bool = False, use_exponential_sigmas: bool = False, use_beta_sigmas: bool = False, invert_sigmas: bool = False):
+        if int(use_karras_sigmas) + int(use_exponential_sigmas) + int(use_beta_sigmas) > 1:      # scheduler.rs:85-93
+            raise LtxError("Only one of use_beta_sigmas/use_exponential_sigmas/use_karras_sigmas can be enabled.")
         self.shift = shift
         self.shift_terminal = shift_terminal
         self.stochastic_sampling = stochastic_sampling
+        self.sigma_kind = 1 if use_karras_sigmas else (2 if use_exponential_sigmas else (3 if use_beta_sigmas else 0))
+        self.invert_sigmas = invert_sigmas
         self.sigmas: List[float] = []
         self.timesteps: List[int] = []
         self.step_index = 0
@@ -624,9 +630,9 @@ class FlowMatchEulerDiscreteScheduler:
         sin = _floats(sigmas)
         sout = (C.c_float * (n + 1))()
         tout = (C.c_int64 * n)()
-        _check(lib.ltx_sched_set_timesteps(sin, n, C.c_float(mu if mu is not None else 0.0), int(mu is not None),
-                                           C.c_float(self.shift), C.c_float(self.shift_terminal or 0.0),
-                                           int(self.shift_terminal is not None), sout, tout))
+        _check(lib.ltx_sched_set_timesteps_ex(sin, n, C.c_float(mu if mu is not None else 0.0), int(mu is not None),
+                                              C.c_float(self.shift), C.c_float(self.shift_terminal or 0.0),
+                                              int(self.shift_terminal is not None), self.sigma_kind, int(self.invert_sigmas), sout, tout))
         self.sigmas = list(sout)
         self.timesteps = list(tout)
         self.step_index = 0

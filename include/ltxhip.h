@@ -173,6 +173,14 @@ int ltx_guidance_step_stochastic(const void* text, const void* uncond, const voi
  * sigmas_in: n values (custom list or linspace(1, 1/n, n)); writes n+1 sigmas and n truncated timesteps. */
 int ltx_sched_set_timesteps(const float* sigmas_in, int n, float mu, int use_mu, float shift,
                             float shift_terminal, int use_shift_terminal, float* sigmas_out, int64_t* timesteps_out);
+/* The same with the remaining options of FlowMatchEulerDiscreteSchedulerConfig (scheduler.rs:30-33): sigma_kind 0 = none,
+ * 1 = use_karras_sigmas (convert_to_karras :222-235, rho 7), 2 = use_exponential_sigmas (:237-245), 3 = use_beta_sigmas
+ * (:247-272, alpha = beta = 0.6, the inverse CDF of the Beta distribution in f64), applied after the stretch (:363-370);
+ * invert_sigmas (:389-399): sigma -> 1 - sigma, timesteps from the inverted list, terminal sigma 1.  No preset of configs.rs
+ * enables either. */
+int ltx_sched_set_timesteps_ex(const float* sigmas_in, int n, float mu, int use_mu, float shift,
+                               float shift_terminal, int use_shift_terminal, int sigma_kind, int invert_sigmas,
+                               float* sigmas_out, int64_t* timesteps_out);
 float ltx_calculate_shift(int seq_len, int base_seq_len, int max_seq_len, float base_shift, float max_shift);
 /* Pcg32::new(seed, inc).randn(n) (utils/deterministic_rng.rs:11-81) into HOST memory */
 int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out_host);

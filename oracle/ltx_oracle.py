@@ -739,15 +739,20 @@ class SchedulerCfg:                   # configs.rs:101-121 common_scheduler_conf
     shift: float = 1.0
     shift_terminal: Optional[float] = 0.1
     stochastic_sampling: bool = False
+    use_karras_sigmas: bool = False   # scheduler.rs:30-32; at most one of the three (:85-93); no preset of configs.rs enables them
+    use_exponential_sigmas: bool = False
+    use_beta_sigmas: bool = False
+    invert_sigmas: bool = False       # scheduler.rs:389-399
 
 
 class FlowMatchEulerScheduler:
-    """FlowMatchEulerDiscreteScheduler restricted to the options the LTX presets
-    use (exponential time shift, optional stretch-to-terminal, no karras/exp/beta);
-    scheduler.rs:84-146, 172-207, 274-441, 495-595, 646-668.  All scalar math in
-    np.float32 like the Rust f32 code."""
+    """FlowMatchEulerDiscreteScheduler: exponential time shift, optional stretch-to-terminal, the karras / exponential /
+    beta sigma conversions and invert_sigmas; scheduler.rs:84-146, 172-272, 274-441, 495-595, 646-668.  All scalar math in
+    np.float32 like the Rust f32 code (convert_to_beta goes through f64, as the Rust does)."""
 
     def __init__(self, cfg: SchedulerCfg = SchedulerCfg()):
+        if int(cfg.use_karras_sigmas) + int(cfg.use_exponential_sigmas) + int(cfg.use_beta_sigmas) > 1:
+            raise ValueError("Only one of use_beta_sigmas/use_exponential_sigmas/use_karras_sigmas can be enabled.")   # :85-93
         self.cfg = cfg
         n = cfg.num_train_timesteps
         ts = np.arange(n, 0, -1, dtype=np.float32)
@@ -791,8 +796,30 @@ class FlowMatchEulerScheduler:
             one_minus_last = np.float32(1.0) - sig[-1]
             scale = one_minus_last / (np.float32(1.0) - np.float32(self.cfg.shift_terminal))
             sig = (np.float32(1.0) - (np.float32(1.0) - sig) / scale).astype(np.float32)
+        nsteps = len(sig)
+        if self.cfg.use_karras_sigmas:                              # convert_to_karras :222-235 (rho = 7)
+            smin, smax = np.float32(sig[-1]), np.float32(sig[0])
+            rho = np.float32(7.0)
+            ramp = self._linspace(0.0, 1.0, nsteps)
+            mn, mx = np.power(smin, np.float32(1.0) / rho, dtype=np.float32), np.power(smax, np.float32(1.0) / rho, dtype=np.float32)
+            sig = np.power((mx + ramp * (mn - mx)).astype(np.float32), rho, dtype=np.float32)
+        elif self.cfg.use_exponential_sigmas:                       # convert_to_exponential :237-245
+            smin, smax = np.float32(sig[-1]), np.float32(sig[0])
+            with np.errstate(divide="ignore"):
+                sig = np.exp(self._linspace(np.log(smax, dtype=np.float32), np.log(smin, dtype=np.float32), nsteps), dtype=np.float32)
+        elif self.cfg.use_beta_sigmas:                              # convert_to_beta :247-272 (alpha = beta = 0.6, statrs inverse_cdf = scipy ppf)
+            from scipy.stats import beta as _beta
+            smin, smax = np.float32(sig[-1]), np.float32(sig[0])
+            ts = 1.0 - self._linspace(0.0, 1.0, nsteps).astype(np.float64)
+            ppf = _beta.ppf(ts, 0.6, 0.6)
+            sig = (float(smin) + ppf * float(np.float32(smax - smin))).astype(np.float32)
         self.timesteps = (sig * np.float32(n)).astype(np.float32)
-        self.sigmas = np.concatenate([sig, np.zeros(1, np.float32)]).astype(np.float32)
+        if self.cfg.invert_sigmas:                                  # :389-399
+            sig = (np.float32(1.0) - sig).astype(np.float32)
+            self.timesteps = (sig * np.float32(n)).astype(np.float32)
+            self.sigmas = np.concatenate([sig, np.ones(1, np.float32)]).astype(np.float32)
+        else:
+            self.sigmas = np.concatenate([sig, np.zeros(1, np.float32)]).astype(np.float32)
         self.step_index = None
         return [int(x) for x in self.timesteps]                    # `as i64` truncation (:659)
 

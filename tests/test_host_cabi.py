@@ -135,3 +135,38 @@ def test_team_without_rccl_reports_unsupported_instead_of_crashing():
     assert r.returncode == 0, r.stderr
     rc, rc2, msg = r.stdout.strip().split(" ", 2)
     assert (rc, rc2) == ("4", "4") and "cannot load librccl.so" in msg and "librccl-missing" in msg, r.stdout
+
+
+@pytest.mark.parametrize("kind", ["karras", "exponential", "beta"])
+@pytest.mark.parametrize("invert", [False, True])
+def test_scheduler_sigma_conversions_match_the_oracle(hip, kind, invert):
+    """The options of FlowMatchEulerDiscreteSchedulerConfig no preset enables (scheduler.rs:30-33, 222-272, 363-370, 389-399):
+    use_karras_sigmas / use_exponential_sigmas / use_beta_sigmas (the inverse CDF of Beta(0.6, 0.6): statrs there, a continued
+    fraction + bisection here, scipy.stats.beta.ppf in the oracle) and invert_sigmas, through ltx_sched_set_timesteps_ex, on the
+    distilled list and on linspace schedules of three lengths, with and without mu / stretch."""
+    import numpy as np
+    import ltx_oracle as O
+    flags = {f"use_{kind}_sigmas": True}
+    for sig_in, mu, st in (([1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250], 1.3017, 0.1),
+                           (list(np.linspace(1.0, 1.0 / 30, 30, dtype=np.float32)), 0.5217, 0.1),
+                           (list(np.linspace(1.0, 1.0 / 8, 8, dtype=np.float32)), None, None),
+                           (list(np.linspace(1.0, 1.0 / 40, 40, dtype=np.float32)), 3.428, 0.1)):
+        ref = O.FlowMatchEulerScheduler(O.SchedulerCfg(shift=1.0, shift_terminal=st, invert_sigmas=invert, **flags))
+        want_t = ref.set_timesteps(len(sig_in), sigmas=sig_in, mu=mu)
+        got = hip.FlowMatchEulerDiscreteScheduler(shift=1.0, shift_terminal=st, invert_sigmas=invert, **flags)
+        got_t = got.set_timesteps(sig_in, mu)
+        assert len(got.sigmas) == len(sig_in) + 1 and got.sigmas[-1] == (1.0 if invert else 0.0)
+        assert np.abs(np.asarray(got.sigmas, dtype=np.float64) - ref.sigmas.astype(np.float64)).max() < 2e-6, (kind, invert, mu)
+        assert all(abs(a - b) <= 1 for a, b in zip(got_t, want_t))             # truncation of values within 2e-3 of each other
+    with pytest.raises(hip.LtxError):
+        hip.FlowMatchEulerDiscreteScheduler(use_karras_sigmas=True, use_beta_sigmas=True)
+
+
+def test_scheduler_beta_ppf_known_answers(hip):
+    """Beta(0.6, 0.6) is symmetric: ppf(0.5) = 0.5, ppf(1 - t) = 1 - ppf(t); ends 0 and 1 (scheduler.rs:260-270 evaluates
+    1 - linspace(0, 1, n), i.e. both ends)."""
+    s = hip.FlowMatchEulerDiscreteScheduler(shift=1.0, shift_terminal=None, use_beta_sigmas=True)
+    s.set_timesteps([1.0, 0.75, 0.5, 0.25, 0.0625], None)
+    smax, smin = s.sigmas[0], s.sigmas[4]
+    p = [(v - smin) / (smax - smin) for v in s.sigmas[:5]]
+    assert p[0] == 1.0 and p[4] == 0.0 and abs(p[2] - 0.5) < 1e-6 and abs(p[1] + p[3] - 1.0) < 1e-6
