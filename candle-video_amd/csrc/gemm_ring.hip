@@ -1,0 +1,288 @@
+// Small-M linear layers (C1's 384 video tokens, the 128 text rows of the context projections and of the T5 encoder):
+// bf16 GEMM on small output tiles with a DEEP ring of LDS stages (plan family "ring:*" of gemm_big.hip's plan measurement).
+//
+// Why its own kernel.  At M <= 512 a DiT linear layer has fewer outputs than 256 CUs x one 128 x 128 tile, so every tile shape
+// of gemm_big / gemm_asm16 leaves CUs idle or runs a handful of K-steps per block, and their two-stage pipelines (the loads of
+// step t+1 in flight while step t is multiplied) then pay one memory latency per K-step: 0.4-0.75 us per step whatever it
+// computes (tools/small_m_probe.py; docs/lab_notes.md R4.8 - qkv at M = 384 ran 25 us against a 7 us floor).  What bounds such
+// a shape is the per-CU L2 -> LDS path (~64 B/clk): a CU that owns a BM x BN tile moves (BM + BN) * K * 2 bytes through it.
+// So: tiles small enough that the grid is ONE round of ~256 blocks (96 x 96 / 96 x 128 / 96 x 64 at M = 384), one block per CU,
+// and NS = 5..8 stages of (BM + BN) * 128 B in the 160 KiB of LDS, NS - 1 of them in flight, with a COUNTED vmcnt at the one
+// barrier per K-step - the step's loads were issued NS - 1 steps earlier, so the latency is paid once per block, not per step.
+//
+//   * 256 threads = 4 waves (one per SIMD) as 2 (M) x 2 (N), wave tile (BM/2) x (BN/2) of v_mfma_f32_16x16x32_bf16;
+//   * operands HBM/L2 -> LDS by buffer_load ... lds pieces of 8 rows x 128 B, same swizzle as gemm_big (16-byte chunk ^
+//     ((row >> 1) & 7) on the source side and on the fragment reads); every wave issues (BM + BN) / 32 pieces per stage, dead
+//     stages (past the K range) are out-of-range pieces (zeros, no memory traffic), so the vmcnt arithmetic is static;
+//   * fragments are read one k half ahead into a second register set (conv_halo.hip's pipelined form), the barrier sits between
+//     the two halves of a step;
+//   * K partition and summation order are gemm_big's: the shape-only split factor (ltx_gemm_split_factor), K-ranges
+//     [part * nk / sf, (part + 1) * nk / sf), slabs + ticket, canonical ((s0 + s1) + s2) + ... by the last arriver; k ascending
+//     inside a range with the same MFMA - so a "ring:*" plan returns the same bits as every other plan of the shape
+//     (tests/test_gpu_determinism.py, tests/test_gpu_gemm_ring.py);
+//   * block order: XCD x gets a contiguous run of (column tile, part, row tile) triples, row tile fastest - the blocks that share
+//     a weight tile or an activation K-range run on one XCD and meet in its L2, the weight matrix leaves HBM once.
+#include <atomic>
+#include <cstring>
+#include "gemm_common.h"
+
+#ifndef RING_ABL
+#define RING_ABL 0      // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads, 4 loads all hit one line set
+#endif
+
+namespace {
+
+constexpr int ROWB = 128;
+constexpr uint32_t OOB = 0x80000000u;
+__device__ __forceinline__ int swz_r(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int I, int N, typename F> __device__ __forceinline__ void sfor_r(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor_r<I + 1, N>(f); }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
+
+template <int BM, int BN, int NS, int EPI>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16, NM = FM * FN;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int PA = BM / 32, PW = BN / 32, P = PA + PW;      // LDS-DMA pieces per wave per stage (activation, weight)
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile / wave layout");
+    static_assert(NS >= 3 && (NS - 1) * P <= 63 && NS * STAGE <= 160 * 1024, "ring depth: vmcnt is 6 bits, LDS is 160 KiB");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (g.M + BM - 1) / BM, sf = g.sk_sf;
+    // block -> (column tile, part, row tile): XCD-contiguous runs (blocks b and b + 8 share an XCD), row tile fastest
+    int bid = blockIdx.x;
+    {
+        const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int mt = bid % ntm, rest = bid / ntm, part = rest % sf, nt = rest / sf;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = (g.K + 63) / 64;
+    const int kt0 = sf > 1 ? (int)((int64_t)part * nk / sf) : 0, kt1 = sf > 1 ? (int)((int64_t)(part + 1) * nk / sf) : nk;
+    const int n = kt1 - kt0;
+
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
+    // piece j of this wave fills rows 8 * (4 j + wave) .. + 7 of the activation (j < PA) or weight image of a stage; a lane writes
+    // 16 bytes: row lr = lane >> 3, physical chunk pc = lane & 7 holds logical chunk pc ^ ((row >> 1) & 7)
+    const int lr = lane >> 3, pc = lane & 7;
+    uint32_t voff[P]; int chunk[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const bool isa = j < PA;
+        const int row = 8 * (4 * (isa ? j : j - PA) + wave) + lr;
+        chunk[j] = pc ^ ((row >> 1) & 7);
+        if (isa) { int m = m0 + row; if (m > g.M - 1) m = g.M - 1; voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk[j] * 8) * 2u; }
+        else { int c = n0 + row; if (c > g.N - 1) c = g.N - 1; voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk[j] * 8) * 2u; }
+    }
+    const bool ktail = (g.K & 63) != 0;
+    auto issue = [&](int i, int slot) {                             // stage i of this block's K range into ring slot i % NS
+        const bool live = i < n;
+        const int kk = kt0 + i;
+        unsigned char* base = ring_smem + slot * STAGE;
+        const uint32_t soff = live ? (uint32_t)kk * 128u : 0u;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const bool isa = j < PA;
+            bool ok = live;
+            if (ktail) ok = ok && kk * 64 + chunk[j] * 8 < g.K;
+            uint32_t vo = ok ? voff[j] : OOB;
+#if RING_ABL & 4
+            vo = lane * 16;
+#endif
+            unsigned char* dst = base + (isa ? 0 : BM * ROWB) + (4 * (isa ? j : j - PA) + wave) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isa ? ra : rw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, (int)soff, 0, 0);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    Chunk16 w0[FN], a0[FM], w1[FN], a1[FM];
+    bool first = true; (void)first;
+    auto read_frag = [&](int slot, int kb, auto idx_tag, Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
+        constexpr int idx = decltype(idx_tag)::value;
+#if RING_ABL & 2
+        if (!first) return;
+#endif
+        const unsigned char* As = ring_smem + slot * STAGE;
+        if constexpr (idx < FN) wf[idx].u = *reinterpret_cast<const u32x4*>(As + BM * ROWB + swz_r(wn * WN + idx * 16 + frow, kb * 4 + fq));
+        else af[idx - FN].u = *reinterpret_cast<const u32x4*>(As + swz_r(wm * WM + (idx - FN) * 16 + frow, kb * 4 + fq));
+    };
+    auto mma = [&](auto m_tag, const Chunk16 (&wf)[FN], const Chunk16 (&af)[FM]) {
+        constexpr int mi = decltype(m_tag)::value;
+#if !(RING_ABL & 1)
+        acc[mi / FN][mi % FN] = Mma<bf16_t>::run(wf[mi % FN], af[mi / FN], acc[mi / FN][mi % FN]);
+#endif
+    };
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) issue(s, s);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NS - 1) * P) : "memory");      // stage 0 has landed in every wave
+    sfor_r<0, FN + FM>([&](auto t) { read_frag(0, 0, t, w0, a0); });
+    // step i: [reads of (i, k half 1) | MFMAs of half 0]  barrier: stage i + 1 landed, slot of stage i free
+    //         [stage i + NS issued into that slot | reads of (i + 1, half 0) | MFMAs of half 1]
+    int slot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;
+        first = false;
+        sfor_r<0, (NM > FN + FM ? NM : FN + FM)>([&](auto t) {
+            constexpr int k = decltype(t)::value;
+            if constexpr (k < FN + FM) read_frag(slot, 1, t, w1, a1);
+            if constexpr (k < NM) mma(t, w0, a0);
+        });
+        // a raw barrier (__syncthreads() would add a fence, i.e. vmcnt(0)); lgkmcnt(0): this wave's reads of slot i % NS are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
+        issue(i + NS, slot);
+        sfor_r<0, (NM > FN + FM ? NM : FN + FM)>([&](auto t) {
+            constexpr int k = decltype(t)::value;
+            if constexpr (k < FN + FM) read_frag(nslot, 0, t, w0, a0);
+            if constexpr (k < NM) mma(t, w1, a1);
+        });
+        slot = nslot;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the dead stages' zero fills; every wave is out of the ring
+
+    if (sf > 1) {
+        // In-launch reduction of a tile's parts (gemm_big.hip's protocol and order): f32 slabs, a ticket, the last arriver adds
+        // ((s0 + s1) + s2) + ... and runs the epilogue
+        constexpr int SLAB = BM * BN;
+        const int tt = nt * ntm + mt;
+        float* base = g.sk_ws + (int64_t)tt * sf * SLAB;
+        float* slab = base + (int64_t)part * SLAB;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) *reinterpret_cast<f32x4*>(slab + ((fm * FN + fn) * 256 + tid) * 4) = acc[fm][fn];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(ring_smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(g.sk_cnt + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)sf - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g.sk_cnt + tt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // back to zero for the next launch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        const bool reread_own = sf > 2 && part != 0;
+        if (reread_own) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = *reinterpret_cast<const f32x4*>(base + ((fm * FN + fn) * 256 + tid) * 4);
+        }
+        for (int p = (reread_own || part == 0) ? 1 : 0; p < sf; ++p) {
+            if (p == part && !reread_own) continue;
+            const float* other = base + (int64_t)p * SLAB;
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) acc[fm][fn] += *reinterpret_cast<const f32x4*>(other + ((fm * FN + fn) * 256 + tid) * 4);
+        }
+    }
+
+    // D = Wfrag x Afrag: a lane holds 4 consecutive output columns of one row (gemm_common.h epilogues)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m0 + wm * WM + fm * 16 + frow;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+            if (nb >= g.N) continue;
+            float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
+            epilogue<bf16_t, EPI>(g, m, nb, v);
+        }
+    }
+}
+
+struct RingTile { int bm, bn, ns; const char* name; };
+// ns: stages that fit 160 KiB (at most 8: beyond that the ring holds more than any latency)
+const RingTile kRing[] = {
+    {96, 64, 8, "ring:96x64"}, {96, 96, 6, "ring:96x96"}, {96, 128, 5, "ring:96x128"}, {64, 64, 8, "ring:64x64"},
+    {64, 128, 6, "ring:64x128"}, {128, 64, 6, "ring:128x64"}, {128, 128, 5, "ring:128x128"}, {128, 96, 5, "ring:128x96"},
+};
+constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
+
+template <int BM, int BN, int NS, int EPI>
+int launch_ring(const GemmArgs& g, hipStream_t s) {
+    constexpr int smem = NS * (BM + BN) * ROWB;
+    static std::atomic<unsigned long long> attr_devs{0};
+    auto kern = gemm_ring_kernel<BM, BN, NS, EPI>;
+    LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
+    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+    GemmArgs ga = g;
+    LTX_TRY(ltx_gemm_split_workspace(&ga, tiles, BM, BN, s));
+    ltx_prof_kernel(LTX_PROFK_GEMM_RING);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)(tiles * ga.sk_sf)), dim3(256), smem, s, ga);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+template <int BM, int BN, int NS>
+int launch_ring_epi(const GemmArgs& g, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS>(g, s);
+        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU>(g, s);
+        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID>(g, s);
+        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID>(g, s);
+    }
+    LTX_FAIL(LTX_ERR_ARG, "gemm_ring: bad epilogue");
+}
+}  // namespace
+
+int ltx_gemm_ring_tiles() { return kNumRing; }
+const char* ltx_gemm_ring_tile_name(int i) { return i >= 0 && i < kNumRing ? kRing[i].name : ""; }
+int ltx_gemm_ring_tile_bm(int i) { return i >= 0 && i < kNumRing ? kRing[i].bm : 1; }
+int ltx_gemm_ring_tile_bn(int i) { return i >= 0 && i < kNumRing ? kRing[i].bn : 1; }
+
+// Linear layers of at most 2048 rows whose operands the 32-bit buffer offsets reach (gemm_big's own bound), K in whole 16-byte
+// chunks, 4-column output groups inside or outside N as a whole.
+bool ltx_gemm_ring_fits(const GemmArgs& g, int epi) {
+    const char* e = getenv("LTX_GEMM_RING");
+    if (e && e[0] == '0') return false;
+    if (g.conv || g.pn_on || g.M < 1 || g.M > 2048 || g.N < 32 || g.N % 4 || g.K % 8 || g.lda % 8) return false;
+    if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
+    return ltx_gemm_big_fits(g);
+}
+
+int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s) {
+    if (!ltx_gemm_ring_fits(g, epi)) LTX_FAIL(LTX_ERR_ARG, "gemm_ring: shape not eligible");
+    switch (tile) {
+        case 0: return launch_ring_epi<96, 64, 8>(g, epi, s);
+        case 1: return launch_ring_epi<96, 96, 6>(g, epi, s);
+        case 2: return launch_ring_epi<96, 128, 5>(g, epi, s);
+        case 3: return launch_ring_epi<64, 64, 8>(g, epi, s);
+        case 4: return launch_ring_epi<64, 128, 6>(g, epi, s);
+        case 5: return launch_ring_epi<128, 64, 6>(g, epi, s);
+        case 6: return launch_ring_epi<128, 128, 5>(g, epi, s);
+        case 7: return launch_ring_epi<128, 96, 5>(g, epi, s);
+    }
+    LTX_FAIL(LTX_ERR_ARG, "gemm_ring: unsupported tile");
+}
+
+// Static choice (no measured plan): the tile whose grid wastes the least of whole rounds of 256 blocks, larger tiles on ties.
+int ltx_gemm_ring_pick_tile(const GemmArgs& g) {
+    const int sf = ltx_gemm_split_factor(g);
+    double best = 1e30; int bi = 1;
+    for (int i = 0; i < kNumRing; ++i) {
+        const int64_t blocks = (int64_t)cdiv(g.M, kRing[i].bm) * cdiv(g.N, kRing[i].bn) * sf;
+        // a block's time ~ its bytes through the CU's load path, (bm + bn) per K element
+        const double cost = (double)cdiv64(blocks, 256) * (double)(kRing[i].bm + kRing[i].bn);
+        if (cost < best * 0.999) { best = cost; bi = i; }
+    }
+    return bi;
+}

@@ -13,7 +13,7 @@ enum { LTX_PROF_GEMM = 0, LTX_PROF_CONV = 1, LTX_PROF_ATTN_SELF = 2, LTX_PROF_AT
 bool ltx_prof_begin(int kind, double work, hipStream_t s, void** token);   // work: algorithmic flops (or bytes for ROWNORM)
 void ltx_prof_end(void* token, hipStream_t s);
 // which KERNEL served the launch being timed (set by the launcher that actually enqueues it; read by ltx_prof_end)
-enum { LTX_PROFK_GEMM128 = 0, LTX_PROFK_GEMM_BIG = 1, LTX_PROFK_GEMM_P8 = 2, LTX_PROFK_CONV_HALO = 3, LTX_PROFK_GEMM_ASM = 4, LTX_PROFK_GEMM_ASM16 = 5, LTX_PROFK_N = 6 };
+enum { LTX_PROFK_GEMM128 = 0, LTX_PROFK_GEMM_BIG = 1, LTX_PROFK_GEMM_P8 = 2, LTX_PROFK_CONV_HALO = 3, LTX_PROFK_GEMM_ASM = 4, LTX_PROFK_GEMM_ASM16 = 5, LTX_PROFK_GEMM_RING = 6, LTX_PROFK_N = 7 };
 void ltx_prof_kernel(int which);
 // Kernel-level start / stop events for the launch being timed (the dispatch packet's own timestamps, what rocprofv3's kernel
 // trace reports): stream-level hipEventRecord brackets also count the dispatch latency and the end-of-kernel release that the
@@ -86,6 +86,16 @@ int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile ta
 int ltx_gemm_p8_choice(const GemmArgs& g);  // gemm_p8.hip: phase-interleaved 256-row kernel; returns BN (256/128) or 0
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s);
 bool ltx_gemm_p8_fits(const GemmArgs& g);
+// gemm_ring.hip: small-M linear layers on small tiles with a deep ring of LDS stages (plan family ring:*); same K partition and
+// summation order as gemm_big (the split workspace below is gemm_big's: slabs + ticket counters per (device, stream))
+bool ltx_gemm_ring_fits(const GemmArgs& g, int epi);
+int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s);
+int ltx_gemm_ring_tiles();
+const char* ltx_gemm_ring_tile_name(int i);
+int ltx_gemm_ring_tile_bm(int i);
+int ltx_gemm_ring_tile_bn(int i);
+int ltx_gemm_ring_pick_tile(const GemmArgs& g);
+int ltx_gemm_split_workspace(GemmArgs* g, int tiles, int bm, int bn, hipStream_t s);   // sets sk_sf / sk_full = 0 / sk_ws / sk_cnt
 bool ltx_gemm_big_fits(const GemmArgs& g);   // gemm_big.hip: every span its 32-bit buffer offsets address stays below 2 GiB
 // conv_halo.hip: 3x3x3 conv with the activation patch + rim staged once per nine in-plane taps; bn = 128 / 256
 bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn);

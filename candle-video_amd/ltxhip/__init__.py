@@ -1103,7 +1103,7 @@ def prof_report(kind: int):
     return ms.value, work.value, cnt.value
 
 
-PROF_KERNELS = ("gemm_kernel (128 x 128)", "gemm_big_kernel", "gemm_p8_kernel", "conv_halo_kernel", "gemm_asm_kernel (32x32x16)", "gemm_asm16_kernel")
+PROF_KERNELS = ("gemm_kernel (128 x 128)", "gemm_big_kernel", "gemm_p8_kernel", "conv_halo_kernel", "gemm_asm_kernel (32x32x16)", "gemm_asm16_kernel", "gemm_ring_kernel")
 
 
 def prof_report_kernel(kind: int, kernel: int):
