@@ -487,7 +487,7 @@ bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi) {
     if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
     if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
     if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
-    return g.M >= 512 && g.N >= 512;
+    return g.M > 512 && g.N >= 512;                       // (up to 512 rows: gemm_ring.hip's tiles, never split)
 }
 
 // LTX_GEMM_ASM forces the family for every shape it serves (tests, A/B): "1" the 32x32x16 loop, "16" the 16x16x32 loop.

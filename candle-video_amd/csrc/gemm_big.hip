@@ -437,9 +437,21 @@ int ltx_gemm_split_factor(const GemmArgs& g) {
     const char* e = getenv("LTX_GEMM_SPLITK");
     if (e && e[0] == '0') return 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
+    if (const char* f = getenv("LTX_GEMM_SPLIT_FORCE")) {          // measurement aid (tools/ring_probe.py): this many K-ranges for every linear layer
+        const int sf = atoi(f);
+        if (!g.conv && sf >= 1 && sf <= 8 && nk / sf >= 1) return sf;
+    }
     static const int max_sf = [] { const char* v = getenv("LTX_GEMM_SPLIT_MAX"); return v ? atoi(v) : 8; }();
     static const int min_k = [] { const char* v = getenv("LTX_GEMM_SPLIT_MINK"); return v ? atoi(v) : 8; }();
     static const bool small_rule = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALLM"); return !(v && v[0] == '0'); }();
+    // Linear layers of at most 512 rows (round 4, gemm_ring.hip): never split.  On the deep-ring tiles a K-range costs 0.2-0.3 us
+    // per step where the two-stage tiles paid 0.5, and a grid of 96 x 32 / 64 x 32 tiles fills the chip without cutting K, while
+    // the in-launch reduction costs 5 us for two parts and 8 for four (slab store, agent-scope release + ticket + acquire, the
+    // last arriver re-reading the slabs: tools/ring_trace.py).  Measured over 14 shapes with M = 128 .. 512
+    // (tools/ring_split_probe.py, profiles/r4_ring_split_probe.jsonl): unsplit wins 12, ties one, loses 12 % on one (T5's wo,
+    // K = 10240).  A function of (M, N, K) alone, like the rest of this rule.  LTX_GEMM_SPLIT_RING=0: the round 3 rule below.
+    static const bool ring_rule = [] { const char* v = getenv("LTX_GEMM_SPLIT_RING"); return !(v && v[0] == '0'); }();
+    if (!g.conv && g.M <= 512 && g.N >= 32 && g.N % 4 == 0 && g.K % 8 == 0 && ring_rule) return 1;
     if (!g.conv && g.M <= 1536 && small_rule) {
         // Small-M linear layers (C1's 384 tokens, the 128 text rows; round 3, tools/small_m_probe.py): these are latency-bound
         // weight streams - a K-step costs 0.4-0.75 us whatever it computes - and the in-launch reduction grows faster than
@@ -827,8 +839,12 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     const char* xr = getenv("LTX_XCD_REMAP");
     g.xcd_remap = xr ? (xr[0] == '1') : 1;
     if (g.pn_on) return ltx_launch_conv_halo(g, epi, g.N, s);      // fused output norm: only that kernel's wide epilogue carries it
+    if (const char* rt = getenv("LTX_GEMM_RING_TILE")) {   // "ring:96x96" ...: force a gemm_ring.hip tile where the shape is eligible (tests, A/B)
+        const int plan = plan_from_name(rt);
+        if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
+    }
     const bool split_shape = ltx_gemm_split_factor(g) > 1;
-    if (split_shape) {                                     // gemm_big tiles only: one K partition whatever the plan
+    if (split_shape) {                                     // gemm_big tiles (or gemm_ring's, which keep their K partition): one partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
         if (!getenv("LTX_GEMM_TILE")) (void)cached_or_tuned_plan(g, s, &plan);
         if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
@@ -848,6 +864,9 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     const int p8 = ltx_gemm_p8_choice(g);
     if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
     int plan = ltx_gemm_big_pick_tile(g.M, g.N);
+    // static model, small M: the deep-ring tile whose grid wastes the least of a round (these shapes are never split, see
+    // ltx_gemm_split_factor: a gemm_big tile would leave most CUs idle)
+    if (!g.conv && g.M <= 512 && ltx_gemm_ring_fits(g, epi)) plan = kPlanRing + ltx_gemm_ring_pick_tile(g);
     {   // static model (no measured plan: LTX_GEMM_TUNE=0 / ltx_set_autotune(0) without a plan file): the large linear layers take
         // the one-wave-per-SIMD kernel too, tile by whole rounds x tile area (it won every such shape that was measured)
         const char* a16 = getenv("LTX_GEMM_ASM16");

@@ -40,16 +40,27 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor_r(F&& f
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
+#ifdef RING_TRACE       // per-block phase stamps (100 MHz wall clock) of the last launch: tools/ring_trace.py
+__device__ unsigned g_ring_trace[1024 * 8];
+#define RSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ring_trace[blockIdx.x * 8 + (i)] = (unsigned)wall_clock64(); } while (0)
+#else
+#define RSTAMP(i)
+#endif
 
-template <int BM, int BN, int NS, int EPI>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
+template <int BM, int BN, int NS, int EPI, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmArgs g) {
+    RSTAMP(0);
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16, NM = FM * FN;
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int PA = BM / 32, PW = BN / 32, P = PA + PW;      // LDS-DMA pieces per wave per stage (activation, weight)
+    constexpr int PA = BM / 32, PW = BN / 32, P = PA + PW;      // LDS-DMA pieces per issuing wave per stage (activation, weight)
+    constexpr int NSLOT = NM > FN + FM ? (NM > P ? NM : P) : (FN + FM > P ? FN + FM : P);      // instruction slots of a k half
     static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile / wave layout");
     static_assert(NS >= 3 && (NS - 1) * P <= 63 && NS * STAGE <= 160 * 1024, "ring depth: vmcnt is 6 bits, LDS is 160 KiB");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // SPEC: waves 0..3 multiply (one per SIMD), waves 4..7 (their SIMD partners) do nothing but feed the ring - a wave that
+    // stalls at the issue of an LDS-DMA piece (the CU's one load path takes 16 cycles per piece) then stalls no MFMA
+    const bool producer = SPEC && wave >= 4;
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
     const int ntm = (g.M + BM - 1) / BM, sf = g.sk_sf;
     // block -> (column tile, part, row tile): XCD-contiguous runs (blocks b and b + 8 share an XCD), row tile fastest
     int bid = blockIdx.x;
@@ -67,45 +78,64 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
-    // piece j of this wave fills rows 8 * (4 j + wave) .. + 7 of the activation (j < PA) or weight image of a stage; a lane writes
-    // 16 bytes: row lr = lane >> 3, physical chunk pc = lane & 7 holds logical chunk pc ^ ((row >> 1) & 7)
+    // piece j of issuing wave cw fills rows 8 * (4 j + cw) .. + 7 of the activation (j < PA) or weight image of a stage; a lane
+    // writes 16 bytes: row lr = lane >> 3, physical chunk pc = lane & 7 holds logical chunk pc ^ ((row >> 1) & 7)
     const int lr = lane >> 3, pc = lane & 7;
-    uint32_t voff[P]; int chunk[P];
+    uint32_t voff[P]; int klim[P];                                  // klim: first K position at which the lane's 16-byte chunk lies outside K
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const bool isa = j < PA;
-        const int row = 8 * (4 * (isa ? j : j - PA) + wave) + lr;
-        chunk[j] = pc ^ ((row >> 1) & 7);
-        if (isa) { int m = m0 + row; if (m > g.M - 1) m = g.M - 1; voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk[j] * 8) * 2u; }
-        else { int c = n0 + row; if (c > g.N - 1) c = g.N - 1; voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk[j] * 8) * 2u; }
+        const int row = 8 * (4 * (isa ? j : j - PA) + cw) + lr;
+        const int chunk = pc ^ ((row >> 1) & 7);
+        klim[j] = g.K - chunk * 8;
+        if (isa) { int m = m0 + row; if (m > g.M - 1) m = g.M - 1; voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk * 8) * 2u; }
+        else { int c = n0 + row; if (c > g.N - 1) c = g.N - 1; voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk * 8) * 2u; }
     }
-    const bool ktail = (g.K & 63) != 0;
-    auto issue = [&](int i, int slot) {                             // stage i of this block's K range into ring slot i % NS
-        const bool live = i < n;
-        const int kk = kt0 + i;
-        unsigned char* base = ring_smem + slot * STAGE;
-        const uint32_t soff = live ? (uint32_t)kk * 128u : 0u;
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const bool isa = j < PA;
-            bool ok = live;
-            if (ktail) ok = ok && kk * 64 + chunk[j] * 8 < g.K;
-            uint32_t vo = ok ? voff[j] : OOB;
+    auto issue_piece = [&](int kpos, uint32_t soff, unsigned char* base, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        constexpr bool isa = j < PA;
+        uint32_t vo = kpos < klim[j] ? voff[j] : OOB;
 #if RING_ABL & 4
-            vo = lane * 16;
+        vo = lane * 16;
 #endif
-            unsigned char* dst = base + (isa ? 0 : BM * ROWB) + (4 * (isa ? j : j - PA) + wave) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isa ? ra : rw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, (int)soff, 0, 0);
-        }
+        unsigned char* dst = base + (isa ? 0 : BM * ROWB) + (4 * (isa ? j : j - PA) + cw) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isa ? ra : rw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, (int)soff, 0, 0);
+    };
+    auto issue = [&](int i, int slot) {                             // stage i of this block's K range into ring slot `slot`, all pieces
+        const int kpos = i < n ? (kt0 + i) * 64 : 0x40000000;       // a dead stage lies beyond every klim
+        const uint32_t soff = i < n ? (uint32_t)(kt0 + i) * 128u : 0u;
+        sfor_r<0, P>([&](auto j) { issue_piece(kpos, soff, ring_smem + slot * STAGE, j); });
     };
 
     f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int frow = lane & 15, fq = lane >> 4;
+    // epilogue operands of this lane's outputs, fetched BEFORE the first LDS-DMA piece (loads return in order, so the counted
+    // vmcnt waits below cover them) instead of after the K loop, where their latency was in nobody's shadow
+    constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
+    constexpr bool HAS_G = EPI == EPI_GATE_RESID;
+    u32x2 pbias[FN], presid[HAS_R ? FM : 1][HAS_R ? FN : 1]; f32x4 pgate[HAS_G ? FM : 1][HAS_G ? FN : 1];
+    if (!producer) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            int nb = n0 + wn * WN + fn * 16 + 4 * fq; if (nb > g.N - 4) nb = g.N - 4;
+            pbias[fn] = g.bias ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.bias) + nb) : (u32x2){0u, 0u};
+        }
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                int m = m0 + wm * WM + fm * 16 + frow; if (m > g.M - 1) m = g.M - 1;
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    int nb = n0 + wn * WN + fn * 16 + 4 * fq; if (nb > g.N - 4) nb = g.N - 4;
+                    presid[fm][fn] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m * g.ldr + nb);
+                    if constexpr (HAS_G) pgate[fm][fn] = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(m / g.rows_per_batch) * g.gate_stride + nb);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");           // (!SPEC) these loads stay in front of the ring's pieces: the vmcnt arithmetic counts on it
+    }
+    (void)pgate;
+
     Chunk16 w0[FN], a0[FM], w1[FN], a1[FM];
     bool first = true; (void)first;
     auto read_frag = [&](int slot, int kb, auto idx_tag, Chunk16 (&wf)[FN], Chunk16 (&af)[FM]) {
@@ -117,39 +147,77 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
         if constexpr (idx < FN) wf[idx].u = *reinterpret_cast<const u32x4*>(As + BM * ROWB + swz_r(wn * WN + idx * 16 + frow, kb * 4 + fq));
         else af[idx - FN].u = *reinterpret_cast<const u32x4*>(As + swz_r(wm * WM + (idx - FN) * 16 + frow, kb * 4 + fq));
     };
+    auto mfma = [](f32x4& c, const Chunk16& w, const Chunk16& a_) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w.u), "v"(a_.u));
+    };
     auto mma = [&](auto m_tag, const Chunk16 (&wf)[FN], const Chunk16 (&af)[FM]) {
         constexpr int mi = decltype(m_tag)::value;
 #if !(RING_ABL & 1)
-        acc[mi / FN][mi % FN] = Mma<bf16_t>::run(wf[mi % FN], af[mi / FN], acc[mi / FN][mi % FN]);
+        // in place in the AGPR half of the register file: left to itself hipcc renames the accumulators from MFMA to MFMA and
+        // moves them back at the loop edge (conv_halo.hip)
+        mfma(acc[mi / FN][mi % FN], wf[mi % FN], af[mi / FN]);
 #endif
     };
 
+    // One barrier per K-step, between its two k halves.  At the barrier of step i: stage i + 1 has landed (every issuing wave
+    // waited for its own pieces: all but the NS - 2 youngest stages), and every multiplying wave has finished reading slot
+    // i % NS (lgkmcnt(0)), which is then refilled with stage i + NS.
+    if (producer) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) issue(s, s);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NS - 1) * P) : "memory");      // stage 0 has landed in every wave
-    sfor_r<0, FN + FM>([&](auto t) { read_frag(0, 0, t, w0, a0); });
-    // step i: [reads of (i, k half 1) | MFMAs of half 0]  barrier: stage i + 1 landed, slot of stage i free
-    //         [stage i + NS issued into that slot | reads of (i + 1, half 0) | MFMAs of half 1]
-    int slot = 0;
-    for (int i = 0; i < n; ++i) {
-        const int nslot = slot + 1 == NS ? 0 : slot + 1;
-        first = false;
-        sfor_r<0, (NM > FN + FM ? NM : FN + FM)>([&](auto t) {
-            constexpr int k = decltype(t)::value;
-            if constexpr (k < FN + FM) read_frag(slot, 1, t, w1, a1);
-            if constexpr (k < NM) mma(t, w0, a0);
-        });
-        // a raw barrier (__syncthreads() would add a fence, i.e. vmcnt(0)); lgkmcnt(0): this wave's reads of slot i % NS are done
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
-        issue(i + NS, slot);
-        sfor_r<0, (NM > FN + FM ? NM : FN + FM)>([&](auto t) {
-            constexpr int k = decltype(t)::value;
-            if constexpr (k < FN + FM) read_frag(nslot, 0, t, w0, a0);
-            if constexpr (k < NM) mma(t, w1, a1);
-        });
-        slot = nslot;
+        for (int s = 0; s < NS; ++s) issue(s, s);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NS - 1) * P) : "memory");
+        int slot = 0;
+        for (int i = 0; i < n; ++i) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
+            issue(i + NS, slot);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the dead stages' zero fills have landed: the ring is quiet
+    } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (!SPEC) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) issue(s, s);
+        }
+        RSTAMP(1);
+        if constexpr (SPEC) asm volatile("s_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NS - 1) * P) : "memory");      // stage 0 has landed in every wave
+        RSTAMP(2);
+        sfor_r<0, FN + FM>([&](auto t) { read_frag(0, 0, t, w0, a0); });
+        int slot = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nslot = slot + 1 == NS ? 0 : slot + 1;
+            first = false;
+            // everything in program order, pinned by sched_barrier: one fragment read (of the NEXT half) in front of each MFMA
+            sfor_r<0, NSLOT>([&](auto t) {
+                constexpr int k = decltype(t)::value;
+                if constexpr (k < FN + FM) read_frag(slot, 1, t, w1, a1);
+                if constexpr (k < NM) mma(t, w0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // a raw barrier (__syncthreads() would add a fence, i.e. vmcnt(0))
+            if constexpr (SPEC) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int kpos = i + NS < n ? (kt0 + i + NS) * 64 : 0x40000000;
+            const uint32_t soff = i + NS < n ? (uint32_t)(kt0 + i + NS) * 128u : 0u;
+            unsigned char* const base = ring_smem + slot * STAGE;
+            sfor_r<0, NSLOT>([&](auto t) {                          // (!SPEC) stage i + NS into the slot just freed, its pieces spread over the MFMAs
+                constexpr int k = decltype(t)::value;
+                if constexpr (k < FN + FM) read_frag(nslot, 0, t, w0, a0);
+                if constexpr (!SPEC && k < P) issue_piece(kpos, soff, base, t);
+                if constexpr (k < NM) mma(t, w1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            slot = nslot;
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results before anything reads the accumulators
+        RSTAMP(3);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is out of the ring
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the dead stages' zero fills; every wave is out of the ring
 
     if (sf > 1) {
         // In-launch reduction of a tile's parts (gemm_big.hip's protocol and order): f32 slabs, a ticket, the last arriver adds
@@ -158,11 +226,14 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
         const int tt = nt * ntm + mt;
         float* base = g.sk_ws + (int64_t)tt * sf * SLAB;
         float* slab = base + (int64_t)part * SLAB;
+        if (!producer) {
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
+            for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) *reinterpret_cast<f32x4*>(slab + ((fm * FN + fn) * 256 + tid) * 4) = acc[fm][fn];
+                for (int fn = 0; fn < FN; ++fn) *reinterpret_cast<f32x4*>(slab + ((fm * FN + fn) * 256 + tid) * 4) = acc[fm][fn];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RSTAMP(4);
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(ring_smem);
         if (tid == 0) {
@@ -177,7 +248,8 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
             *flag = last;
         }
         __syncthreads();
-        if (*flag == 0u) return;
+        RSTAMP(5);
+        if (*flag == 0u || producer) return;
         const bool reread_own = sf > 2 && part != 0;
         if (reread_own) {
 #pragma unroll
@@ -194,20 +266,52 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const GemmArgs g) {
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] += *reinterpret_cast<const f32x4*>(other + ((fm * FN + fn) * 256 + tid) * 4);
         }
     }
+    if (producer) return;
 
-    // D = Wfrag x Afrag: a lane holds 4 consecutive output columns of one row (gemm_common.h epilogues)
+    RSTAMP(6);
+    // D = Wfrag x Afrag: a lane holds 4 consecutive output columns of one row; the arithmetic of gemm_common.h's epilogue<> on
+    // the prefetched operands
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * WM + fm * 16 + frow;
         if (m >= g.M) continue;
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-            const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+            int nb = n0 + wn * WN + fn * 16 + 4 * fq;
             if (nb >= g.N) continue;
             float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
-            epilogue<bf16_t, EPI>(g, m, nb, v);
+            if (g.bias) {
+                float b[4];
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(&pbias[fn]), b);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += b[i];
+            }
+            bf16_t* C = Cb;
+            if constexpr (EPI == EPI_BIAS) {
+                if (g.c_seg_shift) { const int sg = nb >> g.c_seg_shift; C += sg * g.c_seg_stride; nb -= sg << g.c_seg_shift; }
+            } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+            } else if constexpr (EPI == EPI_GATE_RESID) {
+                float r[4];
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(&presid[fm][fn]), r);
+                const f32x4 gt = pgate[fm][fn];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+            } else if constexpr (EPI == EPI_RESID) {
+                float r[4];
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(&presid[fm][fn]), r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += r[i];
+            }
+            store4<bf16_t>(C + (int64_t)m * g.ldc + nb, v);
         }
     }
+#ifdef RING_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSTAMP(7);
+#endif
 }
 
 struct RingTile { int bm, bn, ns; const char* name; };
@@ -215,35 +319,47 @@ struct RingTile { int bm, bn, ns; const char* name; };
 const RingTile kRing[] = {
     {96, 64, 8, "ring:96x64"}, {96, 96, 6, "ring:96x96"}, {96, 128, 5, "ring:96x128"}, {64, 64, 8, "ring:64x64"},
     {64, 128, 6, "ring:64x128"}, {128, 64, 6, "ring:128x64"}, {128, 128, 5, "ring:128x128"}, {128, 96, 5, "ring:128x96"},
+    {96, 32, 8, "ring:96x32"}, {128, 32, 8, "ring:128x32"}, {64, 32, 8, "ring:64x32"},
 };
 constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 
-template <int BM, int BN, int NS, int EPI>
+template <int BM, int BN, int NS, int EPI, bool SPEC>
 int launch_ring(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = NS * (BM + BN) * ROWB;
     static std::atomic<unsigned long long> attr_devs{0};
-    auto kern = gemm_ring_kernel<BM, BN, NS, EPI>;
+    auto kern = gemm_ring_kernel<BM, BN, NS, EPI, SPEC>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
     LTX_TRY(ltx_gemm_split_workspace(&ga, tiles, BM, BN, s));
     ltx_prof_kernel(LTX_PROFK_GEMM_RING);
-    LTX_LAUNCH_TIMED(kern, dim3((unsigned)(tiles * ga.sk_sf)), dim3(256), smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)(tiles * ga.sk_sf)), dim3(SPEC ? 512 : 256), smem, s, ga);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
 template <int BM, int BN, int NS>
 int launch_ring_epi(const GemmArgs& g, int epi, hipStream_t s) {
-    switch (epi) {
-        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS>(g, s);
-        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU>(g, s);
-        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID>(g, s);
-        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID>(g, s);
+    // LTX_GEMM_RING_SPEC=0: every wave loads and multiplies (256 threads), the first form of the kernel (A/B aid)
+    static const bool spec = [] { const char* e = getenv("LTX_GEMM_RING_SPEC"); return !(e && e[0] == '0'); }();
+    if (spec) switch (epi) {
+        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, true>(g, s);
+        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, true>(g, s);
+        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, true>(g, s);
+        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, true>(g, s);
+    }
+    else switch (epi) {
+        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, false>(g, s);
+        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, false>(g, s);
+        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, false>(g, s);
+        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, false>(g, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_ring: bad epilogue");
 }
 }  // namespace
 
+#ifdef RING_TRACE
+extern "C" int ltx_dbg_ring_trace(unsigned* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_trace), (size_t)n * 4) == hipSuccess ? 0 : -1; }
+#endif
 int ltx_gemm_ring_tiles() { return kNumRing; }
 const char* ltx_gemm_ring_tile_name(int i) { return i >= 0 && i < kNumRing ? kRing[i].name : ""; }
 int ltx_gemm_ring_tile_bm(int i) { return i >= 0 && i < kNumRing ? kRing[i].bm : 1; }
@@ -270,6 +386,9 @@ int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s) {
         case 5: return launch_ring_epi<128, 64, 6>(g, epi, s);
         case 6: return launch_ring_epi<128, 128, 5>(g, epi, s);
         case 7: return launch_ring_epi<128, 96, 5>(g, epi, s);
+        case 8: return launch_ring_epi<96, 32, 8>(g, epi, s);
+        case 9: return launch_ring_epi<128, 32, 8>(g, epi, s);
+        case 10: return launch_ring_epi<64, 32, 8>(g, epi, s);
     }
     LTX_FAIL(LTX_ERR_ARG, "gemm_ring: unsupported tile");
 }

@@ -1,0 +1,109 @@
+"""GPU suite: the small-M deep-ring GEMM (csrc/gemm_ring.hip, plan family ring:*) against gemm_big's tiles.
+
+gemm_ring keeps gemm_big's K partition (the shape-only split factor, K-ranges [part * nk / sf, (part + 1) * nk / sf), the
+canonical sum of the parts) and its MFMA, so every ring tile must return the same bits as gemm_big for the same call - the
+condition for being one more plan of the per-shape measurement.  Shapes: the C1 DiT's linear layers (384 tokens), the 128 text
+rows, ragged M / N / K, split and unsplit."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RING_TILES = ["ring:96x64", "ring:96x96", "ring:96x128", "ring:64x64", "ring:64x128", "ring:128x64", "ring:128x128", "ring:128x96"]
+KEYS = ("LTX_GEMM_RING_TILE", "LTX_GEMM_RING", "LTX_GEMM_TUNE", "LTX_GEMM_ASM16")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ltxhip
+    assert torch.cuda.is_available()
+    return ltxhip
+
+
+def _arms(hip, tile, fn):
+    """fn() on gemm_big's static tile (ring family off, plan cache bypassed), then on the forced ring tile."""
+    old = {k: os.environ.get(k) for k in KEYS}
+    try:
+        os.environ.pop("LTX_GEMM_RING_TILE", None)
+        os.environ["LTX_GEMM_RING"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"; os.environ["LTX_GEMM_ASM16"] = "0"
+        ref = fn()
+        os.environ.pop("LTX_GEMM_RING"); os.environ.pop("LTX_GEMM_TUNE"); os.environ.pop("LTX_GEMM_ASM16")
+        os.environ["LTX_GEMM_RING_TILE"] = tile
+        hip.prof_enable(True)
+        got = fn()
+        ms, _, cnt = hip.prof_report_kernel(0, hip.PROF_KERNELS.index("gemm_ring_kernel"))
+        hip.prof_enable(False)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    torch.cuda.synchronize()
+    assert cnt >= 1, "the forced ring tile did not run"
+    return ref, got
+
+
+@pytest.mark.parametrize("tile", RING_TILES)
+@pytest.mark.parametrize("M,N,K,epi", [(384, 6144, 2048, 0), (384, 2048, 2048, 2), (384, 8192, 2048, 1), (384, 2048, 8192, 2),
+                                       (128, 4096, 4096, 0), (128, 10240, 4096, 1), (128, 4096, 10240, 3),
+                                       (301, 1028, 200, 0), (77, 36, 72, 3), (1, 2048, 256, 0), (1152, 2048, 2048, 0)])
+def test_ring_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi in (2, 3) else None
+    gate = torch.randn(1, N, device="cuda", generator=g) if epi == 2 else None
+    ref, got = _arms(hip, tile, lambda: hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M))
+    assert torch.isfinite(got.float()).all()
+    if epi == 0:                                                    # and it is a GEMM, not two equal wrongs
+        ref32 = x.float() @ w.float().t() + b.float()
+        assert (got.float() - ref32).norm() / ref32.norm() < 3e-3
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("tile", ["ring:96x96", "ring:64x128"])
+def test_ring_segmented_qkv_output_and_two_batch_gate(hip, tile):
+    """The fused q|k|v projection written as three dense matrices, and gate * y + residual with one gate row per batch element
+    (two batch elements of 192 rows)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, K = 384, 2048
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(6144, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(6144, device="cuda", generator=g).bfloat16()
+    ref, got = _arms(hip, tile, lambda: hip.ops.linear_segmented(x, w, b, 2048))
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    w2 = w[:2048].contiguous(); b2 = b[:2048].contiguous()
+    resid = torch.randn(M, 2048, device="cuda", generator=g).bfloat16(); gate = torch.randn(2, 2048, device="cuda", generator=g)
+    ref, got = _arms(hip, tile, lambda: hip.ops.linear(x, w2, b2, epi=2, resid=resid, gate=gate, rows_per_batch=192))
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    want = resid.float() + gate.repeat_interleave(192, 0) * (x.float() @ w2.float().t() + b2.float())
+    assert (got.float() - want).norm() / want.norm() < 4e-3
+
+
+def test_ring_plans_are_measured_and_saved_for_small_m(hip, tmp_path):
+    """A fresh shape with M = 384 goes through the plan measurement with the ring family among the candidates; whatever wins, the
+    result equals the static gemm_big tile's, and a saved plan file loads back."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 384, 2304, 2048
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    got = hip.ops.linear(x, w, b, epi=0)
+    plan = hip.ops.gemm_plan(M, N, K)
+    assert plan != ""
+    old = {k: os.environ.get(k) for k in KEYS}
+    try:
+        os.environ["LTX_GEMM_RING"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"
+        ref = hip.ops.linear(x, w, b, epi=0)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    p = str(tmp_path / "plans.txt")
+    hip.plan_save(p)
+    assert any(line.split()[:3] == [str(M), str(N), str(K)] for line in open(p) if not line.startswith("#"))
+    hip.plan_load(p)
