@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void rownorm_rows_kernel(const RowNormArgs a, 
 // by-product of the GEMM that wrote x): one thread per 16-byte chunk, no reduction, no wave waiting for a row - where the
 // one-row-per-wave kernel takes 12.6 us for the DiT's [4992, 2048] pass, a pure map of the same bytes takes 6.5 us
 // (tools/norm_probe.py).  rinv is formed exactly as in rownorm_kernel; the partials are summed in ascending order.
-template <typename T, int R>
+template <typename T, int R, bool WIDE>       // WIDE: nch >= 64 (a wave lies inside one row group)
 __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch, int rpb) {
     // block = rpb * R whole rows: thread (sub, c) owns 16-byte chunk c of rows row0 + sub * R .. + R - 1 (nch a power of two
     // <= 256, rpb = 256 / nch).  What bounds the row-reducing kernel is not its reduction but the vector-memory instruction
@@ -323,38 +323,61 @@ __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a
     const int sub = threadIdx.x / nch, c = threadIdx.x - sub * nch;
     const int64_t row0 = ((int64_t)blockIdx.x * rpb + sub) * R;
     if (row0 >= a.rows) return;
-    // 1 / rms of the R rows of this thread: lanes 0 .. R-1 of the wave each sum one row's partials (a wave lies inside one sub
-    // when nch >= 64; for narrower rows every lane does its own rows' sums)
-    float rinv[R];
-    auto rinv_of = [&](int64_t row) {
-        const float* ps = a.presum + (row < a.rows ? row : a.rows - 1) * a.presum_n;
-        float ss = 0.f;
-        for (int g4 = 0; g4 < a.presum_n; g4 += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ps + g4);
-            ss += t[0]; ss += t[1]; ss += t[2]; ss += t[3];
-        }
-        return 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
-    };
-    if (nch >= 64) {
-        float mine = 0.f;
-        if (lane < R) mine = rinv_of(row0 + lane);
-#pragma unroll
-        for (int r = 0; r < R; ++r) rinv[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), r));
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) rinv[r] = rinv_of(row0 + r);
-    }
+    // Every load of the block is issued before anything waits: the R data chunks first, then the rows' partials (all of them at
+    // once - a loop of "load 16 bytes, wait, add" paid one memory latency per four partials, four in a row at D = 2048, before the
+    // data loads were even issued: 10.4 us per [4992, 2048] pass against 6.5 for a plain map of the same bytes), then the operands.
     Chunk16 v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = row0 + r < a.rows ? row0 + r : a.rows - 1;
         v[r].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
     }
+    // 1 / rms of the R rows of this thread: lanes 0 .. R-1 of the wave each sum one row's partials (a wave lies inside one sub
+    // when nch >= 64; for narrower rows every lane does its own rows' sums).  Ascending order; groups past presum_n add 0.0f,
+    // which changes no bit of a non-negative sum.
+    float rinv[R];
+    auto partials_of = [&](int64_t row, f32x4 (&t)[4]) {
+        const float* ps = a.presum + (row < a.rows ? row : a.rows - 1) * a.presum_n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                         // no branch: a group past presum_n re-reads the last one and is zeroed
+            const bool in = 4 * q < a.presum_n;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(ps + (in ? 4 * q : a.presum_n - 4));
+            t[q] = in ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto rinv_from = [&](int64_t row, const f32x4 (&t)[4]) {
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ss += t[q][0]; ss += t[q][1]; ss += t[q][2]; ss += t[q][3]; }
+        if (a.presum_n > 16) {                                // wider rows than the DiT's: the rest in a loop
+            const float* ps = a.presum + (row < a.rows ? row : a.rows - 1) * a.presum_n;
+            for (int g4 = 16; g4 < a.presum_n; g4 += 4) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ps + g4);
+                ss += u[0]; ss += u[1]; ss += u[2]; ss += u[3];
+            }
+        }
+        return 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
+    };
+    f32x4 pt[WIDE ? 1 : R][4];
+    if constexpr (WIDE) { if (lane < R) partials_of(row0 + lane, pt[0]); }
+    else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) partials_of(row0 + r, pt[r]);
+    }
     const uint32_t b0 = (uint32_t)row0 / (uint32_t)a.rows_per_batch;
     const int64_t last = row0 + R - 1 < a.rows ? row0 + R - 1 : a.rows - 1;
     const bool one_batch = (uint32_t)last / (uint32_t)a.rows_per_batch == b0;
     float wv[CH], scv[CH], shv[CH];
     load_chunk_operands<T>(a, c, (int64_t)b0, wv, scv, shv);
+    if constexpr (WIDE) {
+        float mine = 0.f;
+        if (lane < R) mine = rinv_from(row0 + lane, pt[0]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) rinv[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), r));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rinv[r] = rinv_from(row0 + r, pt[r]);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = row0 + r;
@@ -655,11 +678,13 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
         int R = 4;                                           // rows per thread (LTX_NORM_PRESUM_R = 2 / 4 / 8: tuning aid)
         if (const char* re = getenv("LTX_NORM_PRESUM_R")) { const int v = atoi(re); if (v == 2 || v == 4 || v == 8) R = v; }
         const dim3 grid((unsigned)cdiv64(a.rows, (int64_t)rpb * R));
+        const bool wide = nch >= 64;
         if (dtype == LTX_DT_BF16) {
-            if (R == 2) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2>), grid, dim3(256), 0, s, a, nch, rpb);
-            else if (R == 4) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4>), grid, dim3(256), 0, s, a, nch, rpb);
-            else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, a, nch, rpb);
-        } else LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);
+            if (R == 2) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, false>), grid, dim3(256), 0, s, a, nch, rpb); }
+            else if (R == 4) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, a, nch, rpb); }
+            else { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, a, nch, rpb); }
+        } else if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4, true>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);
+        else LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4, false>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);
     } else if (dtype == LTX_DT_BF16) launch_rownorm_t<bf16_t>(a, lpr, nch, s);
     else launch_rownorm_t<float>(a, lpr, nch, s);
     ltx_prof_end(tok, s);
