@@ -63,7 +63,7 @@ __device__ __forceinline__ void finish_chunk(const RowNormArgs& a, const float* 
 // Same, with the per-channel operands (weight, scale, shift of ONE chunk) already in registers: the NARROW mapping
 // keeps a lane on the same chunk for all of its rows, so they are loaded once instead of once per row
 // (64 B of modulation per 16 B of data through the L1/TA path otherwise).
-template <typename T>
+template <typename T, bool NT = false>
 __device__ __forceinline__ void finish_chunk_regs(const RowNormArgs& a, const float* f_in, float mean, float rinv, int c, bool has_w, bool has_mod,
                                                   const float* wv, const float* scv, const float* shv, T* y, bool active) {
     constexpr int CH = ElemTraits<T>::CHUNK;
@@ -77,7 +77,10 @@ __device__ __forceinline__ void finish_chunk_regs(const RowNormArgs& a, const fl
         f[i] = n;
     }
     Chunk16 o; f32_to_chunk<T>(f, o);
-    if (active) *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+    if (active) {
+        if constexpr (NT) __builtin_nontemporal_store(o.u, reinterpret_cast<u32x4*>(y + c * CH));
+        else *reinterpret_cast<u32x4*>(y + c * CH) = o.u;
+    }
 }
 
 template <typename T>
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void rownorm_rows_kernel(const RowNormArgs a, 
 // by-product of the GEMM that wrote x): one thread per 16-byte chunk, no reduction, no wave waiting for a row - where the
 // one-row-per-wave kernel takes 12.6 us for the DiT's [4992, 2048] pass, a pure map of the same bytes takes 6.5 us
 // (tools/norm_probe.py).  rinv is formed exactly as in rownorm_kernel; the partials are summed in ascending order.
-template <typename T, int R, bool WIDE>       // WIDE: nch >= 64 (a wave lies inside one row group)
+template <typename T, int R, bool WIDE, bool NT = false>       // WIDE: nch >= 64 (a wave lies inside one row group); NT: streaming hints on x and y
 __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a, int nch, int rpb) {
     // block = rpb * R whole rows: thread (sub, c) owns 16-byte chunk c of rows row0 + sub * R .. + R - 1 (nch a power of two
     // <= 256, rpb = 256 / nch).  What bounds the row-reducing kernel is not its reduction but the vector-memory instruction
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = row0 + r < a.rows ? row0 + r : a.rows - 1;
-        v[r].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
+        const u32x4* xp = reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
+        if constexpr (NT) v[r].u = __builtin_nontemporal_load(xp); else v[r].u = *xp;
     }
     // 1 / rms of the R rows of this thread: lanes 0 .. R-1 of the wave each sum one row's partials (a wave lies inside one sub
     // when nch >= 64; for narrower rows every lane does its own rows' sums).  Ascending order; groups past presum_n add 0.0f,
@@ -384,13 +388,96 @@ __global__ __launch_bounds__(256) void rownorm_presum_kernel(const RowNormArgs a
         const bool active = row < a.rows;
         float f[CH]; chunk_to_f32<T>(v[r], f);
         T* y = reinterpret_cast<T*>(a.y) + (active ? row : a.rows - 1) * a.ldy;
-        if (one_batch) finish_chunk_regs<T>(a, f, 0.f, rinv[r], c, a.weight != nullptr, a.scale != nullptr, wv, scv, shv, y, active);
+        if (one_batch) finish_chunk_regs<T, NT>(a, f, 0.f, rinv[r], c, a.weight != nullptr, a.scale != nullptr, wv, scv, shv, y, active);
         else if (active) {
             const uint32_t b = (uint32_t)row / (uint32_t)a.rows_per_batch;
             finish_chunk<T>(a, f, 0.f, rinv[r], c, a.scale ? a.scale + (int64_t)b * a.mod_stride : nullptr, a.shift ? a.shift + (int64_t)b * a.mod_stride : nullptr, y, true);
         }
     }
 }
+
+// The DiT's case of the map above with nothing left to decide at run time: bf16, a row of nch chunks
+// (nch = 64 / 128 / 256), modulation present, no weight, no activation, groups of R rows inside one batch element, no ragged tail.
+// rownorm_presum_kernel serves every combination and runs ~550 instructions per wave at 20 000 waves per pass - as many issue
+// cycles as the pass has memory time (a bare copy of the same bytes in the same geometry: 7.5 us; that kernel: 10.4-11.6,
+// tools/norm_diag.py).  Same expressions in the same order: same bits (tests/test_gpu_q2fold.py).
+template <int R>
+__global__ __launch_bounds__(256) void rownorm_presum_lean_kernel(const RowNormArgs a, int nch, int rpb) {
+    const int lane = threadIdx.x & 63;
+    const int sub = threadIdx.x / nch, c = threadIdx.x - sub * nch;
+    const uint32_t row0 = ((uint32_t)blockIdx.x * (uint32_t)rpb + (uint32_t)sub) * R;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)row0 * a.ldx + c * 8;
+    u32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const u32x4*>(x + (int64_t)r * a.ldx);
+    f32x4 pt[4];
+    if (lane < R) {
+        const float* ps = a.presum + (int64_t)(row0 + lane) * a.presum_n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = 4 * q < a.presum_n;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(ps + (in ? 4 * q : a.presum_n - 4));
+            pt[q] = in ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const uint32_t b = row0 / (uint32_t)a.rows_per_batch;
+    const float* sc = a.scale + (int64_t)b * a.mod_stride + c * 8; const float* sh = a.shift + (int64_t)b * a.mod_stride + c * 8;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+    float mine = 0.f;
+    if (lane < R) {
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ss += pt[q][0]; ss += pt[q][1]; ss += pt[q][2]; ss += pt[q][3]; }
+        mine = 1.0f / sqrtf(ss * (1.0f / (float)a.D) + a.eps);
+    }
+    const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    const float shv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + (int64_t)row0 * a.ldy + c * 8;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float rinv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), r));
+        Chunk16 ch; ch.u = v[r];
+        float f[8]; chunk_to_f32<bf16_t>(ch, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float n = (f[i] - 0.f) * rinv;
+            n = n * (1.0f + scv[i]) + shv[i];
+            f[i] = n;
+        }
+        Chunk16 o; f32_to_chunk<bf16_t>(f, o);
+        *reinterpret_cast<u32x4*>(y + (int64_t)r * a.ldy) = o.u;
+    }
+}
+
+#ifdef LTX_NORM_DIAG
+// Diagnosis only (tools/norm_diag.py): what a streaming pass over [rows, D] bf16 costs in this library's launch geometry.
+// var 0: copy, one 16-byte chunk per thread, consecutive threads consecutive chunks (grid = chunks / 256)
+// var 1: the same, four chunks per thread 4 KiB apart (the presum kernel's pattern), var 2: four chunks per thread 256 x 16 B apart (a block's chunks contiguous)
+__global__ __launch_bounds__(256) void norm_diag_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int64_t nchunks, int var, int rowchunks) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (var == 0) { if (t < nchunks) y[t] = x[t]; return; }
+    u32x4 v[4];
+    if (var == 1) {
+        const int64_t row0 = (t / rowchunks) * 4, c = t % rowchunks;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x[(row0 + r) * rowchunks + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[(row0 + r) * rowchunks + c] = v[r];
+    } else {
+        const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x[base + r * 256];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[base + r * 256] = v[r];
+    }
+}
+extern "C" int ltx_dbg_norm_diag(const void* x, void* y, long long nchunks, int var, int rowchunks, void* stream) {
+    const unsigned grid = (unsigned)(var == 0 ? (nchunks + 255) / 256 : nchunks / 1024);
+    hipLaunchKernelGGL(norm_diag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, (int64_t)nchunks, var, rowchunks);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
 
 // CACHED: the (<= NSLOT chunks per lane) segment stays in registers between the two passes
 template <typename T, bool CACHED>
@@ -679,8 +766,15 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
         if (const char* re = getenv("LTX_NORM_PRESUM_R")) { const int v = atoi(re); if (v == 2 || v == 4 || v == 8) R = v; }
         const dim3 grid((unsigned)cdiv64(a.rows, (int64_t)rpb * R));
         const bool wide = nch >= 64;
-        if (dtype == LTX_DT_BF16) {
+        // the DiT's case on the kernel that has nothing to decide (LTX_NORM_LEAN=0: the general one; same bits)
+        const char* le = getenv("LTX_NORM_LEAN");
+        const bool lean_on = !(le && le[0] == '0');
+        const bool lean = lean_on && dtype == LTX_DT_BF16 && wide && R == 4 && a.scale && !a.weight && a.act == 0 && a.presum_n <= 16 &&
+                          a.rows % ((int64_t)rpb * 4) == 0 && a.rows_per_batch % 4 == 0 && !getenv("LTX_NORM_NT");
+        if (lean) LTX_LAUNCH_TIMED((rownorm_presum_lean_kernel<4>), grid, dim3(256), 0, s, a, nch, rpb);
+        else if (dtype == LTX_DT_BF16) {
             if (R == 2) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, false>), grid, dim3(256), 0, s, a, nch, rpb); }
+            else if (R == 4 && wide && getenv("LTX_NORM_NT")) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true, true>), grid, dim3(256), 0, s, a, nch, rpb);
             else if (R == 4) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, a, nch, rpb); }
             else { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, a, nch, rpb); }
         } else if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4, true>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);

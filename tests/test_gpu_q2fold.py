@@ -171,6 +171,23 @@ def test_rownorm_from_presums_matches_the_row_reducing_pass(hip):
         assert torch.equal(h, h0) and torch.equal(hs, hip.ops.rowsq(h))
 
 
+@pytest.mark.parametrize("S,D,B", [(4992, 2048, 1), (384, 2048, 1), (2 * 252, 512, 2), (4992, 1024, 3)])
+def test_presum_lean_kernel_bit_identical_to_the_general_one(hip, S, D, B):
+    """rownorm_presum_lean_kernel (the DiT's case with nothing decided at run time) against rownorm_presum_kernel
+    (LTX_NORM_LEAN=0) on the same rows: same expressions in the same order, every bit equal; several batch elements with their
+    own modulation rows, 64 / 128 / 256 chunks per row."""
+    g = torch.Generator().manual_seed(S + D)
+    x = (torch.randn(S, D, generator=g) * 1.7).bfloat16().to(DEV)
+    sc = torch.randn(B, D, generator=g).to(DEV); sh = torch.randn(B, D, generator=g).to(DEV)
+    rs = hip.ops.rowsq(x)
+    with env(LTX_NORM_LEAN="0"):
+        y_gen = hip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S // B, 0)
+    y_lean = hip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S // B, 0)
+    assert torch.equal(y_gen.view(torch.int16), y_lean.view(torch.int16))
+    ref = O.rms_norm(x.float().cpu()[None], None, 1e-6)[0].view(B, S // B, D) * (1 + sc.cpu()[:, None]) + sh.cpu()[:, None]
+    assert rel_l2(y_lean.float().cpu().view(B, S // B, D), ref) <= 3e-3
+
+
 def test_dit_with_presum_norms_vs_oracle(hip):
     """The same two-layer DiT as above with LTX_NORM_PRESUM=0 / 2 (forced: at M = 252 the partials come from the stand-alone pass,
     which is the same canonical sum): both within the bf16 bar of the f32 oracle, neither worse than the other by more than noise."""
