@@ -15,6 +15,19 @@ extern "C" int ltx_op_linear(const void* x, const void* w, const void* bias, voi
     return ltx_launch_gemm(g, dtc(dtype), epi, (hipStream_t)stream);
 }
 
+extern "C" int64_t ltx_op_ring_packed_bytes(int N, int K) { return (int64_t)ltx_ring_packed_bytes(N, K); }
+extern "C" int ltx_op_ring_pack(const void* w, int N, int K, void* out, ltx_stream stream) { return ltx_pack_ring_weights(w, N, K, out, (hipStream_t)stream); }
+extern "C" int ltx_op_linear_packed(const void* x, const void* w, const void* w_packed, const void* bias, void* y, int M, int N, int K, int epi,
+                                    const void* resid, const float* gate, int rows_per_batch, ltx_stream stream) {
+    if (!x || !w || !w_packed || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_packed: null tensor");
+    if (epi < 0 || epi > 3) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_packed: epi must be 0..3");
+    if ((epi == 2 || epi == 3) && !resid) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_packed: residual epilogue needs resid");
+    if (epi == 2 && (!gate || rows_per_batch < 1)) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_packed: gated epilogue needs gate");
+    GemmArgs g; g.A = x; g.W = w; g.Wp = w_packed; g.C = y; g.bias = bias; g.resid = resid; g.gate = gate;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.gate_stride = N;
+    return ltx_launch_gemm(g, LTX_DT_BF16, epi, (hipStream_t)stream);
+}
+
 extern "C" int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, int epi,
                                    const void* resid, const float* gate, int rows_per_batch, ltx_stream stream) {
     if (!x || !w || !y || !rowsq) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_rowsq: null tensor");

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)OOB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, (int)OOB, 0x00020000);
+    const bool packed = g.Wp != nullptr;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(packed ? reinterpret_cast<const bf16_t*>(g.Wp) : W), 0, (int)OOB, 0x00020000);
+    const uint32_t w_step = packed ? 4096u : 128u;                 // bytes from one K-step to the next in the weight operand
     // piece j of issuing wave cw fills rows 8 * (4 j + cw) .. + 7 of the activation (j < PA) or weight image of a stage; a lane
     // writes 16 bytes: row lr = lane >> 3, physical chunk pc = lane & 7 holds logical chunk pc ^ ((row >> 1) & 7)
     const int lr = lane >> 3, pc = lane & 7;
@@ -89,11 +91,16 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
         const int chunk = pc ^ ((row >> 1) & 7);
         klim[j] = g.K - chunk * 8;
         if (isa) { int m = m0 + row; if (m > g.M - 1) m = g.M - 1; voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk * 8) * 2u; }
-        else { int c = n0 + row; if (c > g.N - 1) c = g.N - 1; voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk * 8) * 2u; }
+        else {
+            int c = n0 + row; if (c > g.N - 1) c = g.N - 1;
+            if (packed) { voff[j] = (uint32_t)(c >> 5) * (uint32_t)nk * 4096u + (uint32_t)(c & 31) * 128u + chunk * 16u; klim[j] = 0x3fffffff; }   // (K is zero padded there)
+            else voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk * 8) * 2u;
+        }
     }
-    auto issue_piece = [&](int kpos, uint32_t soff, unsigned char* base, auto j_tag) {
+    auto issue_piece = [&](int kpos, uint32_t kstep, unsigned char* base, auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         constexpr bool isa = j < PA;
+        const uint32_t soff = kstep * (isa ? 128u : w_step);
         uint32_t vo = kpos < klim[j] ? voff[j] : OOB;
 #if RING_ABL & 4
         vo = lane * 16;
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
     };
     auto issue = [&](int i, int slot) {                             // stage i of this block's K range into ring slot `slot`, all pieces
         const int kpos = i < n ? (kt0 + i) * 64 : 0x40000000;       // a dead stage lies beyond every klim
-        const uint32_t soff = i < n ? (uint32_t)(kt0 + i) * 128u : 0u;
-        sfor_r<0, P>([&](auto j) { issue_piece(kpos, soff, ring_smem + slot * STAGE, j); });
+        const uint32_t kstep = i < n ? (uint32_t)(kt0 + i) : 0u;
+        sfor_r<0, P>([&](auto j) { issue_piece(kpos, kstep, ring_smem + slot * STAGE, j); });
     };
 
     f32x4 acc[FM][FN];
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             const int kpos = i + NS < n ? (kt0 + i + NS) * 64 : 0x40000000;
-            const uint32_t soff = i + NS < n ? (uint32_t)(kt0 + i + NS) * 128u : 0u;
+            const uint32_t soff = i + NS < n ? (uint32_t)(kt0 + i + NS) : 0u;       // (the K-step; issue_piece scales it per operand)
             unsigned char* const base = ring_smem + slot * STAGE;
             sfor_r<0, NSLOT>([&](auto t) {                          // (!SPEC) stage i + NS into the slot just freed, its pieces spread over the MFMAs
                 constexpr int k = decltype(t)::value;
@@ -360,6 +367,28 @@ int launch_ring_epi(const GemmArgs& g, int epi, hipStream_t s) {
 #ifdef RING_TRACE
 extern "C" int ltx_dbg_ring_trace(unsigned* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_trace), (size_t)n * 4) == hipSuccess ? 0 : -1; }
 #endif
+namespace {
+// one thread per 16-byte chunk of the packed image: chunk id -> (row group, K block, row in group, chunk in row)
+__global__ __launch_bounds__(256) void ring_pack_kernel(const bf16_t* __restrict__ W, int N, int K, int nk, u32x4* __restrict__ out, int64_t nchunks) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nchunks) return;
+    const int c8 = (int)(t & 7), r = (int)((t >> 3) & 31);
+    const int64_t blk = t >> 8;
+    const int kb = (int)(blk % nk); const int64_t grp = blk / nk;
+    const int64_t nrow = grp * 32 + r; const int k = kb * 64 + c8 * 8;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (nrow < N && k < K) v = *reinterpret_cast<const u32x4*>(W + nrow * K + k);      // (K % 8 == 0: a chunk is inside K or outside it)
+    out[t] = v;
+}
+}  // namespace
+size_t ltx_ring_packed_bytes(int N, int K) { return (size_t)cdiv(N, 32) * cdiv(K, 64) * 4096; }
+int ltx_pack_ring_weights(const void* W, int N, int K, void* out, hipStream_t s) {
+    if (!W || !out || N < 1 || K < 8 || K % 8) LTX_FAIL(LTX_ERR_ARG, "ring pack: bf16 [N, K] with K a multiple of 8");
+    const int64_t nchunks = (int64_t)(ltx_ring_packed_bytes(N, K) / 16);
+    hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)cdiv64(nchunks, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(W), N, K, cdiv(K, 64), reinterpret_cast<u32x4*>(out), nchunks);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
 int ltx_gemm_ring_tiles() { return kNumRing; }
 const char* ltx_gemm_ring_tile_name(int i) { return i >= 0 && i < kNumRing ? kRing[i].name : ""; }
 int ltx_gemm_ring_tile_bm(int i) { return i >= 0 && i < kNumRing ? kRing[i].bm : 1; }

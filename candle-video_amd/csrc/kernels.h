@@ -54,6 +54,10 @@ struct GemmArgs {
     // ltx_rowsq_leaf / ltx_launch_rowsq - so the value does not depend on which kernel the plan picked: gemm_asm16's
     // epilogue produces it in place, every other kernel is followed by the stand-alone pass (ltx_launch_gemm).
     float* rowsq = nullptr;
+    // Optional second copy of W for gemm_ring.hip (linear layers of at most 512 rows): [ceil(N/32)][ceil(K/64)][32 rows][64] bf16,
+    // zero padded - a tile's K-step is then 4-KiB blocks and a block's whole K range one contiguous stream, instead of 128-byte
+    // pieces of rows K * 2 bytes apart (ltx_pack_ring_weights; same values; measured neutral: opt-in, LTX_RING_PACK=1)
+    const void* Wp = nullptr;
     int xcd_remap = 0;            // gemm_big: give each XCD a contiguous run of tiles
     int group_m = 0;              // gemm_big: tile order inside that run: columns of group_m row-tiles (0/1: row-major)
     int wide_epi = 0;             // gemm_big (set by its launcher): result tile through LDS, 16-byte row-contiguous stores
@@ -95,7 +99,9 @@ const char* ltx_gemm_ring_tile_name(int i);
 int ltx_gemm_ring_tile_bm(int i);
 int ltx_gemm_ring_tile_bn(int i);
 int ltx_gemm_ring_pick_tile(const GemmArgs& g);
-int ltx_gemm_split_workspace(GemmArgs* g, int tiles, int bm, int bn, hipStream_t s);   // sets sk_sf / sk_full = 0 / sk_ws / sk_cnt
+int ltx_gemm_split_workspace(GemmArgs* g, int tiles, int bm, int bn, hipStream_t s);
+size_t ltx_ring_packed_bytes(int N, int K);
+int ltx_pack_ring_weights(const void* W, int N, int K, void* out, hipStream_t s);      // bf16 [N, K] -> the GemmArgs::Wp layout   // sets sk_sf / sk_full = 0 / sk_ws / sk_cnt
 bool ltx_gemm_big_fits(const GemmArgs& g);   // gemm_big.hip: every span its 32-bit buffer offsets address stays below 2 GiB
 // conv_halo.hip: 3x3x3 conv with the activation patch + rim staged once per nine in-plane taps; bn = 128 / 256
 bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn);

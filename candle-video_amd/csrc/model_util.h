@@ -1,6 +1,7 @@
 // Host-side helpers shared by dit.hip / vae.hip / pipeline.hip: device buffers, weight lookup/upload.
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include <cmath>
@@ -26,6 +27,10 @@ struct LinearW {
     void* w = nullptr;   // [out, in] model dtype
     void* b = nullptr;   // [out] model dtype or null
     int in = 0, out = 0;
+    // tile-contiguous second copy for gemm_ring.hip (GemmArgs::Wp), made by ltx_linear on the first call with at most 512 rows
+    // and freed with the last copy of this struct; wp_tried: an allocation that failed is not retried
+    mutable std::shared_ptr<void> wp;
+    mutable bool wp_tried = false;
 };
 
 struct WeightMap {

@@ -113,6 +113,8 @@ _SIGS = {
     "ltx_prof_enable": [_i], "ltx_prof_report": [_i, _vp, _vp, _vp], "ltx_prof_report_kernel": [_i, _i, _vp, _vp, _vp],
     "ltx_op_linear": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_linear_segmented": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ltx_op_ring_packed_bytes": [_i, _i], "ltx_op_ring_pack": [_vp, _i, _i, _vp, _vp],
+    "ltx_op_linear_packed": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_rownorm_presum": [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp],
     "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
     "ltx_op_attention_rowsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp],
@@ -163,6 +165,7 @@ for _name, _sig in _SIGS.items():
                      "ltx_name_mapper_destroy", "ltx_safetensors_close", "ltx_safetensors_count", "ltx_team_destroy"):
         _fn.restype = C.c_int
 lib.ltx_calculate_shift.restype = C.c_float
+lib.ltx_op_ring_packed_bytes.restype = C.c_int64
 lib.ltx_vae_latents_mean.restype = C.c_void_p
 lib.ltx_vae_latents_std.restype = C.c_void_p
 lib.ltx_name_mapper_create.restype = C.c_void_p
@@ -947,6 +950,24 @@ class ops:
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         _check(lib.ltx_op_linear(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(bias), _ptr(y), M, N, K, _dt(x.dtype), epi,
                                  _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
+        return y
+
+    @staticmethod
+    def ring_pack(w):
+        """-> the tile-contiguous second copy of a bf16 [N, K] weight that the small-M kernel streams (GemmArgs::Wp)"""
+        N, K = w.shape
+        out = torch.empty(lib.ltx_op_ring_packed_bytes(N, K) // 2, dtype=torch.bfloat16, device=w.device)
+        _check(lib.ltx_op_ring_pack(_ptr(w.contiguous()), N, K, _ptr(out), _stream()))
+        return out
+
+    @staticmethod
+    def linear_packed(x, w, wp, bias=None, epi=0, resid=None, gate=None, rows_per_batch=1):
+        """ops.linear with the packed copy of w at hand (bf16; same results)"""
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        _check(lib.ltx_op_linear_packed(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(wp), _ptr(bias), _ptr(y), M, N, K, epi,
+                                        _ptr(resid), _ptr(gate), rows_per_batch, _stream()))
         return y
 
     @staticmethod

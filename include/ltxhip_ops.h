@@ -22,6 +22,13 @@ int ltx_op_linear(const void* x, const void* w, const void* bias, void* y, int M
  * group: rowsq[m * ceil(N/128) + g].  The summation order is canonical (independent of the kernel the plan picks), so a
  * consumer can fold an RMS norm of the output rows without a pass over them: the cross-attention q-norm,
  * ltx_transformer.rs:671-678.  ltx_op_rowsq is the stand-alone form on a stored matrix: same values, bit for bit. */
+/* bf16 linear layers of at most 512 rows (csrc/gemm_ring.hip): a second, tile-contiguous copy of w ([ceil(N/32)][ceil(K/64)][32][64],
+ * zero padded; ltx_op_ring_packed_bytes bytes) lets the small-M kernel stream it in 4-KiB blocks.  Same results as ltx_op_linear;
+ * measured to buy nothing for C1 and 4 % for T5-XXL, so the models build these copies only under LTX_RING_PACK=1. */
+int64_t ltx_op_ring_packed_bytes(int N, int K);
+int ltx_op_ring_pack(const void* w, int N, int K, void* out, ltx_stream stream);
+int ltx_op_linear_packed(const void* x, const void* w, const void* w_packed, const void* bias, void* y, int M, int N, int K, int epi,
+                         const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);
 int ltx_op_linear_rowsq(const void* x, const void* w, const void* bias, void* y, float* rowsq, int M, int N, int K, int dtype, int epi,
                         const void* resid, const float* gate, int rows_per_batch, ltx_stream stream);   /* epi 0, 2, 3 as ltx_op_linear */
 int ltx_op_rowsq(const void* x, int64_t rows, int N, int ld, float* rowsq, int dtype, ltx_stream stream);

@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-RING_TILES = ["ring:96x64", "ring:96x96", "ring:96x128", "ring:64x64", "ring:64x128", "ring:128x64", "ring:128x128", "ring:128x96"]
+RING_TILES = ["ring:96x64", "ring:96x96", "ring:96x128", "ring:64x64", "ring:64x128", "ring:128x64", "ring:128x128", "ring:128x96", "ring:96x32", "ring:128x32", "ring:64x32"]
 KEYS = ("LTX_GEMM_RING_TILE", "LTX_GEMM_RING", "LTX_GEMM_TUNE", "LTX_GEMM_ASM16")
 
 
@@ -107,3 +107,35 @@ def test_ring_plans_are_measured_and_saved_for_small_m(hip, tmp_path):
     hip.plan_save(p)
     assert any(line.split()[:3] == [str(M), str(N), str(K)] for line in open(p) if not line.startswith("#"))
     hip.plan_load(p)
+
+
+@pytest.mark.parametrize("tile", RING_TILES)
+@pytest.mark.parametrize("M,N,K,epi", [(384, 2048, 2048, 2), (384, 8192, 2048, 1), (128, 4096, 10240, 3), (301, 1028, 200, 0), (77, 36, 72, 3), (5, 2048, 256, 0)])
+def test_ring_on_packed_weights_bit_identical(hip, tile, M, N, K, epi):
+    """The tile-contiguous weight copy (GemmArgs::Wp: [N/32][K/64][32][64], zero padded - what the models hand the small-M kernel)
+    against the row-major weights: same values through another address map, every bit equal; ragged N (not a multiple of 32) and K
+    (not a multiple of 64) included."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi in (2, 3) else None
+    gate = torch.randn(1, N, device="cuda", generator=g) if epi == 2 else None
+    wp = hip.ops.ring_pack(w)
+    # the packed image holds exactly the weights, in 32 x 64 blocks
+    blocks = wp.view(-(-N // 32), -(-K // 64), 32, 64)
+    assert torch.equal(blocks[0, 0, : min(32, N), : min(64, K)], w[: min(32, N), : min(64, K)])
+    old = {k: os.environ.get(k) for k in KEYS}
+    try:
+        os.environ["LTX_GEMM_RING_TILE"] = tile
+        ref = hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M)
+        hip.prof_enable(True)
+        got = hip.ops.linear_packed(x, w, wp, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M)
+        _, _, cnt = hip.prof_report_kernel(0, hip.PROF_KERNELS.index("gemm_ring_kernel"))
+        hip.prof_enable(False)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    assert cnt >= 1
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
