@@ -625,7 +625,7 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     // 4 x 8 x 12 = 384 voxels of 1024 channels: 11 convs of 57 MB of weights each, 500 us apiece on gemm.hip's kernel, 6.5 of
     // C1's 63 ms; with the split-K tiles the decode went 11.9 -> 6.3 ms); smaller ones stay there.  LTX_GEMM_BIG_MINM /
     // LTX_GEMM_BIG_CONV_MINM override.
-    int min_m = g.conv ? 256 : 1;
+    int min_m = g.conv ? 16 : 1;      // (round 4: the edge tiles of the tiled decode are convs of 48..192 voxels x 1024 channels - 57 MB of weights at 0.11 TB/s on the 128 x 128 kernel, 500 us apiece)
     if (const char* e = getenv("LTX_GEMM_BIG_MINM")) { min_m = atoi(e); if (g.conv && min_m < 1024) min_m = 1024; }
     if (g.conv) { if (const char* e = getenv("LTX_GEMM_BIG_CONV_MINM")) min_m = atoi(e); }
     return g.M >= min_m && g.N >= 32;
