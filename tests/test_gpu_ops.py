@@ -176,7 +176,9 @@ def test_conv3d_known_answer(hip, golden, dt, causal):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,Cin,Cout,T,H,W", [(1, 128, 128, 3, 9, 11), (2, 16, 40, 2, 5, 6), (1, 256, 64, 1, 16, 16)])
+@pytest.mark.parametrize("B,Cin,Cout,T,H,W", [(1, 128, 128, 3, 9, 11), (2, 16, 40, 2, 5, 6), (1, 256, 64, 1, 16, 16),
+                                             # edge tiles of the tiled decode: a few dozen voxels x the mid block's width (split-K tiles since round 4)
+                                             (1, 1024, 1024, 1, 4, 12), (1, 1024, 1024, 2, 4, 12), (1, 512, 512, 1, 8, 24)])
 def test_conv3d_shapes_and_residual(hip, dt, B, Cin, Cout, T, H, W):
     x, w, b = rnd(dt, B, Cin, T, H, W), rnd(dt, Cout, Cin, 3, 3, 3, scale=(27 * Cin) ** -0.5), rnd(dt, Cout, scale=0.1)
     r = rnd(dt, B, Cout, T, H, W, seed=5)
