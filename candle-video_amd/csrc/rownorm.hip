@@ -565,8 +565,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkNormRopeArgs a
 // chunks of a lane are loaded ONCE and reused by both segments (q and k share the table), and the loads of every
 // segment are issued before the first reduction (memory-level parallelism; the slow kernel read the tables twice and
 // serialised the segments).
-template <typename T, int NS>
-__global__ __launch_bounds__(256, 5) void qknorm_rope_fused_kernel(const QkNormRopeArgs a, int lpr) {
+template <typename T, int NS, int OCC = 5>      // OCC: blocks per CU the register allocation must allow (NS = 4: 94 registers, five)
+__global__ __launch_bounds__(256, OCC) void qknorm_rope_fused_kernel(const QkNormRopeArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     static_assert(CH == 8, "bf16 rows only");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -797,6 +797,8 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     const bool cached = nch <= NSLOT * lpr;
     if (dtype == LTX_DT_BF16) {
         if (nch <= 4 * lpr) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 4>), grid, block, 0, s, a, lpr);
+        // the 13B model's 4096-wide rows: eight chunks per lane, the table still read once for q and k (LTX_QKNORM_FUSED8=0: the two-pass kernel)
+        else if (nch <= 8 * lpr && !(getenv("LTX_QKNORM_FUSED8") && getenv("LTX_QKNORM_FUSED8")[0] == '0')) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 8, 2>), grid, block, 0, s, a, lpr);
         else if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
         else hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, false>), grid, block, 0, s, a, lpr);
     } else {

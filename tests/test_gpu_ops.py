@@ -90,7 +90,7 @@ def test_rownorm_layernorm_batched_mod(hip, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("grid,D", [((2, 8, 8), 2048), ((4, 8, 12), 128), ((2, 4, 4), 64), ((1, 2, 3), 32)])
+@pytest.mark.parametrize("grid,D", [((2, 8, 8), 2048), ((4, 8, 12), 128), ((2, 4, 4), 64), ((1, 2, 3), 32), ((2, 4, 6), 4096)])
 def test_rope_table_and_qknorm_rope(hip, dt, grid, D):
     Fr, H, W = grid
     S = Fr * H * W
