@@ -139,3 +139,34 @@ def test_ring_on_packed_weights_bit_identical(hip, tile, M, N, K, epi):
             else: os.environ[k] = v
     assert cnt >= 1
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+def test_ring_fuzz_random_shapes_tiles_and_epilogues(hip):
+    """120 random problems (M 1..512, N a multiple of 4 from 32, K a multiple of 8 from 8, every epilogue, a random ring tile each,
+    with and without the packed weight copy): bit-identical to gemm_big's static tile and within the bf16 bar of f32 torch."""
+    import random
+    rnd = random.Random(20261003)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    for it in range(120):
+        M = rnd.choice([1, 2, 7, 31, 32, 33, 95, 96, 97, 128, 200, 255, 256, 257, 383, 384, 385, 500, 512])
+        N = 4 * rnd.randint(8, 700)
+        K = 8 * rnd.randint(1, 520)
+        epi = rnd.randint(0, 3)
+        tile = rnd.choice(RING_TILES)
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+        b = torch.randn(N, device="cuda", generator=g).bfloat16() if rnd.random() < 0.8 else None
+        resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi in (2, 3) else None
+        nb = rnd.choice([1, 2]) if M % 2 == 0 else 1
+        gate = torch.randn(nb, N, device="cuda", generator=g) if epi == 2 else None
+        packed = rnd.random() < 0.5
+        wp = hip.ops.ring_pack(w) if packed else None
+        def run():
+            if packed and os.environ.get("LTX_GEMM_RING_TILE"):
+                return hip.ops.linear_packed(x, w, wp, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M // nb)
+            return hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M // nb)
+        ref, got = _arms(hip, tile, run)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (it, M, N, K, epi, tile, packed)
+        if epi == 0:
+            ref32 = x.float() @ w.float().t() + (b.float() if b is not None else 0)
+            assert (got.float() - ref32).norm() / ref32.norm() < 4e-3, (it, M, N, K, tile)
