@@ -693,7 +693,8 @@ extern "C" int ltx_dbg_xtrace(unsigned* out, int n) { return hipMemcpyFromSymbol
 #ifndef XATTN_WPS
 #define XATTN_WPS 3          // waves per SIMD the kernel is compiled for (blocks per CU): 2 = round 3's build (254 registers)
 #endif
-__global__ __launch_bounds__(256, XATTN_WPS) void attn_cross64_kernel(const AttnArgs a, int groups) {
+template <bool B2D>          // B2D: a [heads, Sq, Sk] bias on top of the key bias (T5 self-attention over <= 128 tokens)
+__global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(const AttnArgs a, int groups) {
     constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2, NKB = XKV / 32;
     __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
     __shared__ __attribute__((aligned(16))) float sbias[XKV];
@@ -786,6 +787,19 @@ __global__ __launch_bounds__(256, XATTN_WPS) void attn_cross64_kernel(const Attn
     for (; u < nunits; u += ustride) {
         if (xi < 8) { XSTAMP(xi); ++xi; }
         if (u + ustride < nunits) load_q(u + ustride, qn, rsn);
+        // (B2D) this lane's query row of the [heads, Sq, Sk] bias, in accumulator order, in flight under the S MFMAs
+        f32x4 b2[B2D ? NKB : 1][B2D ? 4 : 1];
+        if constexpr (B2D) {
+            int qr = u * 32 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+            const float* brow = a.bias2d + ((int64_t)head * a.Sq + qr) * a.Sk;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int kk = kb * 32 + 8 * g4 + 4 * h;
+                    b2[kb][g4] = kk < a.Sk ? *reinterpret_cast<const f32x4*>(brow + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};      // Sk % 4 == 0: a group lies inside or outside
+                }
+        }
         // S^T = K . Q^T for all keys
         f32x16 sacc[NKB];
 #pragma unroll
@@ -801,7 +815,11 @@ __global__ __launch_bounds__(256, XATTN_WPS) void attn_cross64_kernel(const Attn
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 bq = bias4(kb, g4);
+                f32x4 bq = bias4(kb, g4);
+                if constexpr (B2D) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[i] = fmaf(b2[kb][g4][i], LOG2E, bq[i]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { sacc[kb][4 * g4 + i] = fmaf(sacc[kb][4 * g4 + i], cq, bq[i]); mt = fmaxf(mt, sacc[kb][4 * g4 + i]); }
             }
@@ -978,6 +996,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
         if (a.q_rowsq && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled() && a.q_rowsq_n >= 4 && a.q_rowsq_n <= 16 && a.q_rowsq_n % 4 == 0 && a.q_rowsq_D > 0))
             LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is served by the short-key-set head_dim-64 kernel only (4..16 partials per row, a multiple of 4)");
+        if (a.bias2d && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled())) LTX_FAIL(LTX_ERR_ARG, "attention: bias2d is served by the short-key-set head_dim-64 kernel only");
         if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
             const int nunits = cdiv(a.Sq, 32);
@@ -999,7 +1018,11 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
             }
             if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
             if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
-            LTX_LAUNCH_TIMED(attn_cross64_kernel, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
+            if (a.bias2d) {
+                if (a.Sk % 4 || ((uintptr_t)a.bias2d & 15)) LTX_FAIL(LTX_ERR_ARG, "attention: bias2d needs Sk % 4 == 0 and a 16-byte aligned table");
+                LTX_LAUNCH_TIMED(attn_cross64_kernel<true>, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
+            } else
+            LTX_LAUNCH_TIMED(attn_cross64_kernel<false>, dim3((unsigned)(a.B * a.heads * groups)), block, 0, s, ax, groups);
             LTX_CHECK_LAUNCH();
             return LTX_OK;
         }

@@ -153,6 +153,9 @@ struct AttnArgs {
     int B = 1, Sq = 0, Sk = 0, heads = 0, hd = 0;
     float scale = 1.f;
     const float* bias = nullptr;                  // f32 [B, Sk] additive key bias or null
+    // f32 [heads, Sq, Sk] additive bias shared by the batch (T5's relative position bias; attn_cross64_kernel only: head_dim 64,
+    // Sk <= 128, Sk % 4 == 0)
+    const float* bias2d = nullptr;
     int q_prescaled = 0;                          // bf16, no bias: q already carries scale*log2(e) (qknorm_rope out_scale0)
     int xcd_heads = 0;                            // set by the launcher: whole heads per XCD (block order, speed only)
     int wide_o = 0;                               // set by the launcher: 16-byte output stores (ldo % 8 == 0, 16-byte aligned o)

@@ -148,6 +148,21 @@ int own_fused(ltx_t5* m, const WeightMap& wm, const std::vector<std::string>& na
 
 template <typename T>
 int run_attn(const ltx_t5* m, const void* qkv, const float* bias, const float* kmask, void* out, int B, int S, hipStream_t s) {
+    // The pipeline's case (bf16, d_kv 64, at most 128 tokens): the short-key-set MFMA kernel of the DiT's cross attention with
+    // the relative position bias as its [heads, S, S] table - K and V of a head in LDS once, a 32-query unit per wave: 44.6 -> ~9 us
+    // per layer at S = 128 (the kernel below gives a query to each WAVE and a key to each lane).  LTX_T5_ATTN_MFMA=0: the kernel below.
+    if constexpr (sizeof(T) == 2) {
+        const char* e = getenv("LTX_T5_ATTN_MFMA");
+        if (m->cfg.d_kv == 64 && S <= 128 && S % 4 == 0 && !(e && e[0] == '0')) {
+            const int inner = m->cfg.num_heads * 64;
+            AttnArgs a;
+            a.q = qkv; a.k = reinterpret_cast<const T*>(qkv) + inner; a.v = reinterpret_cast<const T*>(qkv) + 2 * inner; a.o = out;
+            a.ldq = a.ldk = a.ldv = 3 * inner; a.ldo = inner;
+            a.B = B; a.Sq = S; a.Sk = S; a.heads = m->cfg.num_heads; a.hd = 64; a.scale = 1.0f;       // T5 does not scale its scores
+            a.bias = kmask; a.bias2d = bias;
+            return ltx_launch_attention(a, LTX_DT_BF16, s);
+        }
+    }
     dim3 grid((unsigned)cdiv(S, 4), (unsigned)m->cfg.num_heads, (unsigned)B), block(256);
     switch (m->cfg.d_kv) {
         case 32: hipLaunchKernelGGL((t5_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qkv, bias, kmask, (T*)out, S, m->cfg.num_heads); break;

@@ -503,6 +503,48 @@ def test_t5_encoder_matches_oracle(hip, mdt):
         enc.forward(torch.zeros(1, 600, dtype=torch.long))
 
 
+def test_t5_attention_on_the_mfma_kernel_vs_oracle_and_the_scalar_kernel(hip):
+    """The pipeline's T5 geometry class - bf16, d_kv 64, at most 128 tokens (a multiple of 4) - runs its self-attention on the
+    DiT's short-key-set MFMA kernel with the relative position bias as a [heads, S, S] table (AttnArgs::bias2d) and the padding
+    mask as its key bias.  Against the f32 oracle (the bf16 bar of the test above) and against the one-query-per-wave kernel
+    (LTX_T5_ATTN_MFMA=0), with and without a mask, ragged S."""
+    kw = dict(vocab_size=120, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=4)
+    cfg = O.T5Config(**kw)
+    g = torch.Generator().manual_seed(31)
+    p = {}
+    for k, shp in O.t5_weight_shapes(cfg).items():
+        if "relative_attention_bias" in k:
+            p[k] = torch.randn(shp, generator=g)
+        elif len(shp) == 2:
+            p[k] = torch.randn(shp, generator=g) / shp[1] ** 0.5 * (3.0 if "SelfAttention.q" in k else 1.0)
+        else:
+            p[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+    p = {k: v.bfloat16().float() for k, v in p.items()}
+    enc = hip.T5TextEncoder(hip.T5EncoderConfig(**kw), {k: v.to(DEV) for k, v in p.items()}, torch.bfloat16)
+    for S in (4, 28, 128):
+        ids = torch.randint(0, 120, (2, S), generator=g)
+        mask = torch.ones(2, S); mask[0, S // 2:] = 0
+        for am in (None, mask):
+            want = O.t5_encoder_forward(p, cfg, ids, torch.float32, attention_mask=am) if am is not None else O.t5_encoder_forward(p, cfg, ids)
+            d_ref = rel_l2((O.t5_encoder_forward(p, cfg, ids, torch.bfloat16, attention_mask=am) if am is not None else O.t5_encoder_forward(p, cfg, ids, torch.bfloat16)).float(), want)
+            hip.prof_enable(True)
+            got = enc.forward(ids, am).float().cpu()
+            _, _, n_self = hip.prof_report(2); _, _, n_cross = hip.prof_report(3)
+            hip.prof_enable(False)
+            assert n_self + n_cross == kw["num_layers"], "the MFMA attention kernel did not serve the layers"
+            old = os.environ.get("LTX_T5_ATTN_MFMA")
+            os.environ["LTX_T5_ATTN_MFMA"] = "0"
+            try:
+                scalar = enc.forward(ids, am).float().cpu()
+            finally:
+                if old is None: os.environ.pop("LTX_T5_ATTN_MFMA")
+                else: os.environ["LTX_T5_ATTN_MFMA"] = old
+            rows = slice(None) if am is None else None
+            e_new, e_old = rel_l2(got, want), rel_l2(scalar, want)
+            assert e_new <= max(2.0 * d_ref, 2e-2), (S, am is not None, e_new, d_ref)
+            assert e_new <= 1.5 * e_old + 2e-3, (S, e_new, e_old)           # no worse than the kernel it replaces
+
+
 def test_frame_output_rgb8_and_png_files(hip, tmp_path):
     """main.rs:653-675: [B,3,F,H,W] f32 -> per-frame HWC u8 (clamp, truncating cast) on the device, frame_%04d.png on disk."""
     from test_frames_cpu import read_png
