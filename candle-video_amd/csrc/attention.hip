@@ -693,48 +693,21 @@ extern "C" int ltx_dbg_xtrace(unsigned* out, int n) { return hipMemcpyFromSymbol
 #ifndef XATTN_WPS
 #define XATTN_WPS 3          // waves per SIMD the kernel is compiled for (blocks per CU): 2 = round 3's build (254 registers)
 #endif
-template <bool B2D>          // B2D: a [heads, Sq, Sk] bias on top of the key bias (T5 self-attention over <= 128 tokens)
-__global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(const AttnArgs a, int groups) {
-    constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2, NKB = XKV / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
-    __shared__ __attribute__((aligned(16))) float sbias[XKV];
+// The units of one block (after K/V and the key bias sit in LDS), for a key set of NKB blocks of 32 keys: everything that scales
+// with the number of keys (S MFMAs, exps, P V MFMAs, bias registers) is sized by NKB, chosen per BLOCK from the number of keys
+// its batch row really has (AttnArgs::k_count, or Sk): BASELINE's prompts keep 32 of 128 text tokens.
+template <bool B2D, int NKB>
+__device__ __forceinline__ void cross64_units(const AttnArgs& a, int groups, const unsigned char* smem, const float* sbias, int b, int head, int grp) {
+    constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8, NKS = 4, NDB = 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int grp = blockIdx.x % groups, bh = blockIdx.x / groups;
-    const int head = bh % a.heads, b = bh / a.heads;
-    XSTAMP(0);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + head * HD;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
     const float LOG2E = 1.4426950408889634f;
     const float c = a.q_prescaled ? 1.0f : a.scale * LOG2E;
-
-    // K/V -> LDS by buffer LDS-DMA: 16 pieces of 8 rows per matrix, 4 + 4 per wave
-    {
-        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
-        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
-        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = wave * 4 + j, row = piece * 8 + lane / KCPR, pc = lane % KCPR;
-            const uint32_t ko = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
-            const uint32_t vo = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, (int)ko, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + XKV * KROW + piece * 1024), 16, (int)vo, 0, 0, 0);
-        }
-        if (tid < XKV) {
-            float bv = tid < a.Sk ? 0.f : -INFINITY;
-            if (a.bias && tid < a.Sk) bv = a.bias[(int64_t)b * a.Sk + tid] * LOG2E;
-            sbias[tid] = bv;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
     // the key bias stays in LDS and is read in accumulator order (key = kb*32 + (i&3) + 8*(i>>2) + 4h) where the scores are
     // scaled: 64 registers less than keeping the tuples (round 4: three blocks per CU instead of two)
     auto bias4 = [&](int kb, int g4) { return *reinterpret_cast<const f32x4*>(&sbias[kb * 32 + 8 * g4 + 4 * h]); };
-    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
     uint32_t k_base[NKS], tr_base[NDB];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) k_base[ks] = smem_base + r * KROW + kswz<KCPR>(r, 2 * ks + h) * 16;
@@ -844,6 +817,7 @@ __global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(
         // O^T = V^T . P^T
         f32x16 acc_o[NDB];
         constexpr int NSTEP = NDB * NKB * 2;                 // step n = d*(2*NKB) + kb*2 + s
+        constexpr int RING = NSTEP < 4 ? NSTEP : 4;
         u32x2 vr[4][2];
         auto issue = [&](auto n_tag) {
             constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
@@ -851,7 +825,7 @@ __global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(
             vr[n & 3][0] = ds_tr_read<imm>(tr_base[d]);
             vr[n & 3][1] = ds_tr_read<imm + 8 * VROW>(tr_base[d]);
         };
-        static_for<0, 4>([&](auto n_tag) { issue(n_tag); });
+        static_for<0, RING>([&](auto n_tag) { issue(n_tag); });
         static_for<0, NSTEP>([&](auto n_tag) {
             constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
             constexpr int after = (NSTEP - 1 - n < 3 ? NSTEP - 1 - n : 3) * 2;
@@ -886,6 +860,55 @@ __global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (xi < 8) XSTAMP(xi);
 #endif
+}
+
+template <bool B2D>          // B2D: a [heads, Sq, Sk] bias on top of the key bias (T5 self-attention over <= 128 tokens)
+__global__ __launch_bounds__(256, B2D ? 2 : XATTN_WPS) void attn_cross64_kernel(const AttnArgs a, int groups) {
+    constexpr int HD = 64, KROW = 128, VROW = 128, KCPR = 8, VCPR = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XKV * (KROW + VROW)];
+    __shared__ __attribute__((aligned(16))) float sbias[XKV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x % groups, bh = blockIdx.x / groups;
+    const int head = bh % a.heads, b = bh / a.heads;
+    XSTAMP(0);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Sk * a.ldk + head * HD;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Sk * a.ldv + head * HD;
+    const float LOG2E = 1.4426950408889634f;
+    // keys this batch row really has: the first k_count[b] rows of its K / V / bias (AttnArgs::k_count), or all Sk
+    int nkeys = a.Sk;
+    if (a.k_count) { nkeys = __builtin_amdgcn_readfirstlane(a.k_count[b]); if (nkeys > a.Sk) nkeys = a.Sk; if (nkeys < 1) nkeys = 1; }
+    const int nkb = (nkeys + 31) >> 5;
+
+    // K/V -> LDS by buffer LDS-DMA: 16 pieces of 8 rows per matrix, 4 + 4 per wave; only the key blocks that are multiplied
+    // (rows of a multiplied block past nkeys must hold finite values: the caller's buffers, or zeros past Sk by buffer range)
+    {
+        const uint32_t k_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldk * 2u + HD * 2u;
+        const uint32_t v_bytes = (uint32_t)(a.Sk - 1) * (uint32_t)a.ldv * 2u + HD * 2u;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)k_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), 0, (int)v_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j, row = piece * 8 + lane / KCPR, pc = lane % KCPR;
+            if (piece * 8 >= nkb * 32) continue;            // wave-uniform
+            const uint32_t ko = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz<KCPR>(row, pc) * 16u;
+            const uint32_t vo = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz<VCPR>(row, pc) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, (int)ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + XKV * KROW + piece * 1024), 16, (int)vo, 0, 0, 0);
+        }
+        if (tid < XKV) {
+            float bv = tid < nkeys ? 0.f : -INFINITY;
+            if (a.bias && tid < nkeys) bv = a.bias[(int64_t)b * a.Sk + tid] * LOG2E;
+            sbias[tid] = bv;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    switch (nkb) {                                          // block-uniform
+        case 1: cross64_units<B2D, 1>(a, groups, smem, sbias, b, head, grp); break;
+        case 2: cross64_units<B2D, 2>(a, groups, smem, sbias, b, head, grp); break;
+        case 3: cross64_units<B2D, 3>(a, groups, smem, sbias, b, head, grp); break;
+        default: cross64_units<B2D, 4>(a, groups, smem, sbias, b, head, grp); break;
+    }
 }
 
 // ---- exact-f32 flash attention (parity mode): one query per lane, 64 queries per block ----
@@ -975,6 +998,10 @@ bool ltx_attention_rowsq_ok(int hd, int Sk, int D) {
     return hd == 64 && Sk <= XKV && attn_cross_enabled() && D % 512 == 0 && D / 128 <= 16 && !(e && e[0] == '0');
 }
 
+// Shape-only: whether the short-key-set kernel (attn_cross64_kernel: bf16, head_dim 64, at most 128 keys) serves a launch; what
+// AttnArgs::k_count / bias2d / q_rowsq need
+bool ltx_attention_cross64_ok(int hd, int Sk) { return hd == 64 && Sk <= XKV && attn_cross_enabled(); }
+
 bool ltx_attention_prescale_ok(int hd) {
     const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
     return (hd == 64 || hd == 128) && !(e && e[0] == '0');
@@ -997,6 +1024,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         if (a.q_rowsq && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled() && a.q_rowsq_n >= 4 && a.q_rowsq_n <= 16 && a.q_rowsq_n % 4 == 0 && a.q_rowsq_D > 0))
             LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is served by the short-key-set head_dim-64 kernel only (4..16 partials per row, a multiple of 4)");
         if (a.bias2d && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled())) LTX_FAIL(LTX_ERR_ARG, "attention: bias2d is served by the short-key-set head_dim-64 kernel only");
+        if (a.k_count && !ltx_attention_cross64_ok(a.hd, a.Sk)) LTX_FAIL(LTX_ERR_ARG, "attention: k_count is served by the short-key-set head_dim-64 kernel only");
         if (a.hd == 64 && a.Sk <= XKV && attn_cross_enabled()) {
             // few keys (text tokens): K/V resident in LDS, one-shot softmax.  Blocks: (batch, head) x groups, sized for ~2 per CU
             const int nunits = cdiv(a.Sq, 32);
@@ -1046,7 +1074,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
             default: LTX_FAIL(LTX_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
         }
     } else {
-        if (a.q_rowsq) LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is a bf16 path");
+        if (a.q_rowsq || a.k_count) LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq / k_count are bf16 paths");
         if (a.ldq % 4 || a.ldk % 4 || a.ldv % 4 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         dim3 grid((unsigned)cdiv(a.Sq, 64), (unsigned)a.heads, (unsigned)a.B), block(64);
         switch (a.hd) {

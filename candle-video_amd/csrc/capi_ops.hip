@@ -140,6 +140,35 @@ extern "C" int ltx_op_attention_rowsq(const void* q, const void* k, const void* 
     return ltx_launch_attention(a, LTX_DT_BF16, (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_attention_compact(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                                        int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias,
+                                        const float* q_rowsq, int q_rowsq_n, int q_rowsq_D, float q_rowsq_eps, int* counts_out, ltx_stream stream) {
+    if (!q || !k || !v || !o || !key_bias) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention_compact: null tensor");
+    if (!ltx_attention_cross64_ok(hd, Sk) || B < 1 || ldk != heads * hd || ldv != heads * hd) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention_compact: bf16, head_dim 64, at most 128 keys, dense k / v rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = heads * hd;
+    void *kc = nullptr, *vc = nullptr, *bc = nullptr, *idx = nullptr, *cnt = nullptr;
+    auto free_all = [&]() { for (void* p : {kc, vc, bc, idx, cnt}) if (p) (void)hipFree(p); };
+    const size_t rows = (size_t)B * Sk;
+    if (hipMalloc(&kc, rows * D * 2) != hipSuccess || hipMalloc(&vc, rows * D * 2) != hipSuccess || hipMalloc(&bc, rows * 4) != hipSuccess ||
+        hipMalloc(&idx, rows * 4) != hipSuccess || hipMalloc(&cnt, (size_t)B * 4) != hipSuccess) { free_all(); LTX_FAIL(LTX_ERR_HIP, "hipMalloc"); }
+    int rc = ltx_launch_key_compact(key_bias, B, Sk, (int*)idx, (int*)cnt, (float*)bc, s);
+    if (rc == LTX_OK) rc = ltx_launch_gather_rows(k, kc, (const int*)idx, (const int*)cnt, 1, B, Sk, D * 2, s);
+    if (rc == LTX_OK) rc = ltx_launch_gather_rows(v, vc, (const int*)idx, (const int*)cnt, 1, B, Sk, D * 2, s);
+    if (rc == LTX_OK) {
+        AttnArgs a; a.q = q; a.k = kc; a.v = vc; a.o = o; a.ldq = ldq; a.ldk = D; a.ldv = D; a.ldo = ldo;
+        a.B = B; a.Sq = Sq; a.Sk = Sk; a.heads = heads; a.hd = hd; a.scale = scale; a.bias = (const float*)bc; a.k_count = (const int*)cnt;
+        if (q_rowsq) { a.q_rowsq = q_rowsq; a.q_rowsq_n = q_rowsq_n; a.q_rowsq_D = q_rowsq_D; a.q_rowsq_eps = q_rowsq_eps; }
+        rc = ltx_launch_attention(a, LTX_DT_BF16, s);
+    }
+    if (rc == LTX_OK && counts_out && hipMemcpyAsync(counts_out, cnt, (size_t)B * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LTX_ERR_HIP;
+    const hipError_t e = hipStreamSynchronize(s);
+    free_all();
+    if (rc != LTX_OK) return rc;
+    if (e != hipSuccess) { ltx_set_error(hipGetErrorString(e)); return LTX_ERR_HIP; }
+    return LTX_OK;
+}
+
 extern "C" int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                                           int ldq, int ldk, int ldv, int ldo, ltx_stream stream) {
     if (!q || !k || !v || !o) LTX_FAIL(LTX_ERR_ARG, "ltx_op_attention_prescaled: null tensor");

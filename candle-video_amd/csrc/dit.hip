@@ -4,6 +4,7 @@
 //   per block: rms+AdaLN | fused QKV GEMM | qk-RMSNorm+RoPE | flash attention | to_out GEMM (+gate*x+h)
 //              | q GEMM | q-norm | (k,v GEMM | k-norm) | cross attention (key bias) | to_out GEMM (+h)
 //              | rms+AdaLN | FF1 GEMM (+GELU-tanh) | FF2 GEMM (+gate*x+h)
+#include <cstring>
 #include <deque>
 #include "model_util.h"
 
@@ -17,7 +18,20 @@ struct DitCtx {                      // cached text context (see ltx_dit_forward
     int B = 0, K = 0, iodt = 0; bool valid = false;
     bool fold_q2 = false;            // k additionally carries attn2.norm_q.weight (the q-norm folded into cross attention)
     DevBuf kv, bias;                 // [L][B*K][2D] (k already RMS-normed), [B*K]
+    // keys the mask leaves alive, compacted to the front of every batch row (AttnArgs::k_count): the cross-attention kernel then
+    // multiplies ceil(count / 32) key blocks instead of ceil(K / 32) - BASELINE's prompts keep 32 of 128 text tokens
+    bool compact = false;
+    DevBuf kvc, biasc, kidx, kcount; // [L][B*K][2D], [B*K] f32, [B*K] int, [B] int
 };
+
+// AdaLayerNormSingle's output for one set of timesteps (ltx_transformer.rs:262-309): a function of the timestep values and the
+// weights alone, so the chain (sinusoid -> Linear -> SiLU -> Linear -> SiLU -> Linear(6D) -> + tables: 8 launches per forward) runs
+// once per distinct timestep vector of a model and stream; a sampler revisits the same few timesteps for every video.
+struct DitTimeEntry {
+    float t[8] = {0}; int B = 0; hipStream_t stream = nullptr; bool valid = false; uint64_t used = 0;
+    DevBuf ada, adaf;                // [L][B][6D] f32, [2][B][D] f32
+};
+constexpr int kDitTimeEntries = 64;
 
 struct ltx_dit {
     ltx_dit_config cfg{};
@@ -33,6 +47,9 @@ struct ltx_dit {
     std::vector<int> skip_blocks;
     std::deque<DitCtx> ctxs;         // deque: entries must not move while `ctx` points at one
     bool ctx_mode = false;
+    std::deque<DitTimeEntry> tcache; uint64_t tclock = 0;
+    // RoPE tables of the caching scope (ltx_dit_context_cache: the caller keeps coords / geometry constant inside it): what cosb / sinb hold
+    struct { bool valid = false; const float* coords = nullptr; float rs[3] = {0, 0, 0}; bool has_rs = false; int B = 0, S = 0, F = 0, H = 0, W = 0; hipStream_t stream = nullptr; } rope_key;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
     DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq, hsq;
@@ -41,8 +58,10 @@ struct ltx_dit {
         owned.clear();
         DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq, &hsq};
         for (DevBuf* b : bs) b->release();
-        for (auto& e : ctxs) { e.kv.release(); e.bias.release(); }
+        for (auto& e : ctxs) { e.kv.release(); e.bias.release(); e.kvc.release(); e.biasc.release(); e.kidx.release(); e.kcount.release(); }
         ctxs.clear();
+        for (auto& e : tcache) { e.ada.release(); e.adaf.release(); }
+        tcache.clear();
     }
 };
 
@@ -204,7 +223,6 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     LTX_TRY(m->tproj.ensure((size_t)B * 256 * esz)); LTX_TRY(m->e1.ensure((size_t)B * D * esz));
     LTX_TRY(m->emb.ensure((size_t)B * D * esz)); LTX_TRY(m->embs.ensure((size_t)B * D * esz));
     LTX_TRY(m->temb.ensure((size_t)B * 6 * D * esz));
-    LTX_TRY(m->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(m->adaf.ensure((size_t)2 * B * D * sizeof(float)));
     LTX_TRY(m->cosb.ensure(M * (D / 2) * sizeof(float))); LTX_TRY(m->sinb.ensure(M * (D / 2) * sizeof(float)));
     LTX_TRY(m->bias.ensure(MK * sizeof(float)));
     LTX_TRY(m->outT.ensure(M * c.out_channels * esz));
@@ -235,7 +253,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         GemmArgs gp; gp.A = m->attn.p; gp.W = m->blocks[0].o2.w; gp.C = m->h.p; gp.bias = m->blocks[0].o2.b; gp.resid = m->h.p;
         gp.M = (int)M; gp.N = m->blocks[0].o2.out; gp.K = m->blocks[0].o2.in; gp.lda = D; gp.ldc = D; gp.ldr = D;
         GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D;
-        gf.gate = m->ada.as<float>(); gf.gate_stride = 6 * D; gf.rows_per_batch = S;
+        gf.gate = reinterpret_cast<const float*>(m->h.p); gf.gate_stride = 6 * D; gf.rows_per_batch = S;      // (any aligned non-null pointer: a fit test, nothing is launched)
         presum = (!(pe && pe[0] == '0') && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || (pe && pe[0] == '2');
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
@@ -248,14 +266,26 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
 
     // AdaLayerNormSingle (:262-267): sinusoid(256) -> Linear -> SiLU -> Linear = embedded_timestep ; SiLU -> Linear(6D) = temb
     TimeVec tv; tv.n = B; for (int i = 0; i < 8; ++i) tv.t[i] = i < B ? timestep[i] : 0.f;
-    LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
-    LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
-    LTX_TRY(ltx_launch_silu(m->e1.p, m->e1.p, (int64_t)B * D, dt, s));
-    LTX_TRY(ltx_linear(m->te2, m->e1.p, D, m->emb.p, D, B, dt, EPI_BIAS, s));
-    LTX_TRY(ltx_launch_silu(m->emb.p, m->embs.p, (int64_t)B * D, dt, s));
-    LTX_TRY(ltx_linear(m->te_lin, m->embs.p, D, m->temb.p, 6 * D, B, dt, EPI_BIAS, s));
-    LTX_TRY(ltx_launch_ada(m->ada.as<float>(), m->sst_blocks, m->temb.p, L, B, 6 * D, dt, s));
-    LTX_TRY(ltx_launch_ada(m->adaf.as<float>(), m->sst_final, m->emb.p, 2, B, D, dt, s));
+    DitTimeEntry* te = nullptr;
+    for (auto& e : m->tcache) if (e.valid && e.B == B && e.stream == s && !memcmp(e.t, tv.t, sizeof(float) * B)) te = &e;
+    if (!te) {
+        if ((int)m->tcache.size() < kDitTimeEntries) { m->tcache.emplace_back(); te = &m->tcache.back(); }
+        else { te = &m->tcache.front(); for (auto& e : m->tcache) if (e.used < te->used) te = &e; }
+        te->valid = false;
+        LTX_TRY(te->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(te->adaf.ensure((size_t)2 * B * D * sizeof(float)));
+        LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
+        LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
+        LTX_TRY(ltx_launch_silu(m->e1.p, m->e1.p, (int64_t)B * D, dt, s));
+        LTX_TRY(ltx_linear(m->te2, m->e1.p, D, m->emb.p, D, B, dt, EPI_BIAS, s));
+        LTX_TRY(ltx_launch_silu(m->emb.p, m->embs.p, (int64_t)B * D, dt, s));
+        LTX_TRY(ltx_linear(m->te_lin, m->embs.p, D, m->temb.p, 6 * D, B, dt, EPI_BIAS, s));
+        LTX_TRY(ltx_launch_ada(te->ada.as<float>(), m->sst_blocks, m->temb.p, L, B, 6 * D, dt, s));
+        LTX_TRY(ltx_launch_ada(te->adaf.as<float>(), m->sst_final, m->emb.p, 2, B, D, dt, s));
+        memcpy(te->t, tv.t, sizeof(te->t)); te->B = B; te->stream = s; te->valid = true;
+    }
+    te->used = ++m->tclock;
+    const float* ada_all = te->ada.as<float>();
+    const float* adaf = te->adaf.as<float>();
 
     // Text context: caption projection (:186-190), mask bias (:1059-1070) and, for every layer, the cross-attention
     // K/V projections + k-RMSNorm (:667-672).  None of it depends on the timestep or the latents, so inside a
@@ -279,27 +309,47 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             if (fold_q2) k2.w0b = m->blocks[l].nq2;
             LTX_TRY(ltx_launch_qknorm_rope(k2, dt, s));
         }
+        // Masked text tokens (bias -10000, :1059-1070) get softmax weight exp(s - 10000 - max) = +0.0f: exactly nothing.  Where the
+        // short-key-set kernel serves the layer, the keys that are left are moved to the front of their batch row once per context and
+        // the kernel sizes its work by their number (device-side count: no host synchronisation).
+        const char* xc = getenv("LTX_XATTN_COMPACT");        // "0": every layer multiplies all K keys (A/B aid)
+        ctx->compact = enc_mask && dt == LTX_DT_BF16 && ltx_attention_cross64_ok(hd, K) && !(xc && xc[0] == '0');
+        if (ctx->compact) {
+            LTX_TRY(ctx->kvc.ensure((size_t)L * MK * 2 * D * esz)); LTX_TRY(ctx->biasc.ensure(MK * sizeof(float)));
+            LTX_TRY(ctx->kidx.ensure(MK * sizeof(int))); LTX_TRY(ctx->kcount.ensure((size_t)B * sizeof(int)));
+            LTX_TRY(ltx_launch_key_compact(ctx->bias.as<float>(), B, K, ctx->kidx.as<int>(), ctx->kcount.as<int>(), ctx->biasc.as<float>(), s));
+            LTX_TRY(ltx_launch_gather_rows(ctx->kv.p, ctx->kvc.p, ctx->kidx.as<int>(), ctx->kcount.as<int>(), L, B, K, (int)(2 * D * esz), s));
+        }
         ctx->valid = true;     // outside a caching scope the entry is invalidated again at the end of this forward
     }
     const float* bias = enc_mask ? ctx->bias.as<float>() : nullptr;
 
-    // RoPE tables (:436-524)
+    // RoPE tables (:436-524); inside a caching scope the tables of the previous forward are kept when coords / geometry are the same
     {
-        RopeTableArgs r;
-        r.cos = m->cosb.as<float>(); r.sin = m->sinb.as<float>(); r.freqs = m->rope_freqs;
-        r.B = B; r.D = D;
-        if (video_coords) {
-            r.use_coords = 1; r.coords = video_coords; r.F = 1; r.H = 1; r.W = S;
-            r.gscale[0] = (float)(1.0 / 20.0); r.gscale[1] = (float)(1.0 / 2048.0); r.gscale[2] = (float)(1.0 / 2048.0);
-        } else {
-            r.F = num_frames; r.H = height; r.W = width;
-            if (rope_scale) {
-                r.gscale[0] = (float)((double)rope_scale[0] * c.patch_size_t / 20.0);
-                r.gscale[1] = (float)((double)rope_scale[1] * c.patch_size / 2048.0);
-                r.gscale[2] = (float)((double)rope_scale[2] * c.patch_size / 2048.0);
+        auto& rk = m->rope_key;
+        const bool same = m->ctx_mode && rk.valid && rk.coords == video_coords && rk.B == B && rk.S == S && rk.F == num_frames && rk.H == height && rk.W == width &&
+                          rk.stream == s && rk.has_rs == (rope_scale != nullptr) && (!rope_scale || !memcmp(rk.rs, rope_scale, sizeof(rk.rs)));
+        if (!same) {
+            rk.valid = false;
+            RopeTableArgs r;
+            r.cos = m->cosb.as<float>(); r.sin = m->sinb.as<float>(); r.freqs = m->rope_freqs;
+            r.B = B; r.D = D;
+            if (video_coords) {
+                r.use_coords = 1; r.coords = video_coords; r.F = 1; r.H = 1; r.W = S;
+                r.gscale[0] = (float)(1.0 / 20.0); r.gscale[1] = (float)(1.0 / 2048.0); r.gscale[2] = (float)(1.0 / 2048.0);
+            } else {
+                r.F = num_frames; r.H = height; r.W = width;
+                if (rope_scale) {
+                    r.gscale[0] = (float)((double)rope_scale[0] * c.patch_size_t / 20.0);
+                    r.gscale[1] = (float)((double)rope_scale[1] * c.patch_size / 2048.0);
+                    r.gscale[2] = (float)((double)rope_scale[2] * c.patch_size / 2048.0);
+                }
             }
+            LTX_TRY(ltx_launch_rope_table(r, s));
+            rk.coords = video_coords; rk.B = B; rk.S = S; rk.F = num_frames; rk.H = height; rk.W = width; rk.stream = s;
+            rk.has_rs = rope_scale != nullptr; if (rope_scale) memcpy(rk.rs, rope_scale, sizeof(rk.rs));
+            rk.valid = m->ctx_mode;
         }
-        LTX_TRY(ltx_launch_rope_table(r, s));
     }
 
     const float attn_scale = 1.0f / std::sqrt((float)hd);
@@ -316,7 +366,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             if (any) HIP_TRY(hipMemcpyAsync(m->orig.p, m->h.p, M * D * esz, hipMemcpyDeviceToDevice, s));
         }
         const DitBlock& b = m->blocks[l];
-        const float* ada = m->ada.as<float>() + (size_t)l * B * 6 * D;
+        const float* ada = ada_all + (size_t)l * B * 6 * D;
         // norm1 + AdaLN (shift_msa = row 0, scale_msa = row 1)
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
@@ -351,9 +401,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         LTX_TRY(ltx_linear(b.o1, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 2 * D, 6 * D, S));
         hsq_valid = false;
         // cross attention (no pre-norm, no RoPE, q/k RMSNorm, additive key bias)
-        const char* kvl = (const char*)ctx->kv.p + (size_t)l * MK * 2 * D * esz;
+        const char* kvl = (const char*)(ctx->compact ? ctx->kvc.p : ctx->kv.p) + (size_t)l * MK * 2 * D * esz;
         AttnArgs ax; ax.q = m->qkv.p; ax.k = kvl; ax.v = kvl + (size_t)D * esz; ax.o = m->attn.p;
         ax.ldq = D; ax.ldk = ax.ldv = 2 * D; ax.ldo = D; ax.B = B; ax.Sq = S; ax.Sk = K; ax.heads = H; ax.hd = hd; ax.scale = attn_scale; ax.bias = bias;
+        if (ctx->compact) { ax.bias = ctx->biasc.as<float>(); ax.k_count = ctx->kcount.as<int>(); }
         if (fold_q2) {
             GemmArgs g;
             g.A = m->h.p; g.W = b.q2.w; g.C = m->qkv.p; g.bias = b.q2.b; g.M = (int)M; g.N = b.q2.out; g.K = b.q2.in; g.lda = D; g.ldc = D;
@@ -382,7 +433,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     // final LayerNorm (no affine) + modulation (:1126-1161), proj_out (:1163)
     {
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
-        rn.kind = 1; rn.eps = 1e-6f; rn.shift = m->adaf.as<float>(); rn.scale = m->adaf.as<float>() + (size_t)B * D;
+        rn.kind = 1; rn.eps = 1e-6f; rn.shift = adaf; rn.scale = adaf + (size_t)B * D;
         rn.rows_per_batch = S; rn.mod_stride = D;
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         void* dst = iodt == dt ? out : m->outT.p;
@@ -425,6 +476,7 @@ extern "C" int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, 
 extern "C" int ltx_dit_context_cache(ltx_dit* m, int enable) {
     if (!m) LTX_FAIL(LTX_ERR_ARG, "ltx_dit_context_cache: null handle");
     for (auto& e : m->ctxs) e.valid = false;
+    m->rope_key.valid = false;
     m->ctx_mode = enable != 0;
     return LTX_OK;
 }

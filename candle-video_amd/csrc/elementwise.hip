@@ -48,6 +48,39 @@ __global__ void mask_bias_kernel(float* out, const float* mask, int64_t n) {
     GRID_STRIDE(i, n) out[i] = (1.0f - mask[i]) * -10000.0f;      // ltx_transformer.rs:1063
 }
 
+// one wave per batch row: ordered compaction of the keys whose bias is above the drop threshold (kernels.h: k_count)
+__global__ __launch_bounds__(64) void key_compact_kernel(const float* bias, int K, int* idx, int* count, float* bias_c) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* bb = bias + (int64_t)b * K;
+    int n = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const float v = k < K ? bb[k] : -INFINITY;
+        const bool keep = v > -5000.0f;
+        const unsigned long long m = __ballot(keep);
+        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) { idx[(int64_t)b * K + pos] = k; bias_c[(int64_t)b * K + pos] = v; }
+        n += __popcll(m);
+    }
+    if (n == 0) {                                           // every key masked: the mask is a constant shift, keep them all
+        for (int k = lane; k < K; k += 64) { idx[(int64_t)b * K + k] = k; bias_c[(int64_t)b * K + k] = bb[k]; }
+        n = K;
+    }
+    for (int k = n + lane; k < K; k += 64) { idx[(int64_t)b * K + k] = 0; bias_c[(int64_t)b * K + k] = -INFINITY; }
+    if (lane == 0) count[b] = n;
+}
+
+// 16 bytes per thread; one block per destination row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* src, uint4* dst, const int* idx, const int* count, int B, int K, int row_vecs) {
+    const int64_t row = blockIdx.x;                         // (l * B + b) * K + pos
+    const int pos = (int)(row % K), b = (int)((row / K) % B);
+    const int64_t base = row - pos;
+    const bool live = pos < count[b];
+    const uint4* sp = src + (base + (live ? idx[(int64_t)b * K + pos] : 0)) * row_vecs;
+    uint4* dp = dst + row * row_vecs;
+    for (int i = threadIdx.x; i < row_vecs; i += 256) dp[i] = live ? sp[i] : make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ void skip_blend_kernel(void* h, const void* orig, TimeVec m, int64_t rows_per_batch, int D, int dt) {
     const int64_t n = (int64_t)m.n * rows_per_batch * D;
     GRID_STRIDE(i, n) {
@@ -182,6 +215,18 @@ int ltx_launch_ada(float* out, const void* tables, const void* temb, int nl, int
 }
 int ltx_launch_mask_bias(float* out, const float* mask, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(mask_bias_kernel, grid_for(n), dim3(256), 0, s, out, mask, n);
+    LTX_CHECK_LAUNCH(); return LTX_OK;
+}
+int ltx_launch_key_compact(const float* bias, int B, int K, int* idx, int* count, float* bias_c, hipStream_t s) {
+    if (!bias || !idx || !count || !bias_c || B < 1 || K < 1) LTX_FAIL(LTX_ERR_ARG, "key_compact: bad argument");
+    hipLaunchKernelGGL(key_compact_kernel, dim3((unsigned)B), dim3(64), 0, s, bias, K, idx, count, bias_c);
+    LTX_CHECK_LAUNCH(); return LTX_OK;
+}
+int ltx_launch_gather_rows(const void* src, void* dst, const int* idx, const int* count, int nl, int B, int K, int row_bytes, hipStream_t s) {
+    if (!src || !dst || !idx || !count || nl < 1 || B < 1 || K < 1 || row_bytes < 16 || row_bytes % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        LTX_FAIL(LTX_ERR_ARG, "gather_rows: bad argument");
+    if ((int64_t)nl * B * K > 0x7fffffffLL) LTX_FAIL(LTX_ERR_ARG, "gather_rows: too many rows");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nl * B * K)), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), idx, count, B, K, row_bytes / 16);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }
 int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s) {

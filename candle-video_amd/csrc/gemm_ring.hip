@@ -394,13 +394,17 @@ const char* ltx_gemm_ring_tile_name(int i) { return i >= 0 && i < kNumRing ? kRi
 int ltx_gemm_ring_tile_bm(int i) { return i >= 0 && i < kNumRing ? kRing[i].bm : 1; }
 int ltx_gemm_ring_tile_bn(int i) { return i >= 0 && i < kNumRing ? kRing[i].bn : 1; }
 
-// Linear layers of at most 2048 rows whose operands the 32-bit buffer offsets reach (gemm_big's own bound), K in whole 16-byte
+// Linear layers of at most 2048 rows (the plan measurement offers the family up to 512: ltx_gemm_split_factor) whose operands the 32-bit buffer offsets reach (gemm_big's own bound), K in whole 16-byte
 // chunks, 4-column output groups inside or outside N as a whole.
 bool ltx_gemm_ring_fits(const GemmArgs& g, int epi) {
     const char* e = getenv("LTX_GEMM_RING");
     if (e && e[0] == '0') return false;
     if (g.conv || g.pn_on || g.M < 1 || g.M > 2048 || g.N < 32 || g.N % 4 || g.K % 8 || g.lda % 8) return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
+    // the epilogue's prefetch loads 8 bytes of the residual row and 16 bytes of the gate row per lane (gemm_asm16's conditions)
+    if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
+    if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
+    if (g.bias && ((uintptr_t)g.bias & 7)) return false;
     return ltx_gemm_big_fits(g);
 }
 

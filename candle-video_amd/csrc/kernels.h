@@ -163,6 +163,12 @@ struct AttnArgs {
     // 1 / sqrt(sum_g q_rowsq[i * q_rowsq_n + g] / q_rowsq_D + q_rowsq_eps), the RMS-norm scalar of query row i (GemmArgs::rowsq
     // of the projection that produced q); the norm's weight vector is folded into k by the caller.
     const float* q_rowsq = nullptr; int q_rowsq_n = 0, q_rowsq_D = 0; float q_rowsq_eps = 0.f;
+    // Valid keys per batch row (device int [B], attn_cross64_kernel only): batch row b attends to the FIRST k_count[b] rows of its
+    // K / V / bias (row stride between batch rows stays Sk); rows from k_count[b] up to the next multiple of 32 must be finite.
+    // The caller compacts the keys an additive mask leaves alive (ltx_launch_key_compact / ltx_launch_gather_rows): a key whose
+    // bias is <= -5000 contributes exp(s - 5000 - max) = +0.0f exactly in f32 as long as scores stay within +-4000 of each other,
+    // so dropping it changes nothing (ltx_transformer.rs:1059-1070 builds -10000 for masked text tokens).
+    const int* k_count = nullptr;
     const int* gate_flag = nullptr; int gate_ticket = 0;   // attn_bf16_kernel<128>: run only if *gate_flag == gate_ticket (exact pass after attn_q128's overflow flag)
 };
 bool ltx_attention_q128_fits(const AttnArgs& a);           // attn_q128.hip: head_dim 128 one-wave-per-SIMD kernel
@@ -172,6 +178,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)
 bool ltx_attention_q64_fits(const AttnArgs& a);   // attn_q64.hip: every row offset below 2^31 (its 32-bit buffer arithmetic)
 bool ltx_attention_prescale_ok(int hd);
+bool ltx_attention_cross64_ok(int hd, int Sk);   // shape-only: the short-key-set kernel serves the launch (k_count / bias2d / q_rowsq)
 bool ltx_attention_rowsq_ok(int hd, int Sk, int D);   // shape-only: cross attention can fold the q RMS-norm (AttnArgs::q_rowsq)           // whether the bf16 kernel has a q-prescaled instantiation for this head dim
 
 // ---------------- small elementwise kernels (elementwise.hip) ----------------
@@ -186,6 +193,13 @@ int ltx_launch_cast(const void* x, int xdt, void* y, int ydt, int64_t n, hipStre
 // ada[l][b][j] = table_l[j] + temb[b][j]  (j < width), tables given as nl pointers packed contiguously [nl][width] (T), out f32
 int ltx_launch_ada(float* out, const void* tables, const void* temb, int nl, int B, int width, int dtype, hipStream_t s);
 int ltx_launch_mask_bias(float* out, const float* mask, int64_t n, hipStream_t s);
+// Keys an additive key bias leaves alive, per batch row: idx[b][0 .. count[b]) = the keys with bias > -5000 in ascending order
+// (all K keys when none is: a constant shift of every score, softmax unchanged), bias_c[b][pos] = their biases (-inf past
+// count[b]).  bias [B, K] f32 (ltx_launch_mask_bias); idx int [B, K], count int [B].
+int ltx_launch_key_compact(const float* bias, int B, int K, int* idx, int* count, float* bias_c, hipStream_t s);
+// dst[l][b][pos] = src[l][b][idx[b][pos]] for pos < count[b], zeros past it; rows of row_bytes (a multiple of 16) bytes,
+// nl x B x K rows each side
+int ltx_launch_gather_rows(const void* src, void* dst, const int* idx, const int* count, int nl, int B, int K, int row_bytes, hipStream_t s);
 // h = h*(1-m_b) + orig*m_b
 int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s);
 

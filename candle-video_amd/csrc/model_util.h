@@ -9,13 +9,23 @@
 #include "kernels.h"
 #include "../../include/ltxhip.h"
 
+// thread-local "the last failure on this thread was an out-of-memory hipMalloc" (DevBuf::ensure); cleared by the reader
+void ltx_note_oom();
+bool ltx_take_oom();
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int ensure(size_t n) {
         if (n <= bytes) return LTX_OK;
         if (p) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p)); p = nullptr; bytes = 0; }
-        HIP_TRY(hipMalloc(&p, n));
+        const hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            if (e == hipErrorOutOfMemory) ltx_note_oom();     // callers that can shrink their request tell this failure from every other one
+            (void)hipGetLastError();
+            ltx_set_error(std::string("hipMalloc(") + std::to_string(n) + " bytes): " + hipGetErrorString(e)); return LTX_ERR_HIP;
+        }
         bytes = n;
         return LTX_OK;
     }

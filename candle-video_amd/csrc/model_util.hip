@@ -70,3 +70,7 @@ int ltx_linear(const LinearW& l, const void* x, int lda, void* y, int ldc, int M
     }
     return ltx_launch_gemm(g, dtype, epi, s);
 }
+
+static thread_local bool t_oom = false;
+void ltx_note_oom() { t_oom = true; }
+bool ltx_take_oom() { const bool v = t_oom; t_oom = false; return v; }

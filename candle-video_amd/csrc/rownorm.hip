@@ -756,11 +756,12 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     if (a.D % ch != 0 || a.ldx % ch != 0 || a.ldy % ch != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: D/ld must be multiples of the 16-byte chunk");
     if ((a.scale == nullptr) != (a.shift == nullptr)) LTX_FAIL(LTX_ERR_ARG, "rownorm: scale and shift go together");
     const int nch = a.D / ch, lpr = pick_lpr(nch);
+    // (every argument check sits in front of ltx_prof_begin: a failure after it would leave the timing record open)
+    if (a.presum && (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0 || nch > 256 || (nch & (nch - 1)) || a.rows >= 2147483647LL || a.rows_per_batch >= 2147483647LL))
+        LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows of a power-of-two number (<= 256) of 16-byte chunks with a multiple of 4 partials");
     void* tok = nullptr;
     ltx_prof_begin(LTX_PROF_ROWNORM, 2.0 * (double)a.rows * a.D * (dtype == LTX_DT_BF16 ? 2 : 4), s, &tok);
     if (a.presum) {
-        if (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0 || nch > 256 || (nch & (nch - 1)) || a.rows >= 2147483647LL || a.rows_per_batch >= 2147483647LL)
-            LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows of a power-of-two number (<= 256) of 16-byte chunks with a multiple of 4 partials");
         const int rpb = 256 / nch;
         int R = 4;                                           // rows per thread (LTX_NORM_PRESUM_R = 2 / 4 / 8: tuning aid)
         if (const char* re = getenv("LTX_NORM_PRESUM_R")) { const int v = atoi(re); if (v == 2 || v == 4 || v == 8) R = v; }

@@ -153,7 +153,7 @@ int run_attn(const ltx_t5* m, const void* qkv, const float* bias, const float* k
     // per layer at S = 128 (the kernel below gives a query to each WAVE and a key to each lane).  LTX_T5_ATTN_MFMA=0: the kernel below.
     if constexpr (sizeof(T) == 2) {
         const char* e = getenv("LTX_T5_ATTN_MFMA");
-        if (m->cfg.d_kv == 64 && S <= 128 && S % 4 == 0 && !(e && e[0] == '0')) {
+        if (m->cfg.d_kv == 64 && ltx_attention_cross64_ok(64, S) && S % 4 == 0 && !(e && e[0] == '0')) {     // the launcher's own predicate
             const int inner = m->cfg.num_heads * 64;
             AttnArgs a;
             a.q = qkv; a.k = reinterpret_cast<const T*>(qkv) + inner; a.v = reinterpret_cast<const T*>(qkv) + 2 * inner; a.o = out;

@@ -493,10 +493,12 @@ int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, c
             per_window[l.li][l.slot] = cursor + leaf_out * k;
             if (tv) for (int b = 0; b < B; ++b) tvb.t[k * B + b] = tv->t[b];
         }
+        (void)ltx_take_oom();
         const int rc = decoder_forward(v, v->tile_lat.p, n * B, nf, th, tw, tv ? &tvb : nullptr, 0, cursor, s);
         if (rc != LTX_OK) {
-            if (n == 1) return rc;
-            // (most likely an allocation: give this group's leaves back and go on with smaller calls)
+            // only an allocation that did not fit is retried with fewer leaves per call; every other failure (argument, launch)
+            // is deterministic and surfaces at once with its own message
+            if (n == 1 || !ltx_take_oom()) return rc;
             (void)hipGetLastError();
             for (size_t k : grp) done[k] = 0;
             max_n = n / 2 < 1 ? 1 : n / 2;

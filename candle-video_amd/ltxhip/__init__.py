@@ -117,6 +117,7 @@ _SIGS = {
     "ltx_op_linear_packed": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_rownorm_presum": [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp],
     "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
+    "ltx_op_attention_compact": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp, _vp],
     "ltx_op_attention_rowsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ltx_op_qknorm_rope": [_vp, _i64, _i, _i, _vp, _f, _vp, _vp, _i, _vp],
@@ -997,6 +998,18 @@ class ops:
         _check(lib.ltx_op_attention_rowsq(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, k.shape[1], heads, D // heads,
                                           D, D, D, D, C.c_float(scale), _ptr(key_bias), _ptr(q_rowsq), q_rowsq.shape[-1], D, C.c_float(eps), _stream()))
         return o
+
+    @staticmethod
+    def attention_compact(q, k, v, heads, scale, key_bias, q_rowsq=None, eps=1e-5):
+        """ops.attention (bf16, head_dim 64, <= 128 keys, key bias) the way the DiT's cross attention runs it: keys whose bias is
+        above -5000 compacted to the front, only their key blocks multiplied.  Returns (o, keys kept per batch row)."""
+        B, Sq, D = q.shape
+        o = torch.empty_like(q)
+        cnt = torch.zeros(B, dtype=torch.int32, device=q.device)
+        _check(lib.ltx_op_attention_compact(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, k.shape[1], heads, D // heads,
+                                            D, D, D, D, C.c_float(scale), _ptr(key_bias.contiguous()), _ptr(q_rowsq) if q_rowsq is not None else None,
+                                            q_rowsq.shape[-1] if q_rowsq is not None else 0, D, C.c_float(eps), _ptr(cnt), _stream()))
+        return o, cnt
 
     @staticmethod
     def linear_segmented(x, w, bias, seg_width):

@@ -247,7 +247,8 @@ int ltx_plan_load(const char* path);
 int ltx_prof_enable(int on);
 int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count);
 /* the same totals for ONE kernel inside a class: kernel 0 gemm_kernel (128 x 128), 1 gemm_big_kernel, 2 gemm_p8_kernel,
- * 3 conv_halo_kernel, 4 gemm_asm_kernel (32x32x16), 5 gemm_asm16_kernel; classes 2..4 have one kernel each (index 0). */
+ * 3 conv_halo_kernel, 4 gemm_asm_kernel (32x32x16), 5 gemm_asm16_kernel, 6 gemm_ring_kernel; classes 2..4 have one kernel each
+ * (index 0). */
 int ltx_prof_report_kernel(int kind, int kernel, double* total_ms, double* total_work, long long* count);
 
 #ifdef __cplusplus

@@ -76,6 +76,14 @@ int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B
 int ltx_op_attention_rowsq(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                            int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias,
                            const float* q_rowsq, int q_rowsq_n, int q_rowsq_D, float q_rowsq_eps, ltx_stream stream);
+/* ltx_op_attention for bf16, head_dim 64, Sk <= 128 with a key bias, run the way the DiT's cross attention runs it (dit.hip): the
+ * keys whose bias is above -5000 are moved to the front of their batch row (order kept) and the kernel multiplies only the key
+ * blocks that hold them - a masked text token (bias -10000, ltx_transformer.rs:1059-1070) has softmax weight exp(s - 10000 - max)
+ * = +0.0f exactly, so the result is that of ltx_op_attention.  q_rowsq may be NULL (then q is used as it is).  counts_out
+ * (DEVICE int [B], may be NULL) receives the number of keys kept per batch row.  Blocks until done (temporary buffers). */
+int ltx_op_attention_compact(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
+                             int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias,
+                             const float* q_rowsq, int q_rowsq_n, int q_rowsq_D, float q_rowsq_eps, int* counts_out, ltx_stream stream);
 /* Same core for bf16, head_dim 64 or 128, no key bias, with q ALREADY multiplied by scale*log2(e) (the DiT self-attention
  * path folds that factor into the q RMSNorm+RoPE kernel): o = softmax_base2(q' k^T) v. */
 int ltx_op_attention_prescaled(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
