@@ -56,9 +56,10 @@ CONFIGS = {
                name="LTX-Video-0.9.8-13B-distilled 704x1216x161, 7 steps, skip block 42 (configs.rs:264-282), untiled VAE decode"),
 }
 DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # configs.rs:232 (the CPU baseline's C1 run)
-# the one full oracle run of the headline workload (10 minutes of 8 host cores; too long for the default bench run)
-FULL_C2_RUN = {"seconds": 622.57, "frames_per_sec": 97 / 622.57, "cores": 8, "machine": "the 8-core build container (Intel Xeon @ 2.60GHz), NOT the GPU box of this run",
-               "record": "profiles/r3_oracle_cpu_runs.json"}
+# The full oracle run of the headline workload, MEASURED on a GPU box's host cores (round 5, tools/oracle_full_c2.py through gpurun:
+# 8 minutes of 16 threads - too long for the default bench run, which times a bounded sample and labels its value an ESTIMATE).
+FULL_C2_RUN = {"seconds": 501.07, "frames_per_sec": 97 / 501.07, "cores": 16, "machine": "a GPU box of the pool (AMD EPYC 9575F 64-Core, 256 logical CPUs), not necessarily the box of this run",
+               "record": "profiles/r5_oracle_c2_on_gpu_box.json", "earlier": "622.57 s on the 8-core build container (profiles/r3_oracle_cpu_runs.json)"}
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 

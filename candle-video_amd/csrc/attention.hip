@@ -751,19 +751,29 @@ __device__ __forceinline__ void cross64_units(const AttnArgs& a, int groups, con
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    // UB units per iteration of a wave.  With one key block a unit is 4 + 4 MFMAs and 16 exps behind a global load and in front of
+    // a store: the wave's time is memory latency, so it carries two units at once (their loads, and the next two units' loads, in
+    // flight together); with more key blocks the registers go to the scores instead.
+    constexpr int UB = (NKB == 1 && !B2D) ? 2 : 1;
     int u = grp * 4 + wave;
-    bf16x8 qf[NKS], qn[NKS];
-    f32x4 rsq[4], rsn[4];
+    bf16x8 qf[UB][NKS], qn[UB][NKS];
+    f32x4 rsq[UB][4], rsn[UB][4];
     XSTAMP(1);
-    if (u < nunits) load_q(u, qf, rsq);
+#pragma unroll
+    for (int j = 0; j < UB; ++j) if (u + j * ustride < nunits) load_q(u + j * ustride, qf[j], rsq[j]);
     int xi = 2;
-    for (; u < nunits; u += ustride) {
+    for (; u < nunits; u += UB * ustride) {
         if (xi < 8) { XSTAMP(xi); ++xi; }
-        if (u + ustride < nunits) load_q(u + ustride, qn, rsn);
+#pragma unroll
+        for (int j = 0; j < UB; ++j) if (u + (UB + j) * ustride < nunits) load_q(u + (UB + j) * ustride, qn[j], rsn[j]);
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+        const int uj = u + j * ustride;
+        if (uj >= nunits) break;                             // wave-uniform
         // (B2D) this lane's query row of the [heads, Sq, Sk] bias, in accumulator order, in flight under the S MFMAs
         f32x4 b2[B2D ? NKB : 1][B2D ? 4 : 1];
         if constexpr (B2D) {
-            int qr = u * 32 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
+            int qr = uj * 32 + r; if (qr > a.Sq - 1) qr = a.Sq - 1;
             const float* brow = a.bias2d + ((int64_t)head * a.Sq + qr) * a.Sk;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
@@ -780,10 +790,10 @@ __device__ __forceinline__ void cross64_units(const AttnArgs& a, int groups, con
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *(__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(k_base[ks] + kb * 32 * KROW);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j][ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
             }
         float mt = -INFINITY;
-        const float cq = row_factor(rsq);
+        const float cq = row_factor(rsq[j]);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -820,23 +830,23 @@ __device__ __forceinline__ void cross64_units(const AttnArgs& a, int groups, con
         constexpr int RING = NSTEP < 4 ? NSTEP : 4;
         u32x2 vr[4][2];
         auto issue = [&](auto n_tag) {
-            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
-            constexpr int imm = ((j >> 1) * 32 + (j & 1) * 16) * VROW;
+            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), jj = n % (2 * NKB);
+            constexpr int imm = ((jj >> 1) * 32 + (jj & 1) * 16) * VROW;
             vr[n & 3][0] = ds_tr_read<imm>(tr_base[d]);
             vr[n & 3][1] = ds_tr_read<imm + 8 * VROW>(tr_base[d]);
         };
         static_for<0, RING>([&](auto n_tag) { issue(n_tag); });
         static_for<0, NSTEP>([&](auto n_tag) {
-            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), j = n % (2 * NKB);
+            constexpr int n = decltype(n_tag)::value, d = n / (2 * NKB), jj = n % (2 * NKB);
             constexpr int after = (NSTEP - 1 - n < 3 ? NSTEP - 1 - n : 3) * 2;
             lds_wait<after>(vr[n & 3][0], vr[n & 3][1]);
             union { u32x2 u2[2]; bf16x8 v; } cvt;
             cvt.u2[0] = vr[n & 3][0]; cvt.u2[1] = vr[n & 3][1];
-            acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf[j >> 1][j & 1], j == 0 ? zero16 : acc_o[d], 0, 0, 0);
+            acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf[jj >> 1][jj & 1], jj == 0 ? zero16 : acc_o[d], 0, 0, 0);
             if constexpr (n + 4 < NSTEP) issue(std::integral_constant<int, n + 4>{});
         });
         const float inv = 1.0f / l;
-        const int qr = u * 32 + r;
+        const int qr = uj * 32 + r;
         if (qr < a.Sq) {
             bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + ((int64_t)b * a.Sq + qr) * a.ldo + head * HD;
             if (a.wide_o) store_o_wide<NDB>(acc_o, inv, O, h);
@@ -851,10 +861,14 @@ __device__ __forceinline__ void cross64_units(const AttnArgs& a, int groups, con
                     *reinterpret_cast<bf16x4*>(O + dd) = o4;
                 }
         }
+        }
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
+        for (int j = 0; j < UB; ++j) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) rsq[g4] = rsn[g4];
+            for (int ks = 0; ks < NKS; ++ks) qf[j][ks] = qn[j][ks];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) rsq[j][g4] = rsn[j][g4];
+        }
     }
 #ifdef XTRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -87,13 +87,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
         const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    // Order inside an XCD's run (GemmArgs::group_m, set by the launcher): 1 = frames fastest - the 32 tiles an XCD works on at a
-    // time are ONE patch position in 32 consecutive frames, so a frame's patch is fetched into that XCD's L2 once for the three
-    // output frames that read it (frame taps t-1, t, t+1) instead of three times, rounds apart; 0 = patch positions fastest (rounds 1-4)
+    // (round 5, measured and left out: frames fastest inside a run - one patch position in 32 consecutive frames at a time, so that
+    // a frame's patch is fetched once for the three output frames that read it - moved 8 % fewer bytes past the L2s and not a
+    // microsecond: profiles/r5a_conv_tile_order_ab.json)
     const int nt = bid % ntn; int rr = bid / ntn;
-    int px, py, t, b;
-    if (g.group_m == 1) { t = rr % g.T; rr /= g.T; px = rr % pwn; rr /= pwn; py = rr % phn; b = rr / phn; }
-    else { px = rr % pwn; rr /= pwn; py = rr % phn; const int bt = rr / phn; t = bt % g.T; b = bt / g.T; }
+    const int px = rr % pwn; rr /= pwn;
+    const int py = rr % phn; const int bt = rr / phn;
+    const int t = bt % g.T, b = bt / g.T;
     const int y0 = py * PH, x0 = px * PW, n0 = nt * BN;
 
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
@@ -517,7 +517,6 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
     ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
                   (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.H * g.Wd * g.ldr * 2.0 < 2147483648.0));
-    { const char* oe = getenv("LTX_CONV_HALO_ORDER"); ga.group_m = (oe && oe[0] == '0') ? 0 : 1; }     // "0": patch positions fastest (A/B aid)
     if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
     LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(WGM * WGN * 64), smem, s, ga);
     LTX_CHECK_LAUNCH();

@@ -232,6 +232,28 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 1024u));
     const int nk = __builtin_amdgcn_readfirstlane(g.K / 64);
     f32x32 c[10];
+    // Residual tile requested BEFORE the K loop (160-row tiles: 80 registers per lane, free during the loop).  A one-round grid runs
+    // its blocks in lockstep, so every block reaches its epilogue together and nothing hides the residual's latency: in-kernel stamps
+    // (tools/gemm2048_trace.py, profiles/r5b_gemm2048_trace.jsonl) put the row passes at 2.6 us with a bias only and 5.8 / 6.9 us
+    // with a residual / gate + residual, of a 35-40 us block.  Loads return in order, so the loop's counted waits cover these too.
+    constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
+    constexpr int RP = BM == 256 ? 128 : 80;               // tile rows per pass of the wide epilogue: RP KiB of f32 must fit the two stages
+    constexpr bool PF_R = HAS_R && BM == 160;
+    constexpr int PFN = PF_R ? (BM / RP) * (RP / 8) : 1;
+    u32x2 pfA[PFN], pfB[PFN];
+    if constexpr (PF_R) {
+        const int rows_valid_pf = g.M - m0 < BM ? g.M - m0 : BM;
+        const __amdgpu_buffer_rsrc_t rres_pf = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m0 * g.ldr + n0), 0, (int)(((uint32_t)(rows_valid_pf - 1) * (uint32_t)g.ldr + 256u) * 2u), 0x00020000);
+        const int cg_pf = tid & 31;
+        const uint32_t cA_pf = n0 + 4 * cg_pf < g.N ? (uint32_t)(8 * cg_pf) : 0x80000000u, cB_pf = n0 + 4 * cg_pf + 128 < g.N ? (uint32_t)(8 * cg_pf + 256) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < PFN; ++i) {
+            const uint32_t ro = (uint32_t)((tid >> 5) + 8 * i) * (uint32_t)g.ldr * 2u;      // tile row (tid >> 5) + 8 i = pass i / (RP / 8), step row i % (RP / 8)
+            pfA[i] = __builtin_amdgcn_raw_buffer_load_b64(rres_pf, (int)(ro + cA_pf), 0, 0);
+            pfB[i] = __builtin_amdgcn_raw_buffer_load_b64(rres_pf, (int)(ro + cB_pf), 0, 0);
+        }
+    }
 #ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
 #else
@@ -257,9 +279,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     // to VGPRs and spill; shapes that do not meet the conditions - ltx_gemm_asm16_epilogue_ok - stay on gemm_big.)
     {
         static_assert(BN == 256, "thread -> column map below");
-        constexpr int RP = BM == 256 ? 128 : 80;           // tile rows per pass: RP KiB of f32 must fit the two stages
         static_assert(RP * 1024 <= 2 * STAGE && BM % RP == 0 && RP % 16 == 0 && RP % 8 == 0, "pass geometry");
-        constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
         constexpr bool RSQ_COMPACT = RSQ && 2 * STAGE - RP * 1024 >= RP * 2 * 144;   // GemmArgs::rowsq leaves in the LDS behind a pass
         const int r0 = tid >> 5, cg = tid & 31;
         int nA = n0 + 4 * cg, nB = nA + 128;
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
             // are computed on clamped addresses and not stored - no branch in front of a load)
             constexpr int UN = RP % 32 == 0 ? 4 : 5;
             static_assert((RP / 8) % UN == 0, "row steps");
-#pragma unroll 1
+#pragma unroll (PF_R ? RP / 8 / UN : 1)
             for (int k0 = 0; k0 < RP / 8; k0 += UN) {
                 f32x4 vA[UN], vB[UN];
                 bf16x4 qA[UN] = {}, qB[UN] = {};
@@ -350,7 +370,10 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                     const unsigned char* rowp = asm_smem + row * 1024;
                     vA[j] = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
                     vB[j] = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
-                    if constexpr (HAS_R) {
+                    if constexpr (PF_R) {                  // requested before the K loop (tile row p * RP + r0 + 8 (k0 + j))
+                        qA[j] = __builtin_bit_cast(bf16x4, pfA[p * (RP / 8) + k0 + j]);
+                        qB[j] = __builtin_bit_cast(bf16x4, pfB[p * (RP / 8) + k0 + j]);
+                    } else if constexpr (HAS_R) {
                         const uint32_t ro = (uint32_t)(p * RP + row) * (uint32_t)g.ldr * 2u;
                         qA[j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)(ro + cA), 0, 0));
                         qB[j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)(ro + cB), 0, 0));
