@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 
 #ifndef ATTN_DMA
 #define ATTN_DMA 1
@@ -992,24 +993,16 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnArgs a) {
 
 }  // namespace
 
-static bool attn_cross_enabled() {
-    const char* e = getenv("LTX_ATTN_CROSS");               // "0" = generic tiled kernel for short key sets too (A/B aid)
-    return !(e && e[0] == '0');
-}
-static bool attn_q64_enabled() {
-    const char* e = getenv("LTX_ATTN_Q64");                 // "0" = 32-query waves, two blocks per CU (attn_pipe64_kernel; A/B aid)
-    return !(e && e[0] == '0');
-}
-static bool attn_pipe_enabled() {
-    const char* e = getenv("LTX_ATTN_PIPE");                // "0" = one tile at a time per wave (A/B aid)
-    return !(e && e[0] == '0');
-}
+// option attn_off (A/B aid): "cross" = the generic tiled kernel for short key sets too; "q64" = 32-query waves, two blocks per CU
+// (attn_pipe64_kernel); "pipe" = one tile at a time per wave
+static bool attn_cross_enabled() { return !(ltx_opt().attn_off & LTX_ATTN_CROSS); }
+static bool attn_q64_enabled() { return !(ltx_opt().attn_off & LTX_ATTN_Q64); }
+static bool attn_pipe_enabled() { return !(ltx_opt().attn_off & LTX_ATTN_PIPE); }
 
 // Shape-only: whether cross attention may take its queries un-normalised (AttnArgs::q_rowsq; bf16, head_dim 64, a key set
 // that fits attn_cross64_kernel, at most 16 partials per row).  LTX_Q2_FOLD=0: the stand-alone q-norm pass (A/B aid).
 bool ltx_attention_rowsq_ok(int hd, int Sk, int D) {
-    const char* e = getenv("LTX_Q2_FOLD");
-    return hd == 64 && Sk <= XKV && attn_cross_enabled() && D % 512 == 0 && D / 128 <= 16 && !(e && e[0] == '0');
+    return hd == 64 && Sk <= XKV && attn_cross_enabled() && D % 512 == 0 && D / 128 <= 16 && ltx_opt().q2_fold != 0;
 }
 
 // Shape-only: whether the short-key-set kernel (attn_cross64_kernel: bf16, head_dim 64, at most 128 keys) serves a launch; what
@@ -1017,8 +1010,7 @@ bool ltx_attention_rowsq_ok(int hd, int Sk, int D) {
 bool ltx_attention_cross64_ok(int hd, int Sk) { return hd == 64 && Sk <= XKV && attn_cross_enabled(); }
 
 bool ltx_attention_prescale_ok(int hd) {
-    const char* e = getenv("LTX_ATTN_PRESCALE");           // "0" = keep the per-score scale multiply (A/B aid)
-    return (hd == 64 || hd == 128) && !(e && e[0] == '0');
+    return (hd == 64 || hd == 128) && ltx_exp("attn_prescale", 1);      // (experiment builds: 0 = keep the per-score scale multiply)
 }
 
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
@@ -1030,10 +1022,8 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) LTX_FAIL(LTX_ERR_ARG, "attention: strides must be 16-byte aligned");
         dim3 grid((unsigned)(cdiv(a.Sq, BQ) * a.heads * a.B)), block(256);
         AttnArgs ax = a;
-        const char* xe = getenv("LTX_ATTN_XCD");             // "0" = plain head-major block order (A/B aid)
-        ax.xcd_heads = (a.heads % 8 == 0 && !(xe && xe[0] == '0')) ? 1 : 0;
-        const char* wo = getenv("LTX_ATTN_WIDE_O");          // "0": 8-byte output stores (A/B aid)
-        ax.wide_o = (a.ldo % 8 == 0 && ((uintptr_t)a.o & 15) == 0 && a.hd % 8 == 0 && !(wo && wo[0] == '0')) ? 1 : 0;
+        ax.xcd_heads = (a.heads % 8 == 0 && ltx_exp("attn_xcd", 1)) ? 1 : 0;                 // (experiment builds: 0 = plain head-major block order)
+        ax.wide_o = (a.ldo % 8 == 0 && ((uintptr_t)a.o & 15) == 0 && a.hd % 8 == 0 && ltx_exp("attn_wide_o", 1)) ? 1 : 0;   // (0 = 8-byte output stores)
         if (a.q_prescaled && (a.bias || !ltx_attention_prescale_ok(a.hd))) LTX_FAIL(LTX_ERR_ARG, "attention: q_prescaled needs head_dim 64 or 128 and no key bias");
         if (a.q_rowsq && !(a.hd == 64 && a.Sk <= XKV && attn_cross_enabled() && a.q_rowsq_n >= 4 && a.q_rowsq_n <= 16 && a.q_rowsq_n % 4 == 0 && a.q_rowsq_D > 0))
             LTX_FAIL(LTX_ERR_ARG, "attention: q_rowsq is served by the short-key-set head_dim-64 kernel only (4..16 partials per row, a multiple of 4)");
@@ -1058,7 +1048,7 @@ int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
                     if (upw <= best_upw) { best_upw = upw; groups = gq; }
                 }
             }
-            if (const char* ge = getenv("LTX_ATTN_CROSS_GROUPS")) groups = atoi(ge);   // tuning aid
+            { const int xg = ltx_exp("attn_cross_groups", 0); if (xg > 0) groups = xg; }   // tuning aid (experiment builds)
             if (groups > cdiv(nunits, 4)) groups = cdiv(nunits, 4); if (groups < 1) groups = 1;
             if (a.bias2d) {
                 if (a.Sk % 4 || ((uintptr_t)a.bias2d & 15)) LTX_FAIL(LTX_ERR_ARG, "attention: bias2d needs Sk % 4 == 0 and a 16-byte aligned table");

@@ -24,6 +24,7 @@
 #include <vector>
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -148,8 +149,7 @@ std::atomic<int> g_q128_ticket{1};
 
 // shapes the generated loop serves: prescaled bf16, head_dim 128, at least two key tiles, 32-bit buffer offsets
 bool ltx_attention_q128_fits(const AttnArgs& a) {
-    const char* e = getenv("LTX_ATTN_Q128");                // "0" = attn_bf16_kernel<128> (A/B aid)
-    if (e && e[0] == '0') return false;
+    if (ltx_opt().attn_off & LTX_ATTN_Q128) return false;      // attn_off=q128: attn_bf16_kernel<128> (A/B aid)
     if (a.hd != 128 || !a.q_prescaled || a.bias || a.Sk < 128 || a.Sq < 1) return false;
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8 || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.o & 15)) return false;
     const double lim = 2147483648.0 - 512.0;
@@ -230,7 +230,7 @@ int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, 
         }
         nbig = it->second;
     }
-    if (const char* e = getenv("LTX_ATTN_Q128_BIG")) { const int v = atoi(e); if (v >= 0 && v <= a.Sq / 256) nbig = v; }   // tuning aid (0: 128-query blocks only)
+    { const int v = ltx_exp("attn_q128_big", -1); if (v >= 0 && v <= a.Sq / 256) nbig = v; }   // tuning aid (experiment builds; 0: 128-query blocks only)
     const int nsmall = (a.Sq - nbig * 256 + 127) / 128;
     const int blocks = a.B * a.heads * (nbig + nsmall);
     LTX_LAUNCH_TIMED(attn_q128_kernel, dim3((unsigned)blocks), dim3(256), smem, s, a, nbig, nsmall, flag, ticket);

@@ -38,6 +38,7 @@
 #include <vector>
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 
 #ifndef Q64_ROWSUM_MFMA
 #define Q64_ROWSUM_MFMA 1      // 0: row sums by VALU adds
@@ -739,6 +740,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnArgs a, int 
     else attn_q64_block<1>(a, smem, b, head, nbig * 256 + qb * 128, 0, a.Sk, nullptr);
 }
 
+#ifdef LTX_EXPERIMENTS     // the persistent form (measured 3 % behind the block grid, lab notes): experiment builds only (x_attn_q64_persist=1)
 // ---- persistent form: one workgroup per CU walks a static list of items ---------------------------------------------
 // The one-block-per-(head, 256 queries) grid above runs 2.44 rounds of work in 2 + 0.70 rounds at S = 4992 (the last
 // round as 128-query blocks at 70 % of a big block's time each).  Here the host cuts the work evenly: every CU gets
@@ -842,6 +844,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_persist_kernel(const AttnArgs
     }
 }
 
+#endif  // LTX_EXPERIMENTS
 }  // namespace
 #if Q64_TRACE
 extern "C" int ltx_dbg_q64_trace(unsigned long long* host, int n) {
@@ -849,6 +852,7 @@ extern "C" int ltx_dbg_q64_trace(unsigned long long* host, int n) {
 }
 #endif
 
+#ifdef LTX_EXPERIMENTS
 // ---- host side of the persistent form: the static item lists ----------------------------------------------------------
 namespace {
 struct Q64Plan { Q64Item* items = nullptr; int* first = nullptr; int grid = 0, nslab = 0, ncnt = 0; };
@@ -986,6 +990,8 @@ extern "C" int ltx_dbg_q64_schedule(int B, int heads, int Sq, int Sk, int n_cu, 
     return 0;
 }
 
+#endif  // LTX_EXPERIMENTS
+
 static int q64_n_cu() {
     static std::mutex mu; static std::map<int, int> per_dev;
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -1004,6 +1010,7 @@ bool ltx_attention_q64_fits(const AttnArgs& a) {
     return (double)a.Sk * a.ldk * 2.0 < lim && (double)a.Sk * a.ldv * 2.0 < lim && (double)a.Sq * a.ldq * 2.0 < lim && (double)a.Sq * a.ldo * 2.0 < lim;
 }
 
+#ifdef LTX_EXPERIMENTS
 static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
     int dev = 0; (void)hipGetDevice(&dev);
     const int xcd = (a.xcd_heads && n_cu % 8 == 0) ? 1 : 0;
@@ -1050,6 +1057,8 @@ static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
     return LTX_OK;
 }
 
+#endif  // LTX_EXPERIMENTS
+
 // Split of a head's queries into big (256) and small (128) blocks: as many big blocks as fill whole rounds of the
 // chip's CUs (one block per CU), the rest as small blocks that run in about half a big block's time, so the last
 // round of the grid is short instead of running a few long blocks on a mostly idle chip.
@@ -1061,14 +1070,15 @@ int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
         // on MI355X at S = 4992, 32 heads: 183 us against 178 us for the block grid below - a 128-query block costs 0.59 of a
         // 256-query block (not the 0.70 the split was sized for), and publish + merge cost a workgroup 1.4 + 4.5 (up to 9.5) us,
         // which is what halving the last round saves.  Kept as a tested option; the block grid stays the default.
-        const char* pe = getenv("LTX_ATTN_Q64_PERSIST");
-        const bool on = pe && pe[0] == '1';
+#ifdef LTX_EXPERIMENTS     // x_attn_q64_persist=1 (experiment builds only)
+        const bool on = ltx_exp("attn_q64_persist", 0) == 1;
         const int64_t blocks = (int64_t)heads_total * ((a.Sq + 255) / 256);
-        if (on && a.Sk % 64 == 0 && a.Sk >= 64 * 2 * Q64_MIN_PART && blocks > n_cu && !getenv("LTX_ATTN_Q64_BIG")) return launch_q64_persist(a, n_cu, s);
+        if (on && a.Sk % 64 == 0 && a.Sk >= 64 * 2 * Q64_MIN_PART && blocks > n_cu && ltx_opt().attn_q64_big < 0) return launch_q64_persist(a, n_cu, s);
+#endif
     }
     const int nbig_max = a.Sq / 256;                                   // whole big blocks per head
     int nbig = nbig_max;
-    if (const char* e = getenv("LTX_ATTN_Q64_BIG")) { nbig = atoi(e); if (nbig > nbig_max) nbig = nbig_max; if (nbig < 0) nbig = 0; }
+    if (ltx_opt().attn_q64_big >= 0) { nbig = ltx_opt().attn_q64_big; if (nbig > nbig_max) nbig = nbig_max; }      // option attn_q64_big: tests of both block sizes
     else {
         // The split whose greedy schedule (one block per CU, big blocks first; a 128-query block costs 0.59 of a 256-query one,
         // tools/attn_q64_tune.py) finishes first.  Round 2's rule - big blocks in whole rounds - is that split at one batch

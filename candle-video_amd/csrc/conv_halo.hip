@@ -18,6 +18,7 @@
 //     temporal replicate padding is a clamp of the frame index (vae.rs:374-413).
 #include <type_traits>
 #include "gemm_common.h"
+#include "options.h"
 
 #ifndef HALO_WIDE_EPI
 #define HALO_WIDE_EPI 1
@@ -514,8 +515,7 @@ int launch_halo(const GemmArgs& g, hipStream_t s) {
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = g.B * g.T * cdiv(g.H, PH) * cdiv(g.Wd, PW) * cdiv(g.N, BN);
     GemmArgs ga = g;
-    const char* we = getenv("LTX_GEMM_WIDE_EPI");           // "0": fragment-wise 8-byte epilogue (A/B aid)
-    ga.wide_epi = !(we && we[0] == '0') && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
+    ga.wide_epi = ltx_opt().gemm_wide_epi && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 &&
                   (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0 && (double)g.H * g.Wd * g.ldr * 2.0 < 2147483648.0));
     if (g.pn_on && (!ga.wide_epi || EPI != EPI_BIAS || BN != g.N || !HALO_WIDE_EPI)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: the fused output norm needs the wide bias epilogue and BN == N");
     LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(WGM * WGN * 64), smem, s, ga);
@@ -557,10 +557,12 @@ int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     if (bn == 64) return launch_halo<64, 8, 1, EPI_UNPATCH, false>(g, s);      // conv_out: eight waves of 32 x 64
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
 #if HALO_LOADERS == 4
-    const char* pe = getenv("LTX_CONV_HALO_PIPE");          // "0": the barrier-per-step form (A/B)
-    const char* w4 = getenv("LTX_CONV_HALO_W4");            // "1": one wave per SIMD (four waves of 128 x 64), round 4 experiment
-    if (w4 && w4[0] == '1' && !(pe && pe[0] == '0')) return launch_halo_epi<128, 2, 2, true>(g, epi, s);
-    if (!(pe && pe[0] == '0')) return launch_halo_epi<128, 4, 2, true>(g, epi, s);
+#ifdef LTX_EXPERIMENTS     // x_conv_halo_pipe=0: the barrier-per-step form; x_conv_halo_w4=1: one wave per SIMD (four waves of 128 x 64; round 4: -3 %)
+    if (!ltx_exp("conv_halo_pipe", 1)) return launch_halo_epi<128, 4, 2>(g, epi, s);
+    if (ltx_exp("conv_halo_w4", 0)) return launch_halo_epi<128, 2, 2, true>(g, epi, s);
 #endif
+    return launch_halo_epi<128, 4, 2, true>(g, epi, s);
+#else
     return launch_halo_epi<128, 4, 2>(g, epi, s);
+#endif
 }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <deque>
 #include "model_util.h"
+#include "options.h"
 
 struct DitBlock {
     LinearW qkv1, o1, q2, kv2, o2, ff1, ff2;
@@ -236,8 +237,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (fold_q2) {
         GemmArgs gq; gq.A = m->h.p; gq.W = m->blocks[0].q2.w; gq.C = m->qkv.p; gq.bias = m->blocks[0].q2.b;
         gq.M = (int)M; gq.N = m->blocks[0].q2.out; gq.K = m->blocks[0].q2.in; gq.lda = D; gq.ldc = D;
-        const char* force = getenv("LTX_Q2_FOLD");           // "2": fold whatever the shape (tests of the stand-alone partials)
-        fold_q2 = ltx_gemm_asm16_fits(gq, EPI_BIAS) || (force && force[0] == '2');
+        fold_q2 = ltx_gemm_asm16_fits(gq, EPI_BIAS) || ltx_opt().q2_fold == 2;       // q2_fold=2: fold whatever the shape (tests of the stand-alone partials)
     }
     if (fold_q2) LTX_TRY(m->rsq.ensure(M * (D / 128) * sizeof(float)));
     // The two RMS norms of a block take their rows' sums of squares from the epilogue of the GEMM that wrote h (ff2 of the block
@@ -249,12 +249,12 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     // (docs/lab_notes.md R4.4 / R4.7).
     bool presum = dt == LTX_DT_BF16 && D % 512 == 0 && (D & (D - 1)) == 0 && D <= 2048;
     if (presum) {
-        const char* pe = getenv("LTX_NORM_PRESUM");
+        const int pe = ltx_opt().norm_presum;
         GemmArgs gp; gp.A = m->attn.p; gp.W = m->blocks[0].o2.w; gp.C = m->h.p; gp.bias = m->blocks[0].o2.b; gp.resid = m->h.p;
         gp.M = (int)M; gp.N = m->blocks[0].o2.out; gp.K = m->blocks[0].o2.in; gp.lda = D; gp.ldc = D; gp.ldr = D;
         GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D;
         gf.gate = reinterpret_cast<const float*>(m->h.p); gf.gate_stride = 6 * D; gf.rows_per_batch = S;      // (any aligned non-null pointer: a fit test, nothing is launched)
-        presum = (!(pe && pe[0] == '0') && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || (pe && pe[0] == '2');
+        presum = (pe != 0 && ltx_gemm_asm16_fits(gp, EPI_RESID) && ltx_gemm_asm16_fits(gf, EPI_GATE_RESID)) || pe == 2;
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h
@@ -312,8 +312,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         // Masked text tokens (bias -10000, :1059-1070) get softmax weight exp(s - 10000 - max) = +0.0f: exactly nothing.  Where the
         // short-key-set kernel serves the layer, the keys that are left are moved to the front of their batch row once per context and
         // the kernel sizes its work by their number (device-side count: no host synchronisation).
-        const char* xc = getenv("LTX_XATTN_COMPACT");        // "0": every layer multiplies all K keys (A/B aid)
-        ctx->compact = enc_mask && dt == LTX_DT_BF16 && ltx_attention_cross64_ok(hd, K) && !(xc && xc[0] == '0');
+        ctx->compact = enc_mask && dt == LTX_DT_BF16 && ltx_attention_cross64_ok(hd, K) && ltx_opt().xattn_compact;     // xattn_compact=0: every layer multiplies all K keys (A/B aid)
         if (ctx->compact) {
             LTX_TRY(ctx->kvc.ensure((size_t)L * MK * 2 * D * esz)); LTX_TRY(ctx->biasc.ensure(MK * sizeof(float)));
             LTX_TRY(ctx->kidx.ensure(MK * sizeof(int))); LTX_TRY(ctx->kcount.ensure((size_t)B * sizeof(int)));
@@ -375,8 +374,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         // self attention
         // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
         // of two: the attention kernel reads K/V rows of a dense matrix 7-11 % faster than column slices of [M, 3D]
-        const char* dense_e = getenv("LTX_DENSE_QKV");        // "0": column slices of [M, 3D] (A/B aid, and the path of a D that is not a power of two)
-        const bool dense_qkv = (D & (D - 1)) == 0 && !(dense_e && dense_e[0] == '0');
+        const bool dense_qkv = (D & (D - 1)) == 0 && ltx_opt().dense_qkv;      // dense_qkv=0: column slices of [M, 3D] (A/B aid, and the path of a D that is not a power of two)
         const int64_t seg = dense_qkv ? M * D : D;           // elements from q to k to v
         const int ldqkv = dense_qkv ? D : 3 * D;
         {

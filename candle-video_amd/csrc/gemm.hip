@@ -14,6 +14,7 @@
 // columns n of one row m (8-B / 16-B stores, vector bias/gate loads).
 // T = bf16 uses v_mfma_f32_16x16x32_bf16; T = float uses v_mfma_f32_16x16x4_f32 (exact f32).
 #include "gemm_common.h"
+#include "options.h"
 
 namespace {
 
@@ -192,7 +193,7 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     void* tok = nullptr;
     ltx_prof_begin(g.conv ? LTX_PROF_CONV : LTX_PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * (g.conv ? g.ntaps : 1), s, &tok);
     int rc;
-    if (getenv("LTX_GEMM_TRACE") && dtype == LTX_DT_BF16 && !ltx_gemm_asm_eligible(g, dtype, epi) && !ltx_gemm_big_eligible(g, dtype))     // debugging aid: bf16 shapes left to the 128 x 128 kernel
+    if (ltx_opt().gemm_trace && dtype == LTX_DT_BF16 && !ltx_gemm_asm_eligible(g, dtype, epi) && !ltx_gemm_big_eligible(g, dtype))     // debugging aid: bf16 shapes left to the 128 x 128 kernel
         fprintf(stderr, "[ltx] gemm128 serves M=%d N=%d K=%d conv=%d ntaps=%d B=%d T=%d H=%d W=%d epi=%d fits=%d\n", g.M, g.N, g.K, g.conv, g.ntaps, g.B, g.T, g.H, g.Wd, epi, (int)ltx_gemm_big_fits(g));
     if (ltx_gemm_asm_eligible(g, dtype, epi)) rc = ltx_launch_gemm_asm(g, epi, s);
     else if (ltx_gemm_big_eligible(g, dtype)) rc = ltx_launch_gemm_big(g, epi, s);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "gemm_common.h"
+#include "options.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char asm_smem[];
 
+#ifdef LTX_EXPERIMENTS     // round 1's 32x32x16 kernel: 4-12 % behind gemm_big on the DiT shapes; experiment builds only (x_gemm_asm=1)
 template <int BM, int BN, int WGM, int WGN> struct AsmLoop;
 template <> struct AsmLoop<256, 256, 2, 2> {
     template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[10], T&&... t) { gemm_asm_loop_256_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], t...); }
@@ -135,6 +137,8 @@ __global__ __launch_bounds__(256, 1) void gemm_asm_kernel(const GemmArgs g) {
     }
 }
 
+#endif  // LTX_EXPERIMENTS
+
 // ---- the 16x16x32 kernel (plan family asm16:*, or LTX_GEMM_ASM=16 to force it; tools/gen_gemm_asm.py gen16).  The vendor library's
 // kernel for these shapes, disassembled, is this structure - four waves of 128 x 128, LDS-DMA staging - with the 16x16x32 MFMA,
 // the shape that holds a higher clock at equal cycles per FLOP.  Fragment = 16 rows x 32 k: lane (rr = lane & 15, q = lane >> 4)
@@ -153,6 +157,10 @@ template <> struct AsmLoop16<160, 256, 1, 4> {
         gemm_asm16_loop_160_256(c[0], c[1], c[2], c[3], c[4], rb, d0, t...); }
     static __device__ __forceinline__ void store(int p, int, const f32x32 (&c)[10], const u32x8& ad) {
         if (p == 0) gemm_asm16_store_160_256_p0(c[0], c[1], c[2], c[3], c[4], ad); else gemm_asm16_store_160_256_p1(c[0], c[1], c[2], c[3], c[4], ad); }
+    // the loop that also requests the lane's 20 residual rows, two per K-step over its first ten K-steps (needs >= 12 K-steps)
+    template <typename... T> static __device__ __forceinline__ void run_res(f32x32 (&c)[10], u32x16 (&res)[5], const u32x2& rvoff, const u32x4& rres, uint32_t rstride,
+                                                                            const u32x8& rb, const u32x16& d0, T&&... t) {
+        gemm_asm16_loop_160_256_res(c[0], c[1], c[2], c[3], c[4], rb, d0, t..., res[0], res[1], res[2], res[3], res[4], rvoff, rres, rstride); }
 };
 template <> struct AsmLoop16<320, 256, 2, 2> {             // 320 accumulator registers: a[0:255] and v[192:255]
     template <typename... T> static __device__ __forceinline__ void run(f32x32 (&c)[10], const u32x8& rb, const u32x16& d0, const u32x2& d1, T&&... t) {
@@ -167,7 +175,7 @@ template <> struct AsmLoop16<320, 256, 2, 2> {             // 320 accumulator re
 __device__ uint32_t g_asm16_trace[1024 * 4 * 16];   // per wave: 8 segment sums, then entry / loop start / loop end / exit (100 MHz clock) and HW_ID
 #endif
 
-template <int BM, int BN, int WGM, int WGN, int EPI, bool RSQ = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, bool RSQ = false, bool PF_R = false>
 __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, NT = MB * NB, AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 128;
@@ -232,27 +240,28 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 1024u));
     const int nk = __builtin_amdgcn_readfirstlane(g.K / 64);
     f32x32 c[10];
-    // Residual tile requested BEFORE the K loop (160-row tiles: 80 registers per lane, free during the loop).  A one-round grid runs
-    // its blocks in lockstep, so every block reaches its epilogue together and nothing hides the residual's latency: in-kernel stamps
-    // (tools/gemm2048_trace.py, profiles/r5b_gemm2048_trace.jsonl) put the row passes at 2.6 us with a bias only and 5.8 / 6.9 us
-    // with a residual / gate + residual, of a 35-40 us block.  Loads return in order, so the loop's counted waits cover these too.
+    // Residual tile requested INSIDE the K loop (PF_R: 160-row tiles, at least 12 K-steps; 80 registers per lane that the loop
+    // leaves free).  A one-round grid runs its blocks in lockstep: every block reaches its epilogue together and the 20 MB residual
+    // read of the whole launch is a burst that nothing overlaps - in-kernel stamps (tools/gemm2048_trace.py,
+    // profiles/r5b_gemm2048_trace.jsonl) put the epilogue's row passes at 2.6 us with a bias only and 5.8 / 6.9 us with a residual /
+    // gate + residual, of a 35-40 us block.  Requesting the whole tile in front of the loop only moved that burst to the start
+    // (measured: no change); the generated loop spreads it, two rows of every lane per K-step over the first ten K-steps, between
+    // the fragment reads and the first barrier.  Loads return in order, so the loop's counted waits are raised by what they skip.
     constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
     constexpr int RP = BM == 256 ? 128 : 80;               // tile rows per pass of the wide epilogue: RP KiB of f32 must fit the two stages
-    constexpr bool PF_R = HAS_R && BM == 160;
-    constexpr int PFN = PF_R ? (BM / RP) * (RP / 8) : 1;
-    u32x2 pfA[PFN], pfB[PFN];
+    static_assert(!PF_R || (HAS_R && BM == 160 && BN == 256), "residual prefetch: the 160 x 256 tile's residual epilogues");
+    u32x16 pf[5];                                          // 20 rows x (first | second) column group x 2 dwords, in that order
+    u32x2 pf_voff = {0x80000000u, 0x80000000u}; u32x4 pf_rsrc = {0u, 0u, 0u, 0u}; uint32_t pf_stride = 0u;
     if constexpr (PF_R) {
         const int rows_valid_pf = g.M - m0 < BM ? g.M - m0 : BM;
-        const __amdgpu_buffer_rsrc_t rres_pf = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m0 * g.ldr + n0), 0, (int)(((uint32_t)(rows_valid_pf - 1) * (uint32_t)g.ldr + 256u) * 2u), 0x00020000);
+        const uint64_t rp = (uint64_t)(uintptr_t)(reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m0 * g.ldr + n0);
+        pf_rsrc = (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rp >> 32)) & 0xffffu,
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)(rows_valid_pf - 1) * (uint32_t)g.ldr + 256u) * 2u)), 0x00020000u};
         const int cg_pf = tid & 31;
-        const uint32_t cA_pf = n0 + 4 * cg_pf < g.N ? (uint32_t)(8 * cg_pf) : 0x80000000u, cB_pf = n0 + 4 * cg_pf + 128 < g.N ? (uint32_t)(8 * cg_pf + 256) : 0x80000000u;
-#pragma unroll
-        for (int i = 0; i < PFN; ++i) {
-            const uint32_t ro = (uint32_t)((tid >> 5) + 8 * i) * (uint32_t)g.ldr * 2u;      // tile row (tid >> 5) + 8 i = pass i / (RP / 8), step row i % (RP / 8)
-            pfA[i] = __builtin_amdgcn_raw_buffer_load_b64(rres_pf, (int)(ro + cA_pf), 0, 0);
-            pfB[i] = __builtin_amdgcn_raw_buffer_load_b64(rres_pf, (int)(ro + cB_pf), 0, 0);
-        }
+        const uint32_t row0 = (uint32_t)(tid >> 5) * (uint32_t)g.ldr * 2u;
+        pf_voff[0] = n0 + 4 * cg_pf < g.N ? row0 + (uint32_t)(8 * cg_pf) : 0x80000000u;
+        pf_voff[1] = n0 + 4 * cg_pf + 128 < g.N ? row0 + (uint32_t)(8 * cg_pf + 256) : 0x80000000u;
+        pf_stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)g.ldr * 2u));
     }
 #ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
@@ -265,7 +274,8 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, dma1, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2), tr);
     const uint32_t t_loop1 = (uint32_t)wall_clock64();
 #else
-    AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, dma1, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
+    if constexpr (PF_R) AsmLoop16<BM, BN, WGM, WGN>::run_res(c, pf, pf_voff, pf_rsrc, pf_stride, rbase, dma0, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
+    else AsmLoop16<BM, BN, WGM, WGN>::run(c, rbase, dma0, dma1, ra, rw, nk, k0, k0, ldsw, (uint32_t)__builtin_amdgcn_readfirstlane(g.K * 2));
 #endif
     // Wide epilogue.  One wave per SIMD hides no latency and the 256 accumulators leave no registers to unroll into, so the
     // fragment-wise epilogue of gemm_big (serial bias load -> wait -> 8-byte store per block) took 8-10 us of a 60 us block
@@ -370,9 +380,10 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                     const unsigned char* rowp = asm_smem + row * 1024;
                     vA[j] = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
                     vB[j] = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
-                    if constexpr (PF_R) {                  // requested before the K loop (tile row p * RP + r0 + 8 (k0 + j))
-                        qA[j] = __builtin_bit_cast(bf16x4, pfA[p * (RP / 8) + k0 + j]);
-                        qB[j] = __builtin_bit_cast(bf16x4, pfB[p * (RP / 8) + k0 + j]);
+                    if constexpr (PF_R) {                  // requested inside the K loop: lane row i = tile row r0 + 8 i, i = p * RP / 8 + k0 + j
+                        const int i = p * (RP / 8) + k0 + j;
+                        qA[j] = __builtin_bit_cast(bf16x4, (u32x2){pf[(2 * i) / 16][(2 * i) % 16], pf[(2 * i) / 16][(2 * i) % 16 + 1]});
+                        qB[j] = __builtin_bit_cast(bf16x4, (u32x2){pf[(40 + 2 * i) / 16][(40 + 2 * i) % 16], pf[(40 + 2 * i) / 16][(40 + 2 * i) % 16 + 1]});
                     } else if constexpr (HAS_R) {
                         const uint32_t ro = (uint32_t)(p * RP + row) * (uint32_t)g.ldr * 2u;
                         qA[j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)(ro + cA), 0, 0));
@@ -457,19 +468,31 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static std::atomic<unsigned long long> attr_devs{0}, attr_devs_rsq{0};      // one mask per kernel (the attribute is per kernel and device)
     void (*kern)(const GemmArgs);
+#ifdef LTX_EXPERIMENTS
     if constexpr (MF16) kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI>; else kern = gemm_asm_kernel<BM, BN, WGM, WGN, EPI>;
+#else
+    static_assert(MF16, "the 32x32x16 kernel is an experiment build's");
+    kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI>;
+#endif
     bool wrote_rowsq = false;
+    // the residual epilogues of the 160 x 256 tile request their residual rows inside the K loop where it is long enough
+    constexpr bool CAN_PF = MF16 && BM == 160 && BN == 256 && (EPI == EPI_GATE_RESID || EPI == EPI_RESID);
+    bool pf_r = false;
+    if constexpr (CAN_PF) pf_r = g.K / 64 >= 12 && ltx_exp("gemm_asm16_resid_prefetch", 1);
     if constexpr (MF16 && (EPI == EPI_BIAS || EPI == EPI_GATE_RESID || EPI == EPI_RESID)) {   // GemmArgs::rowsq as a by-product of the wide epilogue
         if (g.rowsq) { kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, true>; wrote_rowsq = true; }
     }
-    LTX_TRY(ltx_set_max_dyn_smem(wrote_rowsq ? attr_devs_rsq : attr_devs, reinterpret_cast<const void*>(kern), smem));
+    static std::atomic<unsigned long long> attr_devs_pf{0}, attr_devs_pf_rsq{0};
+    if constexpr (CAN_PF) {
+        if (pf_r) kern = g.rowsq ? gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, true, true> : gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, false, true>;
+    }
+    LTX_TRY(ltx_set_max_dyn_smem(pf_r ? (wrote_rowsq ? attr_devs_pf_rsq : attr_devs_pf) : (wrote_rowsq ? attr_devs_rsq : attr_devs), reinterpret_cast<const void*>(kern), smem));
     GemmArgs ga = g;
-    const char* xr = getenv("LTX_XCD_REMAP");
-    ga.xcd_remap = xr ? (xr[0] == '1') : 1;
+    ga.xcd_remap = ltx_exp("xcd_remap", 1);
     {   // near-square patch of tiles per XCD (gemm_big.hip launch_one): one block per CU
         const int C = 32;
         int gm = 1; while ((gm + 1) * (gm + 1) * BM <= C * BN) ++gm;
-        if (const char* e = getenv("LTX_GEMM_GROUP_M")) { const int env_gm = atoi(e); if (env_gm >= 0) gm = env_gm; }
+        { const int x_gm = ltx_exp("gemm_group_m", -1); if (x_gm >= 0) gm = x_gm; }
         const int ntm = cdiv(g.M, BM);
         if (gm > ntm) gm = ntm;
         ga.group_m = gm < 2 ? 0 : gm;
@@ -513,21 +536,24 @@ bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi) {
     return g.M > 512 && g.N >= 512;                       // (up to 512 rows: gemm_ring.hip's tiles, never split)
 }
 
-// LTX_GEMM_ASM forces the family for every shape it serves (tests, A/B): "1" the 32x32x16 loop, "16" the 16x16x32 loop.
+// Experiment builds, x_gemm_asm=1: round 1's 32x32x16 loop for every shape it serves (tests, A/B).  The 16x16x32 kernel is a plan
+// family of gemm_big.hip ("asm16:*"; forced with the gemm_plan option).
 bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi) {
-    if (dtype != LTX_DT_BF16 || g.conv) return false;
-    const char* e = getenv("LTX_GEMM_ASM");
-    if (!e || e[0] != '1') return false;
-    if (e[1] == '6') return ltx_gemm_asm16_fits(g, epi) && g.M >= 2048 && g.N >= 1024;
+#ifdef LTX_EXPERIMENTS
+    if (dtype != LTX_DT_BF16 || g.conv || ltx_exp("gemm_asm", 0) != 1) return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     if (g.K < 128 || g.K % 64 != 0 || g.lda % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
     if ((double)g.M * g.lda * 2.0 >= 2147483648.0 || (double)g.N * g.K * 2.0 >= 2147483648.0) return false;     // 32-bit buffer offsets
     if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
     return g.M >= 2048 && g.N >= 1024;
+#else
+    (void)g; (void)dtype; (void)epi;
+    return false;
+#endif
 }
 
 int ltx_gemm_asm_pick_tile(int M, int N) {
-    if (const char* f = getenv("LTX_GEMM_ASM_TILE")) for (int i = 0; i < 3; ++i) if (!strcmp(f, kAsmTiles[i].name)) return i;
+    { const int f = ltx_exp("gemm_asm_tile", -1); if (f >= 0 && f < 3) return f; }      // experiment builds: 0 / 1 / 2 = kAsmTiles order
     double best = 1e30; int bi = 0;
     for (int i = 0; i < 3; ++i) {
         const int64_t tiles = (int64_t)cdiv(M, kAsmTiles[i].bm) * cdiv(N, kAsmTiles[i].bn);
@@ -551,15 +577,15 @@ int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {
 }
 
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {
-    const char* e = getenv("LTX_GEMM_ASM");
-    if (e && e[0] == '1' && e[1] == '6') {                 // 16x16x32 loop: 256 x 256 and 160 x 256 tiles
-        const int tile = ltx_gemm_asm_pick_tile(g.M, g.N);  // kAsmTiles order: 256 x 256, 320 x 256, 160 x 256
-        return ltx_launch_gemm_asm16(g, epi, tile == 0 ? 0 : (tile == 1 ? 2 : 1), s);
-    }
+#ifdef LTX_EXPERIMENTS
     ltx_prof_kernel(LTX_PROFK_GEMM_ASM);
     switch (ltx_gemm_asm_pick_tile(g.M, g.N)) {
         case 0: return launch_asm_epi<256, 256, 2, 2>(g, epi, s);
         case 1: return launch_asm_epi<320, 256, 2, 2>(g, epi, s);
         default: return launch_asm_epi<160, 256, 1, 4>(g, epi, s);
     }
+#else
+    (void)g; (void)epi; (void)s;
+    LTX_FAIL(LTX_ERR_UNSUPPORTED, "gemm_asm (32x32x16) is compiled into experiment builds only");
+#endif
 }

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <atomic>
 #include "gemm_common.h"
+#include "options.h"
 
 #ifndef GEMM_LOADERS
 #define GEMM_LOADERS 4   // 8: every wave issues its share of the LDS-DMA pieces; 4: the first wave of each SIMD issues them all
@@ -434,36 +435,27 @@ std::mutex g_split_mu;
 // Measured on MI355X: cutting the thin LAST round of a multi-round grid loses (qkv/ff1 -4..-16 %); a grid that cannot even
 // half-fill the chip gains (VAE mid-block conv, 27648-deep K: +11..16 %).
 int ltx_gemm_split_factor(const GemmArgs& g) {
-    const char* e = getenv("LTX_GEMM_SPLITK");
-    if (e && e[0] == '0') return 1;
+    if (!ltx_opt().gemm_splitk) return 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
-    if (const char* f = getenv("LTX_GEMM_SPLIT_FORCE")) {          // measurement aid (tools/ring_probe.py): this many K-ranges for every linear layer
-        const int sf = atoi(f);
+    if (const int sf = ltx_exp("gemm_split_force", 0)) {            // measurement aid (tools/ring_probe.py): this many K-ranges for every linear layer
         if (!g.conv && sf >= 1 && sf <= 8 && nk / sf >= 1) return sf;
     }
-    static const int max_sf = [] { const char* v = getenv("LTX_GEMM_SPLIT_MAX"); return v ? atoi(v) : 8; }();
-    static const int min_k = [] { const char* v = getenv("LTX_GEMM_SPLIT_MINK"); return v ? atoi(v) : 8; }();
-    static const bool small_rule = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALLM"); return !(v && v[0] == '0'); }();
+    const int max_sf = ltx_exp("gemm_split_max", 8), min_k = ltx_exp("gemm_split_mink", 8);
     // Linear layers of at most 512 rows (round 4, gemm_ring.hip): never split.  On the deep-ring tiles a K-range costs 0.2-0.3 us
     // per step where the two-stage tiles paid 0.5, and a grid of 96 x 32 / 64 x 32 tiles fills the chip without cutting K, while
     // the in-launch reduction costs 5 us for two parts and 8 for four (slab store, agent-scope release + ticket + acquire, the
     // last arriver re-reading the slabs: tools/ring_trace.py).  Measured over 14 shapes with M = 128 .. 512
     // (tools/ring_split_probe.py, profiles/r4_ring_split_probe.jsonl): unsplit wins 12, ties one, loses 12 % on one (T5's wo,
-    // K = 10240).  A function of (M, N, K) alone, like the rest of this rule.  LTX_GEMM_SPLIT_RING=0: the round 3 rule below.
-    static const bool ring_rule = [] { const char* v = getenv("LTX_GEMM_SPLIT_RING"); return !(v && v[0] == '0'); }();
-    if (!g.conv && g.M <= 512 && g.N >= 32 && g.N % 4 == 0 && g.K % 8 == 0 && ring_rule) return 1;
-    if (!g.conv && g.M <= 1536 && small_rule) {
+    // K = 10240).  A function of (M, N, K) alone, like the rest of this rule.
+    if (!g.conv && g.M <= 512 && g.N >= 32 && g.N % 4 == 0 && g.K % 8 == 0 && ltx_exp("gemm_split_ring", 1)) return 1;
+    if (!g.conv && g.M <= 1536 && ltx_exp("gemm_split_smallm", 1)) {
         // Small-M linear layers (C1's 384 tokens, the 128 text rows; round 3, tools/small_m_probe.py): these are latency-bound
         // weight streams - a K-step costs 0.4-0.75 us whatever it computes - and the in-launch reduction grows faster than
         // linearly with the parts (1.4 / 6 / 22 us for 2 / 4 / 8), so split only until ~256 blocks are in flight (512 when K is
         // long), keep >= 16 K-steps per part, and at most 4 parts once there are more than 16 tiles.  The area rule below cut
         // qkv at M = 384 (144 tiles of 128 x 128) into 4 parts: 36 us against 25 unsplit; M = 1152: 55 against 31.
         const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-        // (round 4: with write-through slab stores a part publishes in 3 us instead of 8; LTX_GEMM_SPLIT_SMALL = "target,mink,maxsf"
-        // re-tunes the rule - the defaults are the measured best of tools/small_m_probe.py)
-        static const int t0 = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return a; }();
-        static const int mk = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return b; }();
-        static const int mx = [] { const char* v = getenv("LTX_GEMM_SPLIT_SMALL"); int a = 256, b = 16, c = 4; if (v) sscanf(v, "%d,%d,%d", &a, &b, &c); return c; }();
+        const int t0 = ltx_exp("gemm_split_small_target", 256), mk = ltx_exp("gemm_split_small_mink", 16), mx = ltx_exp("gemm_split_small_max", 4);
         const int target = nk >= 96 ? 2 * t0 : t0;
         int sf = 1;
         while (sf * 2 <= 8 && tiles * sf * 2 <= target && nk / (sf * 2) >= mk) sf *= 2;
@@ -497,7 +489,7 @@ int plan_tail_split(GemmArgs* g, int tiles, int bm, int bn, int threads, int sme
         HIP_TRY(hipMemsetAsync(w.cnt, 0, nb, s));      // once: every reducer hands its counter back at zero
     }
     g->sk_sf = sf; g->sk_full = full; g->sk_ws = reinterpret_cast<float*>(w.slabs); g->sk_cnt = reinterpret_cast<unsigned*>(w.cnt);
-    { const char* pe = getenv("LTX_GEMM_SPLIT_SC1"); g->sk_plain = !(pe && pe[0] == '1'); }      // default: round 3's protocol (see the kernel)
+    g->sk_plain = !ltx_exp("gemm_split_sc1", 0);          // default: round 3's protocol (see the kernel)
     return LTX_OK;
 }
 }  // namespace
@@ -519,15 +511,14 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
         int per_cu = (160 * 1024) / smem; if (per_cu > 2048 / (64 * WGM * WGN)) per_cu = 2048 / (64 * WGM * WGN); if (per_cu < 1) per_cu = 1;
         const int C = 32 * per_cu;
         int gm = 1; while ((gm + 1) * (gm + 1) * BM <= C * BN) ++gm;
-        if (const char* e = getenv("LTX_GEMM_GROUP_M")) { const int env_gm = atoi(e); if (env_gm >= 0) gm = env_gm; }   // tuning aid: 0/1 row-major
+        { const int x_gm = ltx_exp("gemm_group_m", -1); if (x_gm >= 0) gm = x_gm; }   // tuning aid: 0/1 row-major
         const int ntm = cdiv(g.M, BM);
         if (gm > ntm) gm = ntm;
         ga.group_m = (CONV || gm < 2) ? 0 : gm;
     }
     {   // wide epilogue: 16-byte chunks need 8-column granularity and 16-byte aligned rows
-        const char* we = getenv("LTX_GEMM_WIDE_EPI");       // "0": the fragment-wise 8-byte epilogue (A/B aid)
         const bool seg_ok = !g.c_seg_shift || ((1 << g.c_seg_shift) % 8 == 0 && g.c_seg_stride % 8 == 0);
-        ga.wide_epi = !(we && we[0] == '0') && !CONV && g.N % 8 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 && seg_ok &&
+        ga.wide_epi = ltx_opt().gemm_wide_epi && !CONV && g.N % 8 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C & 15) == 0 && seg_ok &&
                       (!g.resid || (g.ldr % 8 == 0 && ((uintptr_t)g.resid & 15) == 0)) && (double)g.M * g.ldr * 2.0 < 2147483648.0;
     }
     dim3 grid((unsigned)(ga.sk_sf > 1 ? ga.sk_full + (tiles - ga.sk_full) * ga.sk_sf : tiles)), block(64 * WGM * WGN);
@@ -589,8 +580,8 @@ bool tile_fits(const TileInfo& t, int N) { return t.rate > 0 && !(t.bn > 128 && 
 
 // Tile choice: minimise (rounds over the CUs) x (tile time); ties go to the larger tile (less operand re-reading).
 int ltx_gemm_big_pick_tile(int M, int N) {
-    const char* force = getenv("LTX_GEMM_TILE");       // e.g. "256x128" (tuning / test aid)
-    if (force) for (int i = 0; i < kNumTiles; ++i) if (!strcmp(force, kTiles[i].name)) return i;
+    const char* force = ltx_opt().gemm_plan;           // a gemm_big tile named by the gemm_plan option, e.g. "256x128" (tuning / test aid)
+    if (force[0]) for (int i = 0; i < kNumTiles; ++i) if (!strcmp(force, kTiles[i].name)) return i;
     double best = 1e30; int bi = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileInfo& t = kTiles[i];
@@ -614,8 +605,7 @@ bool ltx_gemm_big_fits(const GemmArgs& g) {
 
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     if (dtype != LTX_DT_BF16) return false;
-    const char* off = getenv("LTX_GEMM_BIG");
-    if (off && off[0] == '0') return false;
+    if (ltx_opt().gemm_off & LTX_FAM_BIG) return false;
     if (g.conv && (g.kh > 3 || g.kw > 3)) return false;   // the validity mask covers 3x3 (and 1x1) spatial taps
     if (!ltx_gemm_big_fits(g)) return false;              // 32-bit buffer offsets: every addressed span < 2 GiB (else gemm.hip's kernel)
     // Linear layers of any M take the 128-row tiles with the shape-only split-K (small outputs: up to 8 K-ranges per tile, so
@@ -623,11 +613,11 @@ bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype) {
     // (M = 1) and the T5 encoder's M = 128 GEMMs run 1.5-2.5x faster than on gemm.hip's 128 x 128 register-staged kernel
     // (T5-XXL at 128 tokens 14.9 -> 10.5 ms).  Convs from 256 output voxels up take them too since round 3 (C1's mid block is
     // 4 x 8 x 12 = 384 voxels of 1024 channels: 11 convs of 57 MB of weights each, 500 us apiece on gemm.hip's kernel, 6.5 of
-    // C1's 63 ms; with the split-K tiles the decode went 11.9 -> 6.3 ms); smaller ones stay there.  LTX_GEMM_BIG_MINM /
-    // LTX_GEMM_BIG_CONV_MINM override.
+    // C1's 63 ms; with the split-K tiles the decode went 11.9 -> 6.3 ms); smaller ones stay there.  (experiment builds:
+    // x_gemm_big_minm / x_gemm_big_conv_minm override.)
     int min_m = g.conv ? 16 : 1;      // (round 4: the edge tiles of the tiled decode are convs of 48..192 voxels x 1024 channels - 57 MB of weights at 0.11 TB/s on the 128 x 128 kernel, 500 us apiece)
-    if (const char* e = getenv("LTX_GEMM_BIG_MINM")) { min_m = atoi(e); if (g.conv && min_m < 1024) min_m = 1024; }
-    if (g.conv) { if (const char* e = getenv("LTX_GEMM_BIG_CONV_MINM")) min_m = atoi(e); }
+    { const int x = ltx_exp("gemm_big_minm", -1); if (x >= 0) { min_m = x; if (g.conv && min_m < 1024) min_m = 1024; } }
+    if (g.conv) { const int x = ltx_exp("gemm_big_conv_minm", -1); if (x >= 0) min_m = x; }
     return g.M >= min_m && g.N >= 32;
 }
 
@@ -697,13 +687,9 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     const hipEvent_t e0 = guard.e0, e1 = guard.e1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     float best = 1e30f;
-    const char* p8e = getenv("LTX_GEMM_P8");
-    const bool p8_off = p8e && p8e[0] == '0';
-    const char* he = getenv("LTX_CONV_HALO");
-    const bool halo_off = he && he[0] == '0';
+    const bool p8_off = ltx_opt().gemm_off & LTX_FAM_P8, halo_off = ltx_opt().gemm_off & LTX_FAM_HALO;
     const bool split_shape = ltx_gemm_split_factor(g) > 1;     // split shapes run gemm_big tiles only (same K partition in every plan)
-    const char* a16 = getenv("LTX_GEMM_ASM16");
-    const bool asm16_off = a16 && a16[0] == '0';
+    const bool asm16_off = ltx_opt().gemm_off & LTX_FAM_ASM16;
     for (int plan = 0; plan < kPlanRing + ltx_gemm_ring_tiles(); ++plan) {
         if (plan >= kPlanRing) {
             if (!plan_ok(g, EPI_BIAS, plan)) continue;
@@ -716,7 +702,6 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         else if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
             if (!tile_fits(kTiles[plan], g.N)) continue;
-            if (const char* ex = getenv("LTX_GEMM_EXCLUDE")) { if (strstr(ex, kTiles[plan].name)) continue; }   // A/B aid: tiles left out of the measurement
         } else if (plan < kPlanHalo) {
             if (plan >= kPlanP8 + 2) { plan = kPlanHalo - 1; continue; }
             if (split_shape || p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
@@ -776,8 +761,7 @@ int plan_from_name(const char* n) {
 }
 // *plan holds the static model's choice on entry; replaced by the cached plan, or by a fresh measurement when allowed
 int cached_or_tuned_plan(const GemmArgs& g, hipStream_t s, int* plan) {
-    const char* tune = getenv("LTX_GEMM_TUNE");
-    if (tune && tune[0] == '0') return LTX_OK;
+    if (!ltx_opt().gemm_tune) return LTX_OK;
     const PlanKey key = plan_key(g);
     std::lock_guard<std::mutex> lock(g_plan_mu);
     auto it = g_plans.find(key);
@@ -835,47 +819,56 @@ extern "C" int ltx_plan_load(const char* path) {
 int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     GemmArgs g = g_in;
     ltx_prof_kernel(LTX_PROFK_GEMM_BIG);                   // the kernels this dispatcher hands over to overwrite it
-    // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %); env = tuning aid
-    const char* xr = getenv("LTX_XCD_REMAP");
-    g.xcd_remap = xr ? (xr[0] == '1') : 1;
+    // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %)
+    g.xcd_remap = ltx_exp("xcd_remap", 1);
     if (g.pn_on) return ltx_launch_conv_halo(g, epi, g.N, s);      // fused output norm: only that kernel's wide epilogue carries it
-    if (const char* rt = getenv("LTX_GEMM_RING_TILE")) {   // "ring:96x96" ...: force a gemm_ring.hip tile where the shape is eligible (tests, A/B)
-        const int plan = plan_from_name(rt);
-        if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
-    }
+    const LtxOptions& o = ltx_opt();
     const bool split_shape = ltx_gemm_split_factor(g) > 1;
+    const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
+    // Option gemm_plan (tests, A/B): one plan forced wherever the call is eligible for it - a full plan name, or a family name
+    // ("asm16", "ring") for that family's own tile choice.  A gemm_big tile name is always honoured (ltx_gemm_big_pick_tile).
+    int forced = -1;
+    if (o.gemm_plan[0]) {
+        if (!strcmp(o.gemm_plan, "asm16")) {
+            if (!g.conv && g.M >= 2048 && g.N >= 1024) { const int t = ltx_gemm_asm_pick_tile(g.M, g.N); forced = kPlanAsm16 + (t == 0 ? 0 : (t == 1 ? 2 : 1)); }   // kAsmTiles order: 256 x 256, 320 x 256, 160 x 256
+        } else if (!strcmp(o.gemm_plan, "ring")) {
+            if (ltx_gemm_ring_fits(g, epi)) forced = kPlanRing + ltx_gemm_ring_pick_tile(g);
+        } else forced = plan_from_name(o.gemm_plan);
+        if (forced >= kNumTiles) {                          // not a gemm_big tile: the plan's own predicates for THIS call
+            bool ok = plan_ok(g, epi, forced);
+            if (forced >= kPlanHalo && forced < kPlanAsm16) ok = ok && g.conv && ltx_conv_halo_eligible(g, epi, forced == kPlanHalo ? 128 : 256);
+            if (forced >= kPlanP8 && forced < kPlanHalo) ok = ok && nk >= 2;
+            if (split_shape && forced < kPlanRing) ok = false;      // split shapes: gemm_big tiles or ring tiles (one K partition whatever the plan)
+            if (!ok) forced = -1;
+        }
+    }
+    const bool big_forced = forced >= 0 && forced < kNumTiles;
+    if (forced >= kPlanRing) return ltx_launch_gemm_ring(g, epi, forced - kPlanRing, s);
     if (split_shape) {                                     // gemm_big tiles (or gemm_ring's, which keep their K partition): one partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
-        if (!getenv("LTX_GEMM_TILE")) (void)cached_or_tuned_plan(g, s, &plan);
+        if (!big_forced) (void)cached_or_tuned_plan(g, s, &plan);
         if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
         if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)
         return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
     }
-    {   // conv_out (N = 48, unpatchify): the halo-staged kernel on its 64-wide tile - one staging of the 128-channel activation
-        // per nine taps instead of one per tap (the per-tap 192 x 64 tile moves 27 x 610 MB through L2 -> LDS at C2).  Same K order:
-        // same bits.  LTX_CONV_OUT_HALO=0: the per-tap tile (A/B aid).
-        const char* oe = getenv("LTX_CONV_OUT_HALO");
-        if (g.conv && epi == EPI_UNPATCH && !(oe && oe[0] == '0') && ltx_conv_halo_eligible(g, epi, 64)) return ltx_launch_conv_halo(g, epi, 64, s);
-    }
-    if (const char* he = getenv("LTX_CONV_HALO")) {        // "128" / "256" force the halo-staged conv kernel where eligible (tests, A/B)
-        const int bn = atoi(he);
-        if ((bn == 128 || bn == 256) && ltx_conv_halo_eligible(g, epi, bn)) return ltx_launch_conv_halo(g, epi, bn, s);
-    }
-    const int p8 = ltx_gemm_p8_choice(g);
-    if (p8) return ltx_launch_gemm_p8(g, epi, p8, s);
+    // conv_out (N = 48, unpatchify): the halo-staged kernel on its 64-wide tile - one staging of the 128-channel activation
+    // per nine taps instead of one per tap (the per-tap 192 x 64 tile moves 27 x 610 MB through L2 -> LDS at C2).  Same K order:
+    // same bits.  gemm_off=halo_out: the per-tap tile (A/B aid).
+    if (g.conv && epi == EPI_UNPATCH && !(o.gemm_off & LTX_FAM_HALO_OUT) && ltx_conv_halo_eligible(g, epi, 64)) return ltx_launch_conv_halo(g, epi, 64, s);
+    if (forced >= kPlanP8) return run_plan(g, epi, forced, s);
     int plan = ltx_gemm_big_pick_tile(g.M, g.N);
-    // static model, small M: the deep-ring tile whose grid wastes the least of a round (these shapes are never split, see
-    // ltx_gemm_split_factor: a gemm_big tile would leave most CUs idle)
-    if (!g.conv && g.M <= 512 && ltx_gemm_ring_fits(g, epi)) plan = kPlanRing + ltx_gemm_ring_pick_tile(g);
-    {   // static model (no measured plan: LTX_GEMM_TUNE=0 / ltx_set_autotune(0) without a plan file): the large linear layers take
+    if (!big_forced) {
+        // static model, small M: the deep-ring tile whose grid wastes the least of a round (these shapes are never split, see
+        // ltx_gemm_split_factor: a gemm_big tile would leave most CUs idle)
+        if (!g.conv && g.M <= 512 && ltx_gemm_ring_fits(g, epi)) plan = kPlanRing + ltx_gemm_ring_pick_tile(g);
+        // static model (no measured plan: gemm_tune=0 / ltx_set_autotune(0) without a plan file): the large linear layers take
         // the one-wave-per-SIMD kernel too, tile by whole rounds x tile area (it won every such shape that was measured)
-        const char* a16 = getenv("LTX_GEMM_ASM16");
-        if (!g.conv && !(a16 && a16[0] == '0') && g.M >= 2048 && g.N >= 1024 && ltx_gemm_asm16_fits(g, epi)) {
+        if (!g.conv && !(o.gemm_off & LTX_FAM_ASM16) && g.M >= 2048 && g.N >= 1024 && ltx_gemm_asm16_fits(g, epi)) {
             const int t = ltx_gemm_asm_pick_tile(g.M, g.N);              // 0: 256 x 256, 1: 320 x 256, 2: 160 x 256
             plan = kPlanAsm16 + (t == 0 ? 0 : (t == 1 ? 2 : 1));
         }
+        LTX_TRY(cached_or_tuned_plan(g, s, &plan));
     }
-    if (!getenv("LTX_GEMM_TILE")) LTX_TRY(cached_or_tuned_plan(g, s, &plan));
     return run_plan(g, epi, plan, s);
 }
 

@@ -284,15 +284,6 @@ int launch_epi8(const GemmArgs& g, int epi, hipStream_t s) {
 
 }  // namespace
 
-// LTX_GEMM_P8: "256" / "128" force the phase-interleaved kernel with that BN (tuning aid), "0" disables it
-int ltx_gemm_p8_choice(const GemmArgs& g) {
-    if ((g.K + 63) / 64 * (g.conv ? g.ntaps : 1) < 2) return 0;
-    const char* e = getenv("LTX_GEMM_P8");
-    if (e && e[0] == '0') return 0;
-    if (e && !strcmp(e, "256")) return 256;
-    if (e && !strcmp(e, "128")) return 128;
-    return 0;
-}
 
 // buffer-addressed staging uses 32-bit byte offsets with 0x80000000 as the out-of-range marker
 bool ltx_gemm_p8_fits(const GemmArgs& g) {

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cstring>
 #include "gemm_common.h"
+#include "options.h"
 
 #ifndef RING_ABL
 #define RING_ABL 0      // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads, 4 loads all hit one line set
@@ -346,22 +347,23 @@ int launch_ring(const GemmArgs& g, hipStream_t s) {
 }
 template <int BM, int BN, int NS>
 int launch_ring_epi(const GemmArgs& g, int epi, hipStream_t s) {
-    // LTX_GEMM_RING_SPEC=0: every wave loads and multiplies (256 threads), the first form of the kernel (A/B aid)
-    static const bool spec = [] { const char* e = getenv("LTX_GEMM_RING_SPEC"); return !(e && e[0] == '0'); }();
-    if (spec) switch (epi) {
-        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, true>(g, s);
-        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, true>(g, s);
-        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, true>(g, s);
-        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, true>(g, s);
-    }
-    else switch (epi) {
+#ifdef LTX_EXPERIMENTS     // x_gemm_ring_spec=0: every wave loads and multiplies (256 threads), the first form of the kernel (A/B aid)
+    if (!ltx_exp("gemm_ring_spec", 1)) switch (epi) {
         case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, false>(g, s);
         case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, false>(g, s);
         case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, false>(g, s);
         case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, false>(g, s);
     }
+#endif
+    switch (epi) {
+        case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, true>(g, s);
+        case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, true>(g, s);
+        case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, true>(g, s);
+        case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, true>(g, s);
+    }
     LTX_FAIL(LTX_ERR_ARG, "gemm_ring: bad epilogue");
 }
+
 }  // namespace
 
 #ifdef RING_TRACE
@@ -397,8 +399,7 @@ int ltx_gemm_ring_tile_bn(int i) { return i >= 0 && i < kNumRing ? kRing[i].bn :
 // Linear layers of at most 2048 rows (the plan measurement offers the family up to 512: ltx_gemm_split_factor) whose operands the 32-bit buffer offsets reach (gemm_big's own bound), K in whole 16-byte
 // chunks, 4-column output groups inside or outside N as a whole.
 bool ltx_gemm_ring_fits(const GemmArgs& g, int epi) {
-    const char* e = getenv("LTX_GEMM_RING");
-    if (e && e[0] == '0') return false;
+    if (ltx_opt().gemm_off & LTX_FAM_RING) return false;
     if (g.conv || g.pn_on || g.M < 1 || g.M > 2048 || g.N < 32 || g.N % 4 || g.K % 8 || g.lda % 8) return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     // the epilogue's prefetch loads 8 bytes of the residual row and 16 bytes of the gate row per lane (gemm_asm16's conditions)

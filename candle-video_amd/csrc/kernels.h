@@ -87,7 +87,6 @@ int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s);
 int ltx_gemm_asm_pick_tile(int M, int N);
 const char* ltx_gemm_asm_tile_name(int i);
 int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table
-int ltx_gemm_p8_choice(const GemmArgs& g);  // gemm_p8.hip: phase-interleaved 256-row kernel; returns BN (256/128) or 0
 int ltx_launch_gemm_p8(const GemmArgs& g, int epi, int bn, hipStream_t s);
 bool ltx_gemm_p8_fits(const GemmArgs& g);
 // gemm_ring.hip: small-M linear layers on small tiles with a deep ring of LDS stages (plan family ring:*); same K partition and

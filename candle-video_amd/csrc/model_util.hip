@@ -1,4 +1,5 @@
 #include "model_util.h"
+#include "options.h"
 
 int ltx_stage_src(const ltx_weight* w, const void** dev_src, void** temp_to_free) {
     *temp_to_free = nullptr;
@@ -53,11 +54,11 @@ int ltx_linear(const LinearW& l, const void* x, int lda, void* y, int ldc, int M
     g.A = x; g.W = l.w; g.C = y; g.bias = l.b; g.resid = resid; g.gate = gate;
     g.M = M; g.N = l.out; g.K = l.in; g.lda = lda; g.ldc = ldc; g.ldr = ldr;
     g.rows_per_batch = rows_per_batch; g.gate_stride = gate_stride; g.rowsq = rowsq;
-    // Opt-in experiment (LTX_RING_PACK=1; measured: C1 654 vs 654 frames/s, T5-XXL 4.87 vs 5.08 ms - not worth a second copy
+    // Opt-in experiment (x_ring_pack=1 in an experiment build; measured: C1 654 vs 654 frames/s, T5-XXL 4.87 vs 5.08 ms - not worth a second copy
     // of the weights, docs/lab_notes.md R4.11): small-M calls hand gemm_ring.hip a tile-contiguous copy of the weights, built
     // once per layer on its first such call (+ 100 % of the layer's weight bytes).
     if (dtype == LTX_DT_BF16 && M <= 512 && l.out >= 32 && l.out % 4 == 0 && l.in % 8 == 0) {
-        static const bool pack_on = [] { const char* e = getenv("LTX_RING_PACK"); return e && e[0] == '1'; }();
+        const bool pack_on = ltx_exp("ring_pack", 0) == 1;      // experiment builds only
         if (pack_on && !l.wp && !l.wp_tried) {
             l.wp_tried = true;
             void* p = nullptr;

@@ -5,6 +5,7 @@
 #include <vector>
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 #include "../../include/ltxhip.h"
 
 namespace {
@@ -55,7 +56,7 @@ void ltx_prof_end(void* token, hipStream_t s) {
 extern "C" int ltx_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
-    { const char* e = getenv("LTX_PROF_KERNEL_EVENTS"); g_kernel_events = !(e && e[0] == '0'); }
+    g_kernel_events = ltx_opt().prof_kernel_events != 0;
     for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); if (r.ka) (void)hipEventDestroy(r.ka); if (r.kb) (void)hipEventDestroy(r.kb); }
     g_recs.clear();
     for (int i = 0; i < LTX_PROF_NKINDS; ++i) {

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gemm_common.h"
+#include "options.h"
 
 namespace {
 
@@ -727,18 +728,19 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
         const int64_t rows_per_block = 4 * rpw;
         dim3 grid((unsigned)cdiv64(a.rows, rows_per_block));
         // wide rows (one wave per row, <= 4 chunks per lane), enough of them: four rows per wave, two in flight (LTX_ROWNORM_ROWS=0: one row per wave)
-        const char* re = getenv("LTX_ROWNORM_ROWS");
-        if (lpr == 64 && nch <= 4 * 64 && a.rows >= 2048 && re && re[0] == '1') {       // opt-in: measured 17.3 us against 12.7 us (DESIGN / lab notes)
+#ifdef LTX_EXPERIMENTS     // x_rownorm_rows=1: measured 17.3 us against 12.7 us (lab notes R4.4)
+        if (lpr == 64 && nch <= 4 * 64 && a.rows >= 2048 && ltx_exp("rownorm_rows", 0) == 1) {
             constexpr int R = 4;
             const int waves = (int)cdiv64(a.rows, R);
             const int blocks = (waves + 3) / 4;
             LTX_LAUNCH_TIMED((rownorm_rows_kernel<T, 4, R, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a, blocks * 4);
             return;
         }
+#endif
         // LTX_ROWNORM_OCC=n (experiment): at most n blocks per CU, by asking for 160 KiB / n of LDS the kernel never touches -
         // several generations of blocks instead of one, so that the stores of one overlap the loads of the next
         int shm = 0;
-        if (const char* oe = getenv("LTX_ROWNORM_OCC")) { const int n = atoi(oe); if (n >= 1 && n <= 8) shm = 163840 / n - 1024; }
+        { const int n = ltx_exp("rownorm_occ", 0); if (n >= 1 && n <= 8) shm = 163840 / n - 1024; }
         if (shm > 65536) {
             static std::atomic<unsigned long long> occ_devs{0};
             (void)ltx_set_max_dyn_smem(occ_devs, reinterpret_cast<const void*>(&rownorm_kernel<T, 0>), 163840);
@@ -764,18 +766,17 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     if (a.presum) {
         const int rpb = 256 / nch;
         int R = 4;                                           // rows per thread (LTX_NORM_PRESUM_R = 2 / 4 / 8: tuning aid)
-        if (const char* re = getenv("LTX_NORM_PRESUM_R")) { const int v = atoi(re); if (v == 2 || v == 4 || v == 8) R = v; }
+        { const int v = ltx_exp("norm_presum_r", 4); if (v == 2 || v == 4 || v == 8) R = v; }
         const dim3 grid((unsigned)cdiv64(a.rows, (int64_t)rpb * R));
         const bool wide = nch >= 64;
         // the DiT's case on the kernel that has nothing to decide (LTX_NORM_LEAN=0: the general one; same bits)
-        const char* le = getenv("LTX_NORM_LEAN");
-        const bool lean_on = !(le && le[0] == '0');
+        const bool lean_on = ltx_opt().norm_lean != 0, nt = ltx_exp("norm_nt", 0) != 0;
         const bool lean = lean_on && dtype == LTX_DT_BF16 && wide && R == 4 && a.scale && !a.weight && a.act == 0 && a.presum_n <= 16 &&
-                          a.rows % ((int64_t)rpb * 4) == 0 && a.rows_per_batch % 4 == 0 && !getenv("LTX_NORM_NT");
+                          a.rows % ((int64_t)rpb * 4) == 0 && a.rows_per_batch % 4 == 0 && !nt;
         if (lean) LTX_LAUNCH_TIMED((rownorm_presum_lean_kernel<4>), grid, dim3(256), 0, s, a, nch, rpb);
         else if (dtype == LTX_DT_BF16) {
             if (R == 2) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 2, false>), grid, dim3(256), 0, s, a, nch, rpb); }
-            else if (R == 4 && wide && getenv("LTX_NORM_NT")) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true, true>), grid, dim3(256), 0, s, a, nch, rpb);
+            else if (R == 4 && wide && nt) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true, true>), grid, dim3(256), 0, s, a, nch, rpb);
             else if (R == 4) { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, a, nch, rpb); }
             else { if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, true>), grid, dim3(256), 0, s, a, nch, rpb); else LTX_LAUNCH_TIMED((rownorm_presum_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, a, nch, rpb); }
         } else if (wide) LTX_LAUNCH_TIMED((rownorm_presum_kernel<float, 4, true>), dim3((unsigned)cdiv64(a.rows, (int64_t)rpb * 4)), dim3(256), 0, s, a, nch, rpb);
@@ -799,7 +800,7 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     if (dtype == LTX_DT_BF16) {
         if (nch <= 4 * lpr) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 4>), grid, block, 0, s, a, lpr);
         // the 13B model's 4096-wide rows: eight chunks per lane, the table still read once for q and k (LTX_QKNORM_FUSED8=0: the two-pass kernel)
-        else if (nch <= 8 * lpr && !(getenv("LTX_QKNORM_FUSED8") && getenv("LTX_QKNORM_FUSED8")[0] == '0')) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 8, 2>), grid, block, 0, s, a, lpr);
+        else if (nch <= 8 * lpr && ltx_exp("qknorm_fused8", 1)) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 8, 2>), grid, block, 0, s, a, lpr);
         else if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
         else hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, false>), grid, block, 0, s, a, lpr);
     } else {

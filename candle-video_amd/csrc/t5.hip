@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "model_util.h"
+#include "options.h"
 #include "../../include/ltxhip_t5.h"
 #include "../../include/ltxhip_weights.h"
 #include <cstring>
@@ -150,10 +151,9 @@ template <typename T>
 int run_attn(const ltx_t5* m, const void* qkv, const float* bias, const float* kmask, void* out, int B, int S, hipStream_t s) {
     // The pipeline's case (bf16, d_kv 64, at most 128 tokens): the short-key-set MFMA kernel of the DiT's cross attention with
     // the relative position bias as its [heads, S, S] table - K and V of a head in LDS once, a 32-query unit per wave: 44.6 -> ~9 us
-    // per layer at S = 128 (the kernel below gives a query to each WAVE and a key to each lane).  LTX_T5_ATTN_MFMA=0: the kernel below.
+    // per layer at S = 128 (the kernel below gives a query to each WAVE and a key to each lane).  Option t5_attn_mfma=0: the kernel below.
     if constexpr (sizeof(T) == 2) {
-        const char* e = getenv("LTX_T5_ATTN_MFMA");
-        if (m->cfg.d_kv == 64 && ltx_attention_cross64_ok(64, S) && S % 4 == 0 && !(e && e[0] == '0')) {     // the launcher's own predicate
+        if (m->cfg.d_kv == 64 && ltx_attention_cross64_ok(64, S) && S % 4 == 0 && ltx_opt().t5_attn_mfma) {     // the launcher's own predicate
             const int inner = m->cfg.num_heads * 64;
             AttnArgs a;
             a.q = qkv; a.k = reinterpret_cast<const T*>(qkv) + inner; a.v = reinterpret_cast<const T*>(qkv) + 2 * inner; a.o = out;

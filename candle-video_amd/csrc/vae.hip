@@ -13,6 +13,7 @@
 // unpack_latents is free on this path.
 #include <deque>
 #include "model_util.h"
+#include "options.h"
 
 struct ConvW {
     void* w = nullptr;   // [27][N][Cin] model dtype (N possibly permuted)
@@ -236,8 +237,8 @@ int conv_chunk(ltx_vae* v, const ConvW& cw, const Dims& d) {
 // whether conv1 of a resnet can carry norm2 in its epilogue: bf16, the halo-staged kernel with BN == channels
 bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d_all, int ch) {
     Dims d = d_all; d.B = conv_chunk(v, cw, d_all);
-    auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
-    if (off("LTX_VAE_FUSE_NORM") || off("LTX_GEMM_WIDE_EPI") || off("LTX_CONV_HALO") || off("LTX_GEMM_BIG")) return false;
+    const LtxOptions& o = ltx_opt();
+    if (!o.vae_fuse_norm || !o.gemm_wide_epi || (o.gemm_off & (LTX_FAM_HALO | LTX_FAM_BIG))) return false;
     if (v->dtype != LTX_DT_BF16 || (ch != 128 && ch != 256) || cw.cout != ch) return false;
     const GemmArgs g = conv_args(v, cw, d);
     return ltx_gemm_big_eligible(g, v->dtype) && ltx_conv_halo_eligible(g, EPI_BIAS, ch);
@@ -458,10 +459,9 @@ int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, c
     // Leaves per decoder call.  The reference tiles to CAP memory (vae.rs:2225-2290), so the batch must not undo that: it is
     // bounded by a share of the memory that is free now, against a generous estimate of one leaf's activations (six tensors
     // of the largest, 128-channel stage + its f32 output), and a call that still fails to allocate is retried with half as
-    // many leaves, down to one.  LTX_VAE_TILE_BATCH=0: one leaf per call; =n: at most n.
-    const char* be = getenv("LTX_VAE_TILE_BATCH");
+    // many leaves, down to one.  Option vae_tile_batch=n: at most n leaves per call (-1: one).
     int max_n = LTX_MAX_BATCH / B; if (max_n < 1) max_n = 1;
-    if (be) { const int n_env = atoi(be); max_n = n_env <= 0 ? 1 : std::min(max_n, n_env); }
+    if (const int n_opt = ltx_opt().vae_tile_batch) max_n = n_opt < 0 ? 1 : std::min(max_n, n_opt);
     std::vector<char> done(leaves.size(), 0);
     float* cursor = v->predec.as<float>();
     for (size_t a = 0; a < leaves.size(); ++a) {

@@ -106,6 +106,7 @@ _SIGS = {
     "ltx_device_alloc": [_sz, _i, _vp], "ltx_device_free": [_vp], "ltx_memcpy_h2d": [_vp, _vp, _sz, _vp], "ltx_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "ltx_stream_synchronize": [_vp],
     "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
+    "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_reset_options": [], "ltx_has_experiments": [],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -894,6 +895,30 @@ def warmup(transformer: Optional[LtxVideoTransformer3DModel], vae: Optional["Aut
 
 def set_autotune(enabled: bool):
     _check(lib.ltx_set_autotune(int(enabled)))
+
+
+def set_option(key: str, value=None):
+    """ltx_set_option (include/ltxhip.h, run-time options): value None = the option's default"""
+    _check(lib.ltx_set_option(key.encode(), None if value is None else str(value).encode()))
+
+
+def reset_options():
+    _check(lib.ltx_reset_options())
+
+
+def has_experiments() -> bool:
+    return bool(lib.ltx_has_experiments())
+
+
+class options:
+    """with ltxhip.options(gemm_tune=0, gemm_off="asm16"): ...  - options set for the block, defaults restored after it"""
+    def __init__(self, **kw): self.kw = kw
+    def __enter__(self):
+        for k, v in self.kw.items(): set_option(k, v)
+        return self
+    def __exit__(self, *a):
+        for k in self.kw: set_option(k, None)
+        return False
 
 
 def plan_save(path: str):

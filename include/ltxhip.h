@@ -239,6 +239,40 @@ int ltx_set_autotune(int enabled);
 int ltx_plan_save(const char* path);
 int ltx_plan_load(const char* path);
 
+/* ---- run-time options (A/B and diagnostic aids; the engine needs none of them) ----
+ * One set of options per process: read ONCE, at first use, from the environment variable LTX_OPTIONS = "key=value,key=value",
+ * changed with ltx_set_option (value NULL: the option's default), restored with ltx_reset_options (defaults + LTX_OPTIONS again).
+ * No launch path reads the environment.  The only other environment variable of the library is LTX_RCCL_LIB (path of the
+ * RCCL library ltxhip_team.h loads).
+ *
+ *  speed only - the same bits with any value (PLANS never change a result: every plan of a GEMM shape sums K in one order):
+ *   gemm_tune=0            no plan measurement: the static cost model (as ltx_set_autotune(0))
+ *   gemm_plan=NAME         force one plan wherever a call is eligible for it: a gemm_big tile ("256x128", "160x256w16", ...),
+ *                          "asm16:256x256" | "asm16:160x256" | "asm16:320x256" | "asm16" (its own tile choice), "ring:96x96" ... | "ring",
+ *                          "p8:256" | "p8:128", "halo:128" | "halo:256"
+ *   gemm_off=a+b           plan families left out of the choice: asm16, ring, p8, halo, halo_out (conv_out on the per-tap tile)
+ *   gemm_wide_epi=0        fragment-wise 8-byte epilogue stores instead of the LDS-transposed 16-byte ones
+ *   gemm_trace=1           print every bf16 GEMM shape left to the 128 x 128 register-staged kernel
+ *   attn_q64_big=N         self-attention (head_dim 64): N 256-query blocks per head, the rest in 128-query blocks
+ *   norm_lean=0            the general RMS-norm map kernel instead of the DiT-specialised one
+ *   vae_tile_batch=N       at most N leaves per decoder call of the tiled decode (-1: one)
+ *   prof_kernel_events=0   stream-level event brackets in the ltx_prof_* timing
+ *  another ALGORITHM - results differ in rounding (each is a tested A/B arm against the oracle):
+ *   gemm_off=big           every GEMM on the 128 x 128 kernel (small outputs then keep one K range)
+ *   gemm_splitk=0          small outputs keep one K range (another f32 summation order)
+ *   q2_fold=0 | 2          cross-attention q-norm as its own pass | folded whatever the shape
+ *   norm_presum=0 | 2      row-reducing RMS norms | sums of squares from the producing GEMM whatever the shape
+ *   xattn_compact=0        cross attention multiplies every text key (differs from the default only for non-prefix masks)
+ *   dense_qkv=0            q | k | v as column slices of one [M, 3D] matrix (same bits; another memory layout)
+ *   vae_fuse_norm=0        the resnet's second norm as its own pass
+ *   t5_attn_mfma=0         the scalar T5 attention kernel
+ *   attn_off=a+b           attention kernels left out: q64, q128, cross, pipe (the next more general kernel serves)
+ * Measured-negative experiments and tuning knobs ("x_name=int") exist only in builds made with -DLTX_EXPERIMENTS
+ * (`make -C candle-video_amd experiments`, for tools/); the shipped library ignores them.  ltx_has_experiments() tells. */
+int ltx_set_option(const char* key, const char* value);
+int ltx_reset_options(void);
+int ltx_has_experiments(void);
+
 /* ---- optional measurement hooks (bench.py roofline object) ----
  * kinds: 0 linear GEMM, 1 conv3d implicit GEMM, 2 self-attention, 3 cross-attention, 4 row norms.
  * When enabled, every launch of those kernels is bracketed by hipEvents on ITS stream; report()
@@ -247,7 +281,7 @@ int ltx_plan_load(const char* path);
 int ltx_prof_enable(int on);
 int ltx_prof_report(int kind, double* total_ms, double* total_work, long long* count);
 /* the same totals for ONE kernel inside a class: kernel 0 gemm_kernel (128 x 128), 1 gemm_big_kernel, 2 gemm_p8_kernel,
- * 3 conv_halo_kernel, 4 gemm_asm_kernel (32x32x16), 5 gemm_asm16_kernel, 6 gemm_ring_kernel; classes 2..4 have one kernel each
+ * 3 conv_halo_kernel, 4 gemm_asm_kernel (32x32x16; experiment builds), 5 gemm_asm16_kernel, 6 gemm_ring_kernel; classes 2..4 have one kernel each
  * (index 0). */
 int ltx_prof_report_kernel(int kind, int kernel, double* total_ms, double* total_work, long long* count);
 

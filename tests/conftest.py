@@ -34,6 +34,15 @@ def _build_library():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _default_options():
+    """Run-time options (ltx_set_option, include/ltxhip.h) set by a test never leak into the next one."""
+    yield
+    m = sys.modules.get("ltxhip")
+    if m is not None:
+        m.reset_options()
+
+
 def rel_max(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 

@@ -1,7 +1,7 @@
 """GPU suite: the head_dim-128 self-attention kernel of the 13B model (csrc/attn_q128.hip, generated loop
 tools/gen_attn_q128_asm.py; LtxAttention::forward with flash attention, ltx_transformer.rs:699-712) against an f32 torch
 reference of softmax(q k^T) v in base 2 (q arrives prescaled by scale * log2 e) and against the kernel it replaces
-(attn_bf16_kernel<128>, LTX_ATTN_Q128=0).  Bars: rel-L2 <= 4e-3 vs f32 on the checked rows (bf16 P and bf16 output rounding;
+(attn_bf16_kernel<128>, option attn_off=q128).  Bars: rel-L2 <= 4e-3 vs f32 on the checked rows (bf16 P and bf16 output rounding;
 the replaced kernel measures the same), no non-finite value, bit-repeatable."""
 import math
 import os
@@ -39,14 +39,8 @@ def rel(a, b): return float((a - b).norm() / b.norm())
 
 
 def run(hip, q, k, v, on, H=H):
-    old = os.environ.get("LTX_ATTN_Q128")
-    try:
-        if on: os.environ.pop("LTX_ATTN_Q128", None)
-        else: os.environ["LTX_ATTN_Q128"] = "0"
+    with hip.options(attn_off=None if on else "q128"):
         return hip.ops.attention_prescaled(q, k, v, H)
-    finally:
-        if old is None: os.environ.pop("LTX_ATTN_Q128", None)
-        else: os.environ["LTX_ATTN_Q128"] = old
 
 
 @pytest.mark.parametrize("S", [4992, 1300, 192, 17556 // 4 + 1])          # whole tiles; ragged keys + partial last query block; two tiles; 13B-like ragged count

@@ -90,10 +90,10 @@ def test_q64_forced_big_and_small_agree(hip, monkeypatch):
     ref = ref_attn(qp, k, v, heads)
     outs = {}
     for nbig in ("0", "3", "6"):
-        monkeypatch.setenv("LTX_ATTN_Q64_BIG", nbig)
+        hip.set_option("attn_q64_big", nbig)
         outs[nbig] = run(hip, qp, k, v, heads)
         assert rel_l2(outs[nbig], ref) <= TOL, (nbig, rel_l2(outs[nbig], ref))
-    monkeypatch.delenv("LTX_ATTN_Q64_BIG")
+    hip.set_option("attn_q64_big", None)
     assert rel_l2(outs["0"], outs["6"]) <= 3e-3
 
 
@@ -142,9 +142,8 @@ def test_q64_matches_previous_kernel(hip, monkeypatch):
     heads, S = 8, 4992
     qp, k, v = mk(1, S, S, heads, seed=3)
     o = run(hip, qp, k, v, heads)
-    monkeypatch.setenv("LTX_ATTN_Q64", "0")
-    o_old = run(hip, qp, k, v, heads)
-    monkeypatch.delenv("LTX_ATTN_Q64")
+    with hip.options(attn_off="q64"):
+        o_old = run(hip, qp, k, v, heads)
     assert rel_l2(o, o_old) <= 4e-3, rel_l2(o, o_old)
 
 
@@ -161,7 +160,7 @@ def test_q64_deterministic_and_race_screen(hip):
         assert e <= TOL, (Sq, Sk, e)
 
 
-# ---- persistent form (LTX_ATTN_Q64_PERSIST=1: static item lists, key-range parts merged in the launch): 32 heads, more
+# ---- persistent form (experiment builds, x_attn_q64_persist=1: static item lists, key-range parts merged in the launch): 32 heads, more
 # blocks than CUs.  Not the default (measured 3 % slower than the block grid, attn_q64.hip), kept under test as an option.
 def ref_attn_heads(qp, k, v, heads, pick):
     """f64 reference for the heads in `pick` only (the 32-head problems are too big to hold all score sets at once)."""
@@ -182,7 +181,8 @@ def ref_attn_heads(qp, k, v, heads, pick):
     (1, 4992, 4992),         # the DiT launch itself
 ])
 def test_q64_persistent_vs_f32_reference(hip, B, Sq, Sk, monkeypatch):
-    monkeypatch.setenv("LTX_ATTN_Q64_PERSIST", "1")
+    if not hip.has_experiments(): pytest.skip("the persistent form is compiled into experiment builds only (make experiments)")
+    hip.set_option("x_attn_q64_persist", "1")
     heads = 32
     qp, k, v = mk(B, Sq, Sk, heads, seed=Sq * 3 + Sk)
     o = run(hip, qp, k, v, heads)
@@ -194,17 +194,18 @@ def test_q64_persistent_vs_f32_reference(hip, B, Sq, Sk, monkeypatch):
 
 
 def test_q64_persistent_matches_block_grid_and_repeats(hip, monkeypatch):
-    """Same function as the one-block-per-(head, 256 queries) grid (LTX_ATTN_Q64_PERSIST=0); which workgroup merges a split
+    """Same function as the one-block-per-(head, 256 queries) grid (x_attn_q64_persist=0); which workgroup merges a split
     block depends on timing, the bits must not: ten back-to-back launches are identical."""
     heads, Sq, Sk = 32, 4992, 4992
-    monkeypatch.setenv("LTX_ATTN_Q64_PERSIST", "1")
+    if not hip.has_experiments(): pytest.skip("the persistent form is compiled into experiment builds only (make experiments)")
+    hip.set_option("x_attn_q64_persist", "1")
     qp, k, v = mk(1, Sq, Sk, heads, seed=77)
     qd, kd, vd = qp.cuda(), k.cuda(), v.cuda()
     outs = [hip.ops.attention_prescaled(qd, kd, vd, heads) for _ in range(10)]
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
-    monkeypatch.setenv("LTX_ATTN_Q64_PERSIST", "0")
+    hip.set_option("x_attn_q64_persist", "0")
     o_grid = hip.ops.attention_prescaled(qd, kd, vd, heads)
     torch.cuda.synchronize()
     e = rel_l2(outs[0].float().cpu(), o_grid.float().cpu())
@@ -215,7 +216,8 @@ def test_q64_persistent_parts_with_different_maxima(hip, monkeypatch):
     """A key in the LAST key range scores far above everything in the first: the parts carry different fixed maxima m_p and
     the merge rescales by 2^(m_p - M); a second spike overflows inside one part (exact-max pass of that part only)."""
     heads, Sq, Sk = 32, 2304, 1024
-    monkeypatch.setenv("LTX_ATTN_Q64_PERSIST", "1")
+    if not hip.has_experiments(): pytest.skip("the persistent form is compiled into experiment builds only (make experiments)")
+    hip.set_option("x_attn_q64_persist", "1")
     qp, k, v = mk(1, Sq, Sk, heads, seed=31, qscale=2.0)
     qf, kf = qp.float(), k.float()
     kf[0, 1000] = qf[0, 100] * 3.0          # late key (last part), moderate spike for query 100 of every head

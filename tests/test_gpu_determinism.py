@@ -43,18 +43,18 @@ def test_split_k_result_is_the_same_for_every_tile(hip, monkeypatch):
     r = rnd(dt, M, N, seed=3).cuda(); gate = rnd(torch.float32, M // S, N, seed=4).cuda()
     xc = rnd(dt, 1, 5, 16, 24, 256, seed=5).cuda()                         # channels-last [B,T,H,W,C], 1920 voxels
     wc, bc = rnd(dt, 512, 256, 3, 3, 3, scale=0.012).cuda(), rnd(dt, 512, scale=0.1).cuda()
-    monkeypatch.setenv("LTX_GEMM_TUNE", "0")
+    hip.set_option("gemm_tune", "0")
     base_lin = hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S)
     base_conv = hip.ops.conv3d(xc, wc, bc)
     for tile in TILES:
-        monkeypatch.setenv("LTX_GEMM_TILE", tile)
+        hip.set_option("gemm_plan", tile)
         assert torch.equal(hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S), base_lin), tile
         assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), tile
-    monkeypatch.delenv("LTX_GEMM_TILE")
-    monkeypatch.delenv("LTX_GEMM_TUNE")
+    hip.set_option("gemm_plan", None)
+    hip.set_option("gemm_tune", None)
     assert torch.equal(hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S), base_lin)      # measured plan
     assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv)
-    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")                                # and the split really was active
+    hip.set_option("gemm_splitk", "0")                                        # and the split really was active
     unsplit = hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S)
     assert not torch.equal(unsplit, base_lin) and rel_l2(unsplit.float().cpu(), base_lin.float().cpu()) <= 4e-3
 
@@ -102,9 +102,9 @@ def test_fresh_processes_produce_identical_bits(tmp_path):
     plan_file = str(tmp_path / "plans.txt")
     runs = {
         "tuned": child("run"),
-        "static": child("run", env={"LTX_GEMM_TUNE": "0"}),
-        "tile128": child("run", env={"LTX_GEMM_TILE": "128x128"}),
-        "tile192": child("run", env={"LTX_GEMM_TILE": "192x128"}),
+        "static": child("run", env={"LTX_OPTIONS": "gemm_tune=0"}),
+        "tile128": child("run", env={"LTX_OPTIONS": "gemm_plan=128x128"}),
+        "tile192": child("run", env={"LTX_OPTIONS": "gemm_plan=192x128"}),
         "warm": child("warm", plan_file),
     }
     assert os.path.getsize(plan_file) > 50

@@ -1,4 +1,5 @@
-"""GPU suite: the opt-in one-wave-per-SIMD GEMM (csrc/gemm_asm.hip, LTX_GEMM_ASM=1) against the shipped gemm_big tiles.
+"""GPU suite: the one-wave-per-SIMD GEMMs of csrc/gemm_asm.hip (plan family asm16:*; round 1's 32x32x16 kernel in experiment
+builds) against the gemm_big tiles.
 
 Both accumulate bf16 products in f32 in ascending k; the MFMA shapes differ (32x32x16 vs 16x16x32).  The matrix core's
 accumulation is a k-ordered chain, so the two families are bit-identical - which is also why every gemm_big / gemm_p8
@@ -19,30 +20,32 @@ def hip():
     return ltxhip
 
 
+PLAN16 = {"asm256x256": "asm16:256x256", "asm160x256": "asm16:160x256", "asm320x256": "asm16:320x256"}
+TILE_IDX = {"asm256x256": "0", "asm320x256": "1", "asm160x256": "2"}        # gemm_asm.hip kAsmTiles order (x_gemm_asm_tile)
+
+
 @pytest.mark.parametrize("mode,tile", [("1", "asm256x256"), ("1", "asm320x256"), ("1", "asm160x256"), ("16", "asm256x256"), ("16", "asm160x256"), ("16", "asm320x256")])
 @pytest.mark.parametrize("M,N,K,epi", [(4992, 2048, 2048, 0), (4992, 6144, 2048, 1), (3001, 4104, 192, 0), (4992, 2048, 8192, 3)])
 def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
-    """mode "1": the 32x32x16 loop; "16": the 16x16x32 loop (round 3: the MFMA shape of the vendor kernel for these shapes)."""
+    """mode "16": the 16x16x32 loop (the shipped plan family asm16:*, forced with the gemm_plan option); "1": round 1's 32x32x16
+    loop, compiled into experiment builds only (x_gemm_asm=1)."""
+    if mode == "1" and not hip.has_experiments(): pytest.skip("the 32x32x16 kernel is compiled into experiment builds only (make experiments)")
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
     b = torch.randn(N, device="cuda", generator=g).bfloat16()
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == 3 else None
-    old = {k: os.environ.get(k) for k in ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_ASM16", "LTX_GEMM_TUNE")}
-    try:
-        # the reference arm must be gemm_big: asm16 is the default plan family of these shapes since round 3, so it is taken
-        # out of the static choice (LTX_GEMM_ASM16=0) and the plan cache bypassed (LTX_GEMM_TUNE=0: gemm_big.hip cached_or_tuned_plan
-        # returns before it looks at the cache, which may hold an asm16 plan of this shape from an earlier test)
-        os.environ.pop("LTX_GEMM_ASM", None); os.environ.pop("LTX_GEMM_ASM_TILE", None)
-        os.environ["LTX_GEMM_ASM16"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"
+    # the reference arm must be gemm_big: asm16 is the default plan family of these shapes since round 3, so it is taken out of
+    # the choice (gemm_off=asm16) and the plan cache bypassed (gemm_tune=0: cached_or_tuned_plan returns before it looks at the
+    # cache, which may hold an asm16 plan of this shape from an earlier test)
+    with hip.options(gemm_off="asm16", gemm_tune="0"):
         ref = hip.ops.linear(x, w, b, epi=epi, resid=resid)
-        os.environ.pop("LTX_GEMM_ASM16"); os.environ.pop("LTX_GEMM_TUNE")
-        os.environ["LTX_GEMM_ASM"] = mode; os.environ["LTX_GEMM_ASM_TILE"] = tile
-        got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+    if mode == "16":
+        with hip.options(gemm_plan=PLAN16[tile]):
+            got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
+    else:
+        with hip.options(x_gemm_asm="1", x_gemm_asm_tile=TILE_IDX[tile]):
+            got = hip.ops.linear(x, w, b, epi=epi, resid=resid)
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all()
     ref32 = (x.float() @ w.float().t() + b.float())
@@ -54,7 +57,7 @@ def test_asm_tiles_bit_identical_to_gemm_big(hip, mode, tile, M, N, K, epi):
 def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
     """The remaining epilogues of the DiT on the 16x16x32 loop's wide (LDS-transposed) epilogue: gate * y + residual with one
     f32 gate row per batch element (ragged M: the last row tile is partial) and the q|k|v projection written as three dense
-    matrices; bit-identical to gemm_big's wide epilogue and to its fragment-wise one (LTX_GEMM_WIDE_EPI=0)."""
+    matrices; bit-identical to gemm_big's wide epilogue and to its fragment-wise one (option gemm_wide_epi=0)."""
     g = torch.Generator(device="cuda").manual_seed(7)
     M, N, K = 2 * 1531, 2048, 2048
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -63,23 +66,14 @@ def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16()
     gate = torch.randn(2, N, device="cuda", generator=g)
     w3 = (torch.randn(3 * N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16(); b3 = torch.randn(3 * N, device="cuda", generator=g).bfloat16()
-    keys = ("LTX_GEMM_ASM", "LTX_GEMM_ASM_TILE", "LTX_GEMM_WIDE_EPI", "LTX_GEMM_ASM16", "LTX_GEMM_TUNE")
-    old = {k: os.environ.get(k) for k in keys}
     def run():
         return hip.ops.linear(x, w, b, epi=2, resid=resid, gate=gate, rows_per_batch=1531), hip.ops.linear_segmented(x, w3, b3, N)
-    try:
-        for k in keys: os.environ.pop(k, None)
-        os.environ["LTX_GEMM_ASM16"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"      # reference arms: gemm_big (asm16 out of the plans, static tile)
+    with hip.options(gemm_off="asm16", gemm_tune="0"):          # reference arms: gemm_big (asm16 out of the plans, static tile)
         ref = run()
-        os.environ["LTX_GEMM_WIDE_EPI"] = "0"
-        narrow = run()
-        os.environ.pop("LTX_GEMM_WIDE_EPI"); os.environ.pop("LTX_GEMM_ASM16"); os.environ.pop("LTX_GEMM_TUNE")
-        os.environ["LTX_GEMM_ASM"] = "16"; os.environ["LTX_GEMM_ASM_TILE"] = tile
+        with hip.options(gemm_wide_epi="0"):
+            narrow = run()
+    with hip.options(gemm_plan=PLAN16[tile]):
         wide = run()
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
     torch.cuda.synchronize()
     want = resid.float() + gate.repeat_interleave(1531, 0) * (x.float() @ w.float().t() + b.float())
     assert (ref[0].float() - want).norm() / want.norm() < 4e-3

@@ -13,7 +13,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 RING_TILES = ["ring:96x64", "ring:96x96", "ring:96x128", "ring:64x64", "ring:64x128", "ring:128x64", "ring:128x128", "ring:128x96", "ring:96x32", "ring:128x32", "ring:64x32"]
-KEYS = ("LTX_GEMM_RING_TILE", "LTX_GEMM_RING", "LTX_GEMM_TUNE", "LTX_GEMM_ASM16")
 
 
 @pytest.fixture(scope="module")
@@ -25,21 +24,13 @@ def hip():
 
 def _arms(hip, tile, fn):
     """fn() on gemm_big's static tile (ring family off, plan cache bypassed), then on the forced ring tile."""
-    old = {k: os.environ.get(k) for k in KEYS}
-    try:
-        os.environ.pop("LTX_GEMM_RING_TILE", None)
-        os.environ["LTX_GEMM_RING"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"; os.environ["LTX_GEMM_ASM16"] = "0"
-        ref = fn()
-        os.environ.pop("LTX_GEMM_RING"); os.environ.pop("LTX_GEMM_TUNE"); os.environ.pop("LTX_GEMM_ASM16")
-        os.environ["LTX_GEMM_RING_TILE"] = tile
+    with hip.options(gemm_off="ring+asm16", gemm_tune="0"):
+        ref = fn(False)
+    with hip.options(gemm_plan=tile):
         hip.prof_enable(True)
-        got = fn()
+        got = fn(True)
         ms, _, cnt = hip.prof_report_kernel(0, hip.PROF_KERNELS.index("gemm_ring_kernel"))
         hip.prof_enable(False)
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
     torch.cuda.synchronize()
     assert cnt >= 1, "the forced ring tile did not run"
     return ref, got
@@ -56,7 +47,7 @@ def test_ring_tiles_bit_identical_to_gemm_big(hip, tile, M, N, K, epi):
     b = torch.randn(N, device="cuda", generator=g).bfloat16()
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi in (2, 3) else None
     gate = torch.randn(1, N, device="cuda", generator=g) if epi == 2 else None
-    ref, got = _arms(hip, tile, lambda: hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M))
+    ref, got = _arms(hip, tile, lambda forced: hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M))
     assert torch.isfinite(got.float()).all()
     if epi == 0:                                                    # and it is a GEMM, not two equal wrongs
         ref32 = x.float() @ w.float().t() + b.float()
@@ -73,11 +64,11 @@ def test_ring_segmented_qkv_output_and_two_batch_gate(hip, tile):
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(6144, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
     b = torch.randn(6144, device="cuda", generator=g).bfloat16()
-    ref, got = _arms(hip, tile, lambda: hip.ops.linear_segmented(x, w, b, 2048))
+    ref, got = _arms(hip, tile, lambda forced: hip.ops.linear_segmented(x, w, b, 2048))
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     w2 = w[:2048].contiguous(); b2 = b[:2048].contiguous()
     resid = torch.randn(M, 2048, device="cuda", generator=g).bfloat16(); gate = torch.randn(2, 2048, device="cuda", generator=g)
-    ref, got = _arms(hip, tile, lambda: hip.ops.linear(x, w2, b2, epi=2, resid=resid, gate=gate, rows_per_batch=192))
+    ref, got = _arms(hip, tile, lambda forced: hip.ops.linear(x, w2, b2, epi=2, resid=resid, gate=gate, rows_per_batch=192))
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     want = resid.float() + gate.repeat_interleave(192, 0) * (x.float() @ w2.float().t() + b2.float())
     assert (got.float() - want).norm() / want.norm() < 4e-3
@@ -94,14 +85,8 @@ def test_ring_plans_are_measured_and_saved_for_small_m(hip, tmp_path):
     got = hip.ops.linear(x, w, b, epi=0)
     plan = hip.ops.gemm_plan(M, N, K)
     assert plan != ""
-    old = {k: os.environ.get(k) for k in KEYS}
-    try:
-        os.environ["LTX_GEMM_RING"] = "0"; os.environ["LTX_GEMM_TUNE"] = "0"
+    with hip.options(gemm_off="ring", gemm_tune="0"):
         ref = hip.ops.linear(x, w, b, epi=0)
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     p = str(tmp_path / "plans.txt")
     hip.plan_save(p)
@@ -125,18 +110,12 @@ def test_ring_on_packed_weights_bit_identical(hip, tile, M, N, K, epi):
     # the packed image holds exactly the weights, in 32 x 64 blocks
     blocks = wp.view(-(-N // 32), -(-K // 64), 32, 64)
     assert torch.equal(blocks[0, 0, : min(32, N), : min(64, K)], w[: min(32, N), : min(64, K)])
-    old = {k: os.environ.get(k) for k in KEYS}
-    try:
-        os.environ["LTX_GEMM_RING_TILE"] = tile
+    with hip.options(gemm_plan=tile):
         ref = hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M)
         hip.prof_enable(True)
         got = hip.ops.linear_packed(x, w, wp, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M)
         _, _, cnt = hip.prof_report_kernel(0, hip.PROF_KERNELS.index("gemm_ring_kernel"))
         hip.prof_enable(False)
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
     assert cnt >= 1
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
@@ -161,8 +140,8 @@ def test_ring_fuzz_random_shapes_tiles_and_epilogues(hip):
         gate = torch.randn(nb, N, device="cuda", generator=g) if epi == 2 else None
         packed = rnd.random() < 0.5
         wp = hip.ops.ring_pack(w) if packed else None
-        def run():
-            if packed and os.environ.get("LTX_GEMM_RING_TILE"):
+        def run(forced):
+            if packed and forced:
                 return hip.ops.linear_packed(x, w, wp, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M // nb)
             return hip.ops.linear(x, w, b, epi=epi, resid=resid, gate=gate, rows_per_batch=M // nb)
         ref, got = _arms(hip, tile, run)

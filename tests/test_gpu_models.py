@@ -89,7 +89,7 @@ def test_dit_batch_rows_are_independent(hip, golden):
 
 @pytest.mark.parametrize("mdt", [torch.float32, torch.bfloat16])
 def test_dit_dense_and_sliced_qkv_layouts_agree(hip, golden, mdt, monkeypatch):
-    """The fused q|k|v projection writes three dense [M, D] matrices (segmented GEMM output); LTX_DENSE_QKV=0 keeps the
+    """The fused q|k|v projection writes three dense [M, D] matrices (segmented GEMM output); option dense_qkv=0 keeps the
     column-slice layout that a D which is not a power of two takes.  Same arithmetic either way: identical outputs."""
     g, md, w, out = _dit_case(hip, golden, "B", mdt)
     cfgd = ast.literal_eval(md["cfg"])
@@ -97,8 +97,8 @@ def test_dit_dense_and_sliced_qkv_layouts_agree(hip, golden, mdt, monkeypatch):
     model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, mdt)
     args = (g["hidden"].to(DEV), g["enc"].to(DEV), g["timestep"], g["mask"].to(DEV), Fr, H, W, None, g["coords"].to(DEV), g["skip_layer_mask"])
     o_dense = model.forward(*args)
-    monkeypatch.setenv("LTX_DENSE_QKV", "0")
-    o_sliced = model.forward(*args)
+    with hip.options(dense_qkv="0"):
+        o_sliced = model.forward(*args)
     assert torch.equal(o_dense, o_sliced)
 
 
@@ -112,7 +112,7 @@ def _vae(hip, dt, seed=7):
 def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch):
     """Where one conv tile spans all channels (128 / 256-channel stages, >= 1024 voxels) the resnet's norm2 + modulation +
     SiLU runs inside conv1's wide epilogue.  A decoder with 512 / 256 / 128-channel stages: fused vs the separate norm
-    pass (LTX_VAE_FUSE_NORM=0) agree to bf16 rounding of the row statistics' summation order, with and without timestep
+    pass (option vae_fuse_norm=0) agree to bf16 rounding of the row statistics' summation order, with and without timestep
     conditioning, and both stay within the bf16 bar of the f32-mode decode."""
     cfgd = dict(latent_channels=16, decoder_block_out_channels=(256, 512), decoder_layers_per_block=(1, 1, 1))
     cfg = O.VaeConfig(**cfgd)
@@ -127,10 +127,9 @@ def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch):
         if dt == torch.bfloat16:
             assert torch.equal(outs[dt], model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu())
             no_t = model.decode(z.to(DEV), None).float().cpu()
-            monkeypatch.setenv("LTX_VAE_FUSE_NORM", "0")
-            sep = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
-            sep_no_t = model.decode(z.to(DEV), None).float().cpu()
-            monkeypatch.delenv("LTX_VAE_FUSE_NORM")
+            with hip.options(vae_fuse_norm="0"):
+                sep = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
+                sep_no_t = model.decode(z.to(DEV), None).float().cpu()
             assert rel_l2(outs[dt], sep) <= 5e-3, rel_l2(outs[dt], sep)
             assert rel_l2(no_t, sep_no_t) <= 5e-3
         del model
@@ -507,7 +506,7 @@ def test_t5_attention_on_the_mfma_kernel_vs_oracle_and_the_scalar_kernel(hip):
     """The pipeline's T5 geometry class - bf16, d_kv 64, at most 128 tokens (a multiple of 4) - runs its self-attention on the
     DiT's short-key-set MFMA kernel with the relative position bias as a [heads, S, S] table (AttnArgs::bias2d) and the padding
     mask as its key bias.  Against the f32 oracle (the bf16 bar of the test above) and against the one-query-per-wave kernel
-    (LTX_T5_ATTN_MFMA=0), with and without a mask, ragged S."""
+    (option t5_attn_mfma=0), with and without a mask, ragged S."""
     kw = dict(vocab_size=120, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=4)
     cfg = O.T5Config(**kw)
     g = torch.Generator().manual_seed(31)
@@ -532,13 +531,8 @@ def test_t5_attention_on_the_mfma_kernel_vs_oracle_and_the_scalar_kernel(hip):
             _, _, n_self = hip.prof_report(2); _, _, n_cross = hip.prof_report(3)
             hip.prof_enable(False)
             assert n_self + n_cross == kw["num_layers"], "the MFMA attention kernel did not serve the layers"
-            old = os.environ.get("LTX_T5_ATTN_MFMA")
-            os.environ["LTX_T5_ATTN_MFMA"] = "0"
-            try:
+            with hip.options(t5_attn_mfma="0"):
                 scalar = enc.forward(ids, am).float().cpu()
-            finally:
-                if old is None: os.environ.pop("LTX_T5_ATTN_MFMA")
-                else: os.environ["LTX_T5_ATTN_MFMA"] = old
             rows = slice(None) if am is None else None
             e_new, e_old = rel_l2(got, want), rel_l2(scalar, want)
             assert e_new <= max(2.0 * d_ref, 2e-2), (S, am is not None, e_new, d_ref)

@@ -218,17 +218,14 @@ def test_conv_out_on_the_halo_tile_vs_oracle_and_per_tap_tile(hip):
     """conv_out at the decoder's real channel count (128 -> 48, unpatchify epilogue, vae.rs:1626-1654) on a ragged plane
     (19 x 37: partial patches on both edges, three frames: first / middle / last frame taps): the 64-wide halo-staged tile
     (round 4 default) against the f32 oracle at the bf16 bar and BIT-IDENTICAL to the per-tap 192 x 64 tile it replaced
-    (LTX_CONV_OUT_HALO=0; same K order), with and without the post-processing epilogue."""
-    import os
+    (option gemm_off=halo_out; same K order), with and without the post-processing epilogue."""
     dt = torch.bfloat16
     x, w, b = rnd(dt, 1, 128, 3, 19, 37), rnd(dt, 48, 128, 3, 3, 3, scale=0.02), rnd(dt, 48, scale=0.1)
     ref = O.unpatchify(O.causal_conv3d(x.float(), w.float(), b.float(), False), 4, 1)
     outs = {}
     for arm in ("0", None):
-        if arm is None: os.environ.pop("LTX_CONV_OUT_HALO", None)
-        else: os.environ["LTX_CONV_OUT_HALO"] = arm
-        outs[arm] = (hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda()), hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda(), postprocess=True))
-    os.environ.pop("LTX_CONV_OUT_HALO", None)
+        with hip.options(gemm_off="halo_out" if arm == "0" else None):
+            outs[arm] = (hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda()), hip.ops.conv_out_unpatchify(cl(x).cuda(), w.cuda(), b.cuda(), postprocess=True))
     check(outs[None][0], ref, dt)
     assert torch.equal(outs[None][0], outs["0"][0]) and torch.equal(outs[None][1], outs["0"][1])
     assert (outs[None][1].cpu() - O.postprocess_video(outs[None][0].cpu())).abs().max() < 1e-3
@@ -278,10 +275,7 @@ def test_errors_are_reported_not_crashed(hip):
                                   "160x128", "192x64", "160x256w16", "192x256w16", "320x256w16", "256x256w16", "p8:256", "p8:128"])
 def test_big_tile_gemm_all_tiles_and_epilogues(hip, tile, monkeypatch):
     """gemm_big.hip (LDS-DMA staged, 8 waves) and gemm_p8.hip (phase-interleaved): every tile shape, ragged M/N/K tails, every epilogue."""
-    if tile.startswith("p8:"):
-        monkeypatch.setenv("LTX_GEMM_P8", tile[3:])
-    else:
-        monkeypatch.setenv("LTX_GEMM_TILE", tile)
+    hip.set_option("gemm_plan", tile)
     dt = torch.bfloat16
     M, N, K, S = 1300, 328, 200, 650
     x, w, b = rnd(dt, M, K), rnd(dt, N, K, scale=K ** -0.5), rnd(dt, N, scale=0.1)
@@ -307,25 +301,24 @@ def test_gemm_plans_are_bit_identical_and_tuner_caches(hip, monkeypatch):
     dispatcher measures best may change speed only: outputs must be bit-identical across forced plans and the tuned path.
     (The tail split-K of gemm_big sums K-ranges separately -- an f32 re-association, covered by test_gemm_tail_split_k --
     so it is switched off here.)"""
-    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
+    hip.set_option("gemm_splitk", "0")
     dt = torch.bfloat16
     M, N, K = 2048, 384, 320
     x, w, b = rnd(dt, M, K).cuda(), rnd(dt, N, K, scale=K ** -0.5).cuda(), rnd(dt, N, scale=0.1).cuda()
     xc, wc, bc = cl(rnd(dt, 1, 64, 3, 24, 20)).cuda(), rnd(dt, 128, 64, 3, 3, 3, scale=0.03).cuda(), rnd(dt, 128, scale=0.1).cuda()
-    monkeypatch.setenv("LTX_GEMM_TUNE", "0")
+    hip.set_option("gemm_tune", "0")
     base_lin, base_conv = hip.ops.linear(x, w, b, epi=1), hip.ops.conv3d(xc, wc, bc)
     for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128", "192x64",
                  "160x256w16", "192x256w16", "320x256w16", "256x256w16"]:
-        monkeypatch.setenv("LTX_GEMM_TILE", tile)
+        hip.set_option("gemm_plan", tile)
         assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), tile
         assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), tile
-    monkeypatch.delenv("LTX_GEMM_TILE")
-    for p8 in ["256", "128"]:
-        monkeypatch.setenv("LTX_GEMM_P8", p8)
+    for p8 in ["p8:256", "p8:128"]:
+        hip.set_option("gemm_plan", p8)
         assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin), p8
         assert torch.equal(hip.ops.conv3d(xc, wc, bc), base_conv), p8
-    monkeypatch.delenv("LTX_GEMM_P8")
-    monkeypatch.setenv("LTX_GEMM_TUNE", "1")
+    hip.set_option("gemm_plan", None)
+    hip.set_option("gemm_tune", "1")
     assert hip.ops.gemm_plan(M, N, K) == ""
     assert torch.equal(hip.ops.linear(x, w, b, epi=1), base_lin)
     plan = hip.ops.gemm_plan(M, N, K)
@@ -372,8 +365,8 @@ def test_attention_prescaled_dma_ring_screen(hip):
 def test_gemm_tail_split_k(hip, tile, monkeypatch):
     """gemm_big cuts the tiles of a partly filled last round into K-ranges that meet in an in-launch reduction (f32 slabs,
     one release/acquire per tile).  Shapes chosen so that the split is active for every tile; repeated launches reuse the
-    self-resetting arrival counters; LTX_GEMM_SPLITK=0 is the unsplit reference (differences = f32 summation order only)."""
-    monkeypatch.setenv("LTX_GEMM_TILE", tile)
+    self-resetting arrival counters; option gemm_splitk=0 is the unsplit reference (differences = f32 summation order only)."""
+    hip.set_option("gemm_plan", tile)
     dt = torch.bfloat16
     M, N, K, S = 1500, 56 if tile == "192x64" else 600, 2048, 750
     x, w, b = rnd(dt, M, K).cuda(), rnd(dt, N, K, scale=K ** -0.5).cuda(), rnd(dt, N, scale=0.1).cuda()
@@ -384,10 +377,9 @@ def test_gemm_tail_split_k(hip, tile, monkeypatch):
     for o in outs:
         check(o, want, dt)
         assert torch.equal(o, outs[0])                      # the reduction order is fixed (slabs summed by part index)
-    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
-    base = hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S)
+    with hip.options(gemm_splitk="0"):
+        base = hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S)
     assert rel_l2(outs[0].float().cpu(), base.float().cpu()) <= 4e-3
-    monkeypatch.delenv("LTX_GEMM_SPLITK")
     xc, wc, bc = cl(rnd(dt, 1, 256, 3, 20, 19)).cuda(), rnd(dt, 64 if tile != "192x64" else 48, 256, 3, 3, 3, scale=0.01).cuda(), rnd(dt, 64 if tile != "192x64" else 48, scale=0.1).cuda()
     if tile != "192x64" and tile != "256x256":              # N = 64 needs a 128-wide tile here
         y = hip.ops.conv3d(xc, wc, bc)
@@ -473,9 +465,8 @@ def test_attention_short_key_kernel_vs_cpu(hip, Sk, monkeypatch):
         o = hip.ops.attention(*args)
         ref = ref_attention(q, k, v, heads, 0.125, bias)
         assert rel_l2(o.float().cpu(), ref) <= BF16_TOL, (Sq, Sk, B, biased, rel_l2(o.float().cpu(), ref))
-        monkeypatch.setenv("LTX_ATTN_CROSS", "0")
-        o_generic = hip.ops.attention(*args)
-        monkeypatch.delenv("LTX_ATTN_CROSS")
+        with hip.options(attn_off="cross"):
+            o_generic = hip.ops.attention(*args)
         assert rel_l2(o.float().cpu(), o_generic.float().cpu()) <= BF16_TOL
 
 
@@ -492,9 +483,12 @@ def test_attention_pipelined_kernel_tile_counts(hip, Sk, monkeypatch):
     o = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
     ref = ref_attention(qp, k, v, heads, math.log(2.0), None)
     assert rel_l2(o.float().cpu(), ref) <= BF16_TOL, (Sk, rel_l2(o.float().cpu(), ref))
-    monkeypatch.setenv("LTX_ATTN_PIPE", "0")
-    o1 = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
-    assert rel_l2(o.float().cpu(), o1.float().cpu()) <= BF16_TOL
+    with hip.options(attn_off="q64"):                # the pipelined kernel itself (attn_q64 serves the launch by default since round 2)
+        o_pipe = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel_l2(o_pipe.float().cpu(), ref) <= BF16_TOL, (Sk, rel_l2(o_pipe.float().cpu(), ref))
+    with hip.options(attn_off="pipe+q64"):
+        o1 = hip.ops.attention_prescaled(qp.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel_l2(o_pipe.float().cpu(), o1.float().cpu()) <= BF16_TOL and rel_l2(o.float().cpu(), o1.float().cpu()) <= BF16_TOL
 
 
 @pytest.mark.gpu
@@ -509,12 +503,12 @@ def test_conv3d_halo_staged_kernel(hip, bn, B, Cin, Cout, T, H, W, causal, monke
     x, w, b = rnd(dt, B, Cin, T, H, W), rnd(dt, Cout, Cin, 3, 3, 3, scale=(27 * Cin) ** -0.5), rnd(dt, Cout, scale=0.1)
     r = rnd(dt, B, Cout, T, H, W, seed=5)
     xc, rc = cl(x).cuda(), cl(r).cuda()
-    monkeypatch.setenv("LTX_CONV_HALO", "0")
-    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
-    base = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal)
-    base_res = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc)
-    base_up = hip.ops.upsample3d(xc, w.cuda(), b.cuda(), causal)
-    monkeypatch.setenv("LTX_CONV_HALO", bn)
+    hip.set_option("gemm_splitk", "0")
+    with hip.options(gemm_off="halo"):
+        base = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal)
+        base_res = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc)
+        base_up = hip.ops.upsample3d(xc, w.cuda(), b.cuda(), causal)
+    hip.set_option("gemm_plan", "halo:" + bn)
     y = hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal)
     assert torch.equal(y, base)
     assert torch.equal(hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc), base_res)
@@ -528,25 +522,25 @@ def test_real_shape_plans_are_bit_identical(hip, monkeypatch):
     """At the DiT's and the VAE's own shapes (not the small test shapes): the 16-wave GEMM tiles, the wide epilogue and the
     halo-staged conv give exactly the bits of the 8-wave / fragment-store / per-tap forms."""
     dt = torch.bfloat16
-    monkeypatch.setenv("LTX_GEMM_SPLITK", "0")
+    hip.set_option("gemm_splitk", "0")
     S = 4992
     x, w, b = rnd(dt, S, 2048).cuda(), rnd(dt, 2048, 2048, scale=2048 ** -0.5).cuda(), rnd(dt, 2048, scale=0.1).cuda()
     r, gate = rnd(dt, S, 2048, seed=3).cuda(), rnd(torch.float32, 1, 2048, seed=4).cuda()
     outs = []
     for tile, wide in [("160x128", "0"), ("160x256w16", "1"), ("256x256w16", "1"), ("320x256w16", "0"), ("192x128", "1")]:
-        monkeypatch.setenv("LTX_GEMM_TILE", tile); monkeypatch.setenv("LTX_GEMM_WIDE_EPI", wide)
+        hip.set_option("gemm_plan", tile); hip.set_option("gemm_wide_epi", wide)
         outs.append((hip.ops.linear(x, w, b), hip.ops.linear(x, w, b, epi=2, resid=r, gate=gate, rows_per_batch=S), hip.ops.linear(x, w, b, epi=1)))
     for o in outs[1:]:
         assert all(torch.equal(a, c) for a, c in zip(o, outs[0]))
-    monkeypatch.delenv("LTX_GEMM_TILE"); monkeypatch.delenv("LTX_GEMM_WIDE_EPI")
+    hip.set_option("gemm_plan", None); hip.set_option("gemm_wide_epi", None)
     # the 128-channel VAE stage's plane (128 x 192) with 4 frames
     xc, wc, bc = cl(rnd(dt, 1, 128, 4, 128, 192)).cuda(), rnd(dt, 128, 128, 3, 3, 3, scale=(27 * 128) ** -0.5).cuda(), rnd(dt, 128, scale=0.1).cuda()
     rc = cl(rnd(dt, 1, 128, 4, 128, 192, seed=6)).cuda()
-    monkeypatch.setenv("LTX_CONV_HALO", "0")
-    base = hip.ops.conv3d(xc, wc, bc, True, resid=rc)
-    monkeypatch.setenv("LTX_CONV_HALO", "128")
+    with hip.options(gemm_off="halo"):
+        base = hip.ops.conv3d(xc, wc, bc, True, resid=rc)
+    hip.set_option("gemm_plan", "halo:128")
     assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
-    monkeypatch.setenv("LTX_GEMM_WIDE_EPI", "0")
+    hip.set_option("gemm_wide_epi", "0")
     assert torch.equal(hip.ops.conv3d(xc, wc, bc, True, resid=rc), base)
 
 

@@ -32,17 +32,9 @@ def hip():
 
 
 def env(**kw):
-    class E:
-        def __enter__(self):
-            self.old = {k: os.environ.get(k) for k in kw}
-            for k, v in kw.items():
-                if v is None: os.environ.pop(k, None)
-                else: os.environ[k] = v
-        def __exit__(self, *a):
-            for k, v in self.old.items():
-                if v is None: os.environ.pop(k, None)
-                else: os.environ[k] = v
-    return E()
+    """run-time options for a block (ltx_set_option; include/ltxhip.h), defaults restored after it"""
+    import ltxhip
+    return ltxhip.options(**kw)
 
 
 @pytest.mark.parametrize("M,N,K", [(4992, 2048, 2048), (384, 2048, 2048), (1000, 640, 256), (3001, 1032, 192), (600, 4096, 512)])
@@ -60,11 +52,11 @@ def test_rowsq_byproduct_is_canonical_and_exact(hip, M, N, K):
     yp = torch.zeros(M, ng * 128, dtype=torch.float64, device=DEV); yp[:, :N] = y0.double()
     want = (yp ** 2).view(M, ng, 128).sum(-1)
     assert (rs0.double() - want).abs().max() <= 2e-6 * want.abs().max()
-    for e in (dict(LTX_GEMM_ASM16="0", LTX_GEMM_TUNE="0"), dict(LTX_GEMM_ASM="16")):
+    for e in (dict(gemm_off="asm16", gemm_tune="0"), dict(gemm_plan="asm16")):
         with env(**e):
             y1, rs1 = hip.ops.linear_rowsq(x, w, b)
         assert torch.equal(y1, y0) and torch.equal(rs1, rs0), e       # same output bits (plan independence), same partials
-    with env(LTX_GEMM_BIG="0"):                                       # gemm.hip's 128 x 128 kernel: un-split K (another f32 order on split shapes)
+    with env(gemm_off="big"):                                       # gemm.hip's 128 x 128 kernel: un-split K (another f32 order on split shapes)
         y2, rs2 = hip.ops.linear_rowsq(x, w, b)
     assert torch.equal(rs2, hip.ops.rowsq(y2)) and (y2.float() - y0.float()).abs().max() <= 0.05
     xf, wf, bf = x.float(), w.float(), b.float()
@@ -108,7 +100,7 @@ def test_folded_cross_attention_vs_f32_reference_and_unfolded_path(hip, B, Sq, S
 
 def test_dit_forward_with_and_without_the_fold_vs_oracle(hip):
     """A two-layer DiT of the fold's shape class (D = 512 = 8 heads x 64, K = 128 text tokens of which 40 are valid, ragged
-    S = 2 x 7 x 9 = 126) through ltx_dit_forward in bf16 with LTX_Q2_FOLD=0 / default: both within the bf16 bar of the f32
+    S = 2 x 7 x 9 = 126) through ltx_dit_forward in bf16 with option q2_fold=0 / default: both within the bf16 bar of the f32
     oracle (fed bf16-rounded weights, inputs and timestep), the folded form no further from it than the stand-alone pass,
     and the two differ (the fold really ran).  f32 mode (which keeps the stand-alone pass) <= 1e-3."""
     from conftest import rel_max
@@ -130,7 +122,7 @@ def test_dit_forward_with_and_without_the_fold_vs_oracle(hip):
     ref = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords)
     outs = {}
     for tag, fold, dt in (("off", "0", torch.bfloat16), ("on", "2", torch.bfloat16), ("f32", None, torch.float32)):   # "2": fold whatever M (the default folds from M = 512 up)
-        with env(LTX_Q2_FOLD=fold):
+        with env(q2_fold=fold):
             model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, dt)
             outs[tag] = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV)).float().cpu()
             y2 = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV)).float().cpu()
@@ -174,13 +166,13 @@ def test_rownorm_from_presums_matches_the_row_reducing_pass(hip):
 @pytest.mark.parametrize("S,D,B", [(4992, 2048, 1), (384, 2048, 1), (2 * 252, 512, 2), (4992, 1024, 3)])
 def test_presum_lean_kernel_bit_identical_to_the_general_one(hip, S, D, B):
     """rownorm_presum_lean_kernel (the DiT's case with nothing decided at run time) against rownorm_presum_kernel
-    (LTX_NORM_LEAN=0) on the same rows: same expressions in the same order, every bit equal; several batch elements with their
+    (option norm_lean=0) on the same rows: same expressions in the same order, every bit equal; several batch elements with their
     own modulation rows, 64 / 128 / 256 chunks per row."""
     g = torch.Generator().manual_seed(S + D)
     x = (torch.randn(S, D, generator=g) * 1.7).bfloat16().to(DEV)
     sc = torch.randn(B, D, generator=g).to(DEV); sh = torch.randn(B, D, generator=g).to(DEV)
     rs = hip.ops.rowsq(x)
-    with env(LTX_NORM_LEAN="0"):
+    with env(norm_lean="0"):
         y_gen = hip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S // B, 0)
     y_lean = hip.ops.rownorm_presum(x, rs, 1e-6, None, sc, sh, S // B, 0)
     assert torch.equal(y_gen.view(torch.int16), y_lean.view(torch.int16))
@@ -189,7 +181,7 @@ def test_presum_lean_kernel_bit_identical_to_the_general_one(hip, S, D, B):
 
 
 def test_dit_with_presum_norms_vs_oracle(hip):
-    """The same two-layer DiT as above with LTX_NORM_PRESUM=0 / 2 (forced: at M = 252 the partials come from the stand-alone pass,
+    """The same two-layer DiT as above with option norm_presum=0 / 2 (forced: at M = 252 the partials come from the stand-alone pass,
     which is the same canonical sum): both within the bf16 bar of the f32 oracle, neither worse than the other by more than noise."""
     cfgd = dict(in_channels=32, out_channels=32, num_attention_heads=8, attention_head_dim=64, cross_attention_dim=512, num_layers=2, caption_channels=64)
     cfg = O.DitConfig(**cfgd)
@@ -206,7 +198,7 @@ def test_dit_with_presum_norms_vs_oracle(hip):
     ref = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords, slm)
     outs = {}
     for tag, v in (("off", "0"), ("on", "2")):
-        with env(LTX_NORM_PRESUM=v):
+        with env(norm_presum=v):
             model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: x.to(DEV) for k, x in w.items()}, torch.bfloat16)
             outs[tag] = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV), slm).float().cpu()
     e_off, e_on = rel_l2(outs["off"], ref), rel_l2(outs["on"], ref)

@@ -8,8 +8,6 @@ instead of ceil(K / 32): BASELINE's prompts keep 32 of 128 tokens.  Checked here
 compacted path against ltx_op_attention on the same inputs (prefix masks: the same bits; any mask: within a bf16 rounding of
 the output) and against an f32 reference; every-key-masked rows (a constant shift: all keys kept); fractional mask values; the
 folded q-norm on top; a whole DiT forward with a non-prefix mask against the oracle with compaction on and off."""
-import os
-
 import pytest
 import torch
 
@@ -112,7 +110,7 @@ def test_compaction_under_the_folded_q_norm(hip):
 
 def test_dit_forward_with_a_scattered_mask_vs_oracle(hip):
     """ltx_dit_forward (bf16, D = 512, 128 text tokens, batch of two with different scattered masks) with the compaction on
-    (default) and off (LTX_XATTN_COMPACT=0): both within the bf16 bar of the f32 oracle, and within rounding of each other."""
+    (default) and off (option xattn_compact=0): both within the bf16 bar of the f32 oracle, and within rounding of each other."""
     cfgd = dict(in_channels=32, out_channels=32, num_attention_heads=8, attention_head_dim=64, cross_attention_dim=512, num_layers=2, caption_channels=64)
     cfg = O.DitConfig(**cfgd)
     w = O.synth_weights(O.dit_weight_shapes(cfg), seed=79)
@@ -127,13 +125,9 @@ def test_dit_forward_with_a_scattered_mask_vs_oracle(hip):
     ref = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords)
     outs = {}
     for tag, val in (("on", None), ("off", "0")):
-        if val is None: os.environ.pop("LTX_XATTN_COMPACT", None)
-        else: os.environ["LTX_XATTN_COMPACT"] = val
-        try:
+        with hip.options(xattn_compact=val):
             model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**cfgd), {k: v.to(DEV) for k, v in w.items()}, torch.bfloat16)
             outs[tag] = model.forward(hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), Fr, H, W, None, coords.to(DEV)).float().cpu()
-        finally:
-            os.environ.pop("LTX_XATTN_COMPACT", None)
     e_on, e_off = rel_l2(outs["on"], ref), rel_l2(outs["off"], ref)
     print(f"dit scattered mask bf16 vs f32 oracle: compact {e_on:.5f}, full {e_off:.5f}; between them {rel_l2(outs['on'], outs['off']):.6f}")
     assert e_on <= 2e-2 and e_on <= 1.25 * e_off + 1e-3

@@ -332,7 +332,12 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         emit("s_add_u32 %[bk], %[bk], 128")
         wrap()
 
-    def kstep2(stage):
+    RES = int(opt.get("res_rows", 0))                       # residual tile rows per lane prefetched inside the loop (see c_function16)
+    RES_PER = 2                                             # rows per K-step -> 2 * RES_PER loads
+    RES_V = RB + 28                                         # v[RES_V : RES_V + 2 RES) first halves, then second halves; lane offsets in v[RB+24 : RB+25]
+    if RES: assert AI + BI <= 16 and RES % RES_PER == 0 and RES_V + 4 * RES <= 256 and not TRACE
+
+    def kstep2(stage, res_row=None):
         """pgr = 2 (the vendor kernel's depth): ALL fragments of K-step t are in registers early in iteration t (half 0's were
         read at the end of t-1, half 1's in the first gaps), so after a barrier the stage is free and takes the DMA pieces of
         K-step t+2, spread over the REST of the iteration: a 1 KB piece occupies the CU's address unit for ~16 cycles and the
@@ -356,13 +361,24 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         pcs = [d for d in (dma(stage, p) for p in range(npieces)) if d]
         dstep = max(2, (last - b1 - 2) // max(len(pcs), 1))
         before_b2 = 0
+        nres = 0
+        if res_row is not None:
+            # residual rows res_row .. res_row + RES_PER - 1 of this lane: plain buffer loads between the fragment reads and the first
+            # barrier, i.e. OLDER than this K-step's pieces and YOUNGER than the pieces the second barrier waits for
+            g0 = min(g_rd * nrd + 1, b1 - 1)
+            for j in range(RES_PER):
+                r = res_row + j
+                slots[min(g0 + 2 * j, b1 - 1)] += [f"buffer_load_dwordx2 v[{RES_V + 2 * r}:{RES_V + 2 * r + 1}], v{RB + 24}, %[rres], %[roff] offen",
+                                                   f"buffer_load_dwordx2 v[{RES_V + 2 * RES + 2 * r}:{RES_V + 2 * RES + 2 * r + 1}], v{RB + 25}, %[rres], %[roff] offen",
+                                                   "s_add_u32 %[roff], %[roff], %[rstride]"]
+                nres += 2
         for i, (m0, ld) in enumerate(pcs):
             g = b1 + 2 + dstep * i
             if g == gb2: g += 1
             before_b2 += g < gb2
             slots[g - 1].append(m0)
             slots[g].append(ld)
-        slots[gb2] = [f"s_waitcnt vmcnt({before_b2})"] + ([] if "nobar" in abl else ["s_barrier"]) + slots[gb2]
+        slots[gb2] = [f"s_waitcnt vmcnt({before_b2 + nres})"] + ([] if "nobar" in abl else ["s_barrier"]) + slots[gb2]
         rd = reads(stage ^ 1, 0, 0)
         for i, r in enumerate(rd): slots[min(gb2 + 1 + rd2_step * i, G - 1)].append(r)
         if TRACE:
@@ -428,6 +444,15 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         for r in (60, 62, 64, 66, 68, 70, 84): emit(f"s_mov_b32 s{r}, s72")
         for r in range(76, 84): emit(f"s_mov_b32 s{r}, 0")
     for ins in reads(0, 0, 0): emit(ins)
+    if RES:
+        # phase A: the first RES / RES_PER K-steps, unrolled, each requesting RES_PER rows of the residual tile (the caller
+        # guarantees at least that many K-steps + 2); an even count, so the main loop starts on stage 0 as always
+        assert PGR == 2 and (RES // RES_PER) % 2 == 0
+        for t in range(RES // RES_PER):
+            kstep2(t & 1, res_row=t * RES_PER)
+            emit("s_add_i32 %[cnt], %[cnt], -1")
+        emit("s_cmp_eq_u32 %[cnt], 0")
+        emit("s_cbranch_scc1 2f")
     emit(".p2align 6")
     emit("1:")
     (kstep2 if PGR == 2 else kstep)(0)
@@ -446,7 +471,7 @@ def gen16(BM, BN, WGM, WGN, opt=None):
     if TRACE:
         for i in range(7): emit(f"s_mov_b32 %[t{i}], s{76 + i}")
         emit("s_mov_b32 %[t7], s88")
-    return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, FS=FS, RB=RB, TRACE=TRACE)
+    return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, FS=FS, RB=RB, TRACE=TRACE, RES=RES, RES_V=RES_V)
 
 
 def c_function16(name, BM, BN, WGM, WGN, opt=None):
@@ -461,18 +486,31 @@ def c_function16(name, BM, BN, WGM, WGN, opt=None):
     npc = d["AI"] + d["BI"]
     d1sig = ", const u32x2& dma1" if npc > 16 else ""
     d1in = f', "{{v[{RB + 24}:{RB + 25}]}}"(dma1)' if npc > 16 else ""
+    ressig = resouts = resins = ""
+    fname = name
+    if d["RES"]: text = '        "s_mov_b32 %[roff], 0\\n\\t"\n' + text
+    if d["RES"]:
+        # the residual-prefetching variant: rres = buffer descriptor of the residual tile, rvoff = this lane's byte offsets of its
+        # first row's two 4-column groups (or out of range), rstride = bytes from one of the lane's rows to the next (8 tile rows);
+        # res0.. = the lane's RES rows of the first column group, then of the second (two dwords per row)
+        nres16 = (4 * d["RES"] + 15) // 16
+        assert 4 * d["RES"] % 16 == 0
+        fname = name + "_res"
+        ressig = ", " + ", ".join(f"u32x16& res{i}" for i in range(nres16)) + ", const u32x2& rvoff, const u32x4& rres, uint32_t rstride"
+        resouts = ", " + ", ".join(f'"={{v[{d["RES_V"] + 16 * i}:{d["RES_V"] + 16 * i + 15}]}}"(res{i})' for i in range(nres16)) + ', [roff] "=&s"(roff)'
+        resins = f', "{{v[{RB + 24}:{RB + 25}]}}"(rvoff), [rres] "s"(rres), [rstride] "s"(rstride)'
     trsig = trouts = ""
     if d["TRACE"]:
         clob += [f'"s{i}"' for i in range(60, 90)]
         trsig = ", uint32_t (&tr)[8]"
         trouts = ", " + ", ".join(f'[t{i}] "=s"(tr[{i}])' for i in range(8))
     return f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  {len(lines)} instructions: tile {BM} x {BN}, waves {WGM} x {WGN}, v_mfma_f32_16x16x32_bf16.
-__device__ __forceinline__ void gemm_asm16_loop_{name}({sig}, const u32x8& rbase, const u32x16& dma0{d1sig},
-        const u32x4& ra, const u32x4& rw, int cnt, uint32_t ak, uint32_t bk, uint32_t ldsw, uint32_t kend{trsig}) {{
-    uint32_t asoff, bsoff;
+__device__ __forceinline__ void gemm_asm16_loop_{fname}({sig}, const u32x8& rbase, const u32x16& dma0{d1sig},
+        const u32x4& ra, const u32x4& rw, int cnt, uint32_t ak, uint32_t bk, uint32_t ldsw, uint32_t kend{trsig}{ressig}) {{
+    uint32_t asoff, bsoff{", roff" if d["RES"] else ""};
     asm volatile(
-{text}        : {outs}, [cnt] "+s"(cnt), [ak] "+s"(ak), [bk] "+s"(bk), [asoff] "=&s"(asoff), [bsoff] "=&s"(bsoff){trouts}
-        : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 8}:{RB + 23}]}}"(dma0){d1in}, [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), [kend] "s"(kend)
+{text}        : {outs}, [cnt] "+s"(cnt), [ak] "+s"(ak), [bk] "+s"(bk), [asoff] "=&s"(asoff), [bsoff] "=&s"(bsoff){trouts}{resouts}
+        : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 8}:{RB + 23}]}}"(dma0){d1in}{resins}, [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), [kend] "s"(kend)
         : {", ".join(clob)});
 }}
 """
@@ -573,6 +611,9 @@ def main():
             f.write("\n")
             f.write(store_functions16(name.replace("x", "_"), BM, BN, WGM, WGN))
             f.write("\n")
+            if name == "160x256" and not int(o16.get("trace", 0)):
+                f.write(c_function16(name.replace("x", "_"), BM, BN, WGM, WGN, dict(o16, res_rows=20)))
+                f.write("\n")
     print("wrote", out, opt)
 
 
