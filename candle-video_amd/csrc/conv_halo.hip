@@ -33,6 +33,16 @@
 #define HALO_ABL 0
 #endif
 
+#ifdef HALO_TRACE         // diagnostic builds (tools/conv_trace.py): per-block stamps on the 100 MHz clock + the shader-clock cycles of the K loop
+__device__ unsigned long long g_halo_trace[16384 * 8];
+extern "C" int ltx_dbg_halo_trace(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_trace), (size_t)n * 8) == hipSuccess ? 0 : -1; }
+#define HSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_halo_trace[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define HCYC(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_halo_trace[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#define HCYC(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;
@@ -73,6 +83,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
     static_assert(!PIPE || (NL == 4 && BN == 128), "pipelined form: four loader waves, 128-wide tile");
     unsigned char* Abuf = halo_smem;
     unsigned char* Bbuf = halo_smem + 2 * A_ST;
+    HSTAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
@@ -228,6 +239,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
         issue_b_p(0, 0); issue_b_p(0, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        HSTAMP(1); HCYC(5);
         read_frags(0, 0, 0, w0, a0);
         if (HALO_PABL & 4) { read_frags(0, 0, 1, w1, a1); frags_once = true; }
         auto step_p = [&](int grp, auto hw_tag) {
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             step_p(grp, std::integral_constant<int, 3>{}); step_p(grp, std::integral_constant<int, 4>{}); step_p(grp, std::integral_constant<int, 5>{});
             step_p(grp, std::integral_constant<int, 6>{}); step_p(grp, std::integral_constant<int, 7>{}); step_p(grp, std::integral_constant<int, 8>{});
         }
+        HCYC(6); HSTAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy pieces of the last steps
         __syncthreads();
     } else {
@@ -452,6 +465,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             // a thread's chunk column is the same in every iteration (NTHR % CPR == 0): its modulation values load once
             float pn_sc[8], pn_sh[8];
             bool pn_mod = false;
+            // (round 5, measured and removed: the residual epilogue writing a second, normalised copy of its rows - the next resnet's
+            // norm1 - cost the conv class +2.5 ms per C2 video for the 2.7 ms of norm passes it replaced: a tile's epilogue is not
+            // overlapped with anything, so work moved into it is paid in full; profiles/r5g_vae_norm1_in_conv2_epilogue_ab.jsonl)
             if constexpr (EPI == EPI_BIAS) {
                 if (g.pn_on && g.pn_scale) {
                     pn_mod = true;
@@ -489,6 +505,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
                 if (!inside) continue;
                 *reinterpret_cast<u32x4*>(Cb + (int64_t)m * g.ldc + n0 + c * 8) = cc.u;
             }
+#ifdef HALO_TRACE
+            HSTAMP(3); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); HSTAMP(4);
+            if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_halo_trace[blockIdx.x * 8 + 7] = hw; }
+#endif
             return;
         }
     }

@@ -11,6 +11,7 @@
 //     accumulator values a lane owns are contiguous in the destination).
 // The packed token layout the denoise loop carries ([B, F*H*W, 128]) IS channels-last, so
 // unpack_latents is free on this path.
+#include <cstring>
 #include <deque>
 #include "model_util.h"
 #include "options.h"
@@ -38,6 +39,10 @@ struct ltx_vae {
     std::vector<void*> owned;
     DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats, predec;
     std::deque<DevBuf> tilebufs;   // deque: growing it must not move DevBufs that Tile.buf points at
+    // CombinedTimestepEmbedder outputs (+ scale_shift_table) per (table, timestep vector, stream): functions of the weights and the
+    // timestep alone (a pipeline decodes every video at the same decode_timestep), 5 launches per resnet when recomputed
+    struct ModEntry { const void* sst = nullptr; float t[LTX_MAX_BATCH] = {0}; int n = 0; hipStream_t stream = nullptr; uint64_t used = 0; DevBuf buf; };
+    std::deque<ModEntry> mods; uint64_t mod_clock = 0;
     size_t act_bytes_reserved() const { return X.bytes + Y.bytes + N.bytes + C.bytes; }   // activation buffers a decoder call re-uses
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
@@ -45,6 +50,8 @@ struct ltx_vae {
         DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats, &predec};
         for (DevBuf* b : bs) b->release();
         for (auto& b : tilebufs) b.release();
+        for (auto& e : mods) e.buf.release();
+        mods.clear();
     }
 };
 
@@ -272,21 +279,33 @@ int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, i
     return LTX_OK;
 }
 
-// CombinedTimestepEmbedder (vae.rs:236-265) + "+ scale_shift_table" -> f32 [B][rows][C]
-int time_mod(ltx_vae* v, const TimeEmbW& te, const void* sst, const TimeVec& tv, float* out, hipStream_t s) {
+// CombinedTimestepEmbedder (vae.rs:236-265) + "+ scale_shift_table" -> f32 [B][rows][C]; *out points at the (cached) result
+int time_mod(ltx_vae* v, const TimeEmbW& te, const void* sst, const TimeVec& tv, const float** out, hipStream_t s) {
     const int dt = v->dtype; const int B = tv.n;
-    LTX_TRY(ltx_launch_sinusoid(v->tproj.p, dt, tv, v->vtab, 128, dt == LTX_DT_BF16, v->has_tsm ? v->tsm : 1.0f, s));
-    LTX_TRY(ltx_linear(te.l1, v->tproj.p, 256, v->e1.p, te.dim, B, dt, EPI_BIAS, s));
-    LTX_TRY(ltx_launch_silu(v->e1.p, v->e1.p, (int64_t)B * te.dim, dt, s));
-    LTX_TRY(ltx_linear(te.l2, v->e1.p, te.dim, v->te.p, te.dim, B, dt, EPI_BIAS, s));
-    LTX_TRY(ltx_launch_ada(out, sst, v->te.p, 1, B, te.dim, dt, s));
+    ltx_vae::ModEntry* e = nullptr;
+    for (auto& c : v->mods) if (c.sst == sst && c.n == B && c.stream == s && !memcmp(c.t, tv.t, sizeof(float) * B)) e = &c;
+    if (!e) {
+        constexpr size_t kMax = 256;                       // entries (a decoder has ~21 tables; tiled decodes add leaf-batch sizes)
+        if (v->mods.size() < kMax) { v->mods.emplace_back(); e = &v->mods.back(); }
+        else { e = &v->mods.front(); for (auto& c : v->mods) if (c.used < e->used) e = &c; }
+        e->sst = nullptr;
+        LTX_TRY(e->buf.ensure((size_t)B * te.dim * sizeof(float)));
+        LTX_TRY(ltx_launch_sinusoid(v->tproj.p, dt, tv, v->vtab, 128, dt == LTX_DT_BF16, v->has_tsm ? v->tsm : 1.0f, s));
+        LTX_TRY(ltx_linear(te.l1, v->tproj.p, 256, v->e1.p, te.dim, B, dt, EPI_BIAS, s));
+        LTX_TRY(ltx_launch_silu(v->e1.p, v->e1.p, (int64_t)B * te.dim, dt, s));
+        LTX_TRY(ltx_linear(te.l2, v->e1.p, te.dim, v->te.p, te.dim, B, dt, EPI_BIAS, s));
+        LTX_TRY(ltx_launch_ada(e->buf.as<float>(), sst, v->te.p, 1, B, te.dim, dt, s));
+        e->sst = sst; e->n = B; e->stream = s; memcpy(e->t, tv.t, sizeof(float) * B);
+    }
+    e->used = ++v->mod_clock;
+    *out = e->buf.as<float>();
     return LTX_OK;
 }
 
 int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims& d, const TimeVec* tv, hipStream_t s) {
     const int dt = v->dtype;
     const float* mod = nullptr;
-    if (tv && r.sst) { LTX_TRY(time_mod(v, te, r.sst, *tv, v->mod.as<float>(), s)); mod = v->mod.as<float>(); }
+    if (tv && r.sst) LTX_TRY(time_mod(v, te, r.sst, *tv, &mod, s));
     RowNormArgs rn; rn.x = v->X.p; rn.y = v->N.p; rn.rows = d.vox(); rn.D = ch; rn.ldx = ch; rn.ldy = ch;
     rn.kind = 0; rn.eps = 1e-8f; rn.act = 1; rn.rows_per_batch = (int64_t)d.T * d.H * d.W; rn.mod_stride = 4 * ch;
     if (mod) { rn.shift = mod; rn.scale = mod + ch; }
@@ -337,7 +356,7 @@ int decoder_forward(ltx_vae* v, const void* z, int B, int F, int H, int W, const
     // norm_out + global scale/shift + SiLU (vae.rs:1687-1723), conv_out + unpatchify
     const int ch = v->last_ch;
     const float* mod = nullptr;
-    if (tvc && v->sst_out) { LTX_TRY(time_mod(v, v->out_te, v->sst_out, *tvc, v->mod.as<float>(), s)); mod = v->mod.as<float>(); }
+    if (tvc && v->sst_out) LTX_TRY(time_mod(v, v->out_te, v->sst_out, *tvc, &mod, s));
     RowNormArgs rn; rn.x = v->X.p; rn.y = v->N.p; rn.rows = d.vox(); rn.D = ch; rn.ldx = ch; rn.ldy = ch;
     rn.kind = 0; rn.eps = 1e-8f; rn.act = 1; rn.rows_per_batch = (int64_t)d.T * d.H * d.W; rn.mod_stride = 2 * ch;
     if (mod) { rn.shift = mod; rn.scale = mod + ch; }

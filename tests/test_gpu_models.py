@@ -109,12 +109,14 @@ def _vae(hip, dt, seed=7):
     return cfg, w, model
 
 
-def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch):
+@pytest.mark.parametrize("blocks,layers,bar", [((256, 512), (1, 1, 1), 5e-3), ((128, 256), (3, 2, 2), 1e-2)])
+def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch, blocks, layers, bar):
     """Where one conv tile spans all channels (128 / 256-channel stages, >= 1024 voxels) the resnet's norm2 + modulation +
-    SiLU runs inside conv1's wide epilogue.  A decoder with 512 / 256 / 128-channel stages: fused vs the separate norm
-    pass (option vae_fuse_norm=0) agree to bf16 rounding of the row statistics' summation order, with and without timestep
+    SiLU runs inside conv1's wide epilogue.  Decoders with 512 / 256 / 128-channel stages (one resnet per stage, and a deeper
+    one with seven): fused vs the separate norm pass (option vae_fuse_norm=0) agree to bf16 rounding of the row statistics'
+    summation order (the bar grows with the number of resnets the difference passes through), with and without timestep
     conditioning, and both stay within the bf16 bar of the f32-mode decode."""
-    cfgd = dict(latent_channels=16, decoder_block_out_channels=(256, 512), decoder_layers_per_block=(1, 1, 1))
+    cfgd = dict(latent_channels=16, decoder_block_out_channels=blocks, decoder_layers_per_block=layers)
     cfg = O.VaeConfig(**cfgd)
     w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=11)
     wd = {"decoder." + k: v.to(DEV) for k, v in w.items()}
@@ -130,8 +132,8 @@ def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch):
             with hip.options(vae_fuse_norm="0"):
                 sep = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
                 sep_no_t = model.decode(z.to(DEV), None).float().cpu()
-            assert rel_l2(outs[dt], sep) <= 5e-3, rel_l2(outs[dt], sep)
-            assert rel_l2(no_t, sep_no_t) <= 5e-3
+            assert rel_l2(outs[dt], sep) <= bar, rel_l2(outs[dt], sep)
+            assert rel_l2(no_t, sep_no_t) <= bar
         del model
     assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) <= 3e-2
 
