@@ -37,7 +37,7 @@ def build(name, opts):
         d = os.path.join(PKG, "build", sub)
         objs += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".o") and not f.startswith("attn_q64")]
     out = os.path.join(VAR, f"libltxhip_{name}.so")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [obj, "-lz"], check=True)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [obj, "-lz", "-ldl"], check=True)
     print("built", out)
 
 
@@ -59,19 +59,18 @@ def measure():
     us = t_us(4992, 4992, 40)
     res["c2_us"] = round(us, 1); res["c2_TF"] = round(4 * heads * 4992 * 4992 * 64 / us / 1e6, 1)
     for kind, env, rounds in (("big", None, 2), ("small", "0", 4)):
-        if env is not None: os.environ["LTX_ATTN_Q64_BIG"] = env
-        else: os.environ["LTX_ATTN_Q64_BIG"] = "16"
+        ltxhip.set_option("attn_q64_big", env if env is not None else "16")
         a, b = t_us(4096, 1024), t_us(4096, 4096)
         it = (b - a) / (48 * rounds)
         res[f"{kind}_it"] = round(it, 4); res[f"{kind}_fix"] = round(a / rounds - 16 * it, 2)
-        os.environ.pop("LTX_ATTN_Q64_BIG")
+        ltxhip.set_option("attn_q64_big", None)
     # in-kernel stamps of the last launch (diagnostic builds): cycles per key tile and the clock inside the loop
     import ctypes
     lib = ctypes.CDLL(os.environ.get("LTXHIP_LIB") or os.path.join(PKG, "libltxhip.so"))
     if hasattr(lib, "ltx_dbg_q64_stamps"):
         import numpy as np
         for kind, env in (("big", "16"), ("small", "0")):
-            os.environ["LTX_ATTN_Q64_BIG"] = env
+            ltxhip.set_option("attn_q64_big", env)
             t_us(4096, 4096, 3)
             buf = (ctypes.c_ulonglong * (8 * 512))()
             lib.ltx_dbg_q64_stamps(buf, 8 * 512)
@@ -84,7 +83,7 @@ def measure():
             w6, w7 = raw[:, 6], raw[:, 7]
             parts = [w6 >> np.uint64(48), (w6 >> np.uint64(32)) & np.uint64(0xffff), (w6 >> np.uint64(16)) & np.uint64(0xffff), w6 & np.uint64(0xffff), w7 >> np.uint64(32), w7 & np.uint64(0xffffffff)]
             res[f"{kind}_pro_parts"] = [int(np.median(x)) for x in parts]   # C++ setup | issue Q+DMA | wait vmcnt | barrier | S0,max,sub,K1 | exp slice
-        os.environ.pop("LTX_ATTN_Q64_BIG")
+        ltxhip.set_option("attn_q64_big", None)
     print(json.dumps(res), flush=True)
 
 

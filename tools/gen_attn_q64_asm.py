@@ -34,7 +34,7 @@ KROW = VROW = 128
 VBASE = 64 * KROW
 
 
-DEFAULTS = dict(align=1, phase=0, abl="", cvt_lag=1, v_early=1, stamp=0, v_gaps="", k_gaps="", dma_gaps="", row_gaps="", v_gaps1="", k_gaps1="", dma_gaps1="", row_gaps1="")
+DEFAULTS = dict(align=1, phase=0, abl="", cvt_lag=1, v_early=1, stamp=0, split_wait=0, v_gaps="", k_gaps="", dma_gaps="", row_gaps="", v_gaps1="", k_gaps1="", dma_gaps1="", row_gaps1="")
 
 
 def gen(QB, opt=None, full=False, part=False):
@@ -198,7 +198,13 @@ def gen(QB, opt=None, full=False, part=False):
         # on the exposed path of every block): 72 independent writes, no result changes
         for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
         for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
-        emit("s_waitcnt vmcnt(8)")                           # Q^T and tiles 0, 1 landed; tiles 2, 3 stay in flight
+        # round 5 experiment (split_wait=1, not the default): S^T(0) needs Q^T and K(0) only - 40 of the block's first 96 KB - so the
+        # first wait would cover those (the loads return in order: Q, K(0), V(0), K(1), ...) and V(0), K(1), V(1) land under the first
+        # sixteen MFMAs.  Measured on MI355X, same box, alternating fresh processes: 183.9 / 184.1 us per C2 launch against 183.4 / 183.4,
+        # per-block constant 5.72 / 5.61 against 5.51 / 5.59 us (profiles/r5_attn_split_wait_ab.json): the prologue is bound by the
+        # burst's bandwidth, not by what the first wait covers
+        split = int(o_["split_wait"])
+        emit("s_waitcnt vmcnt(14)" if split else "s_waitcnt vmcnt(8)")   # Q^T and K(0) [split] / Q^T and tiles 0, 1 landed; the rest stays in flight
         if int(o_["stamp"]): emit("s_memtime %[sa2]")
         emit("s_barrier")
         if int(o_["stamp"]): emit("s_memtime %[sa3]")
@@ -210,6 +216,9 @@ def gen(QB, opt=None, full=False, part=False):
                 kb, ks = i >> 2, i & 3
                 d = vr(S(0, qb, kb), 16)
                 emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {'0' if ks == 0 else d}")
+        if split:
+            emit("s_waitcnt vmcnt(8)")                       # V(0), K(1), V(1) of this wave landed; the barrier makes that true of every wave's pieces
+            emit("s_barrier")
         for i in range(8):                                   # K(1) fragments (the MFMAs above have read theirs long before these land)
             emit(f"ds_read_b128 {ar(KF(i), 4)}, v{208 + (i & 3)} offset:{TILE + (i >> 2) * 32 * KROW}")
         for qb in range(QB):                                 # row maxima: 32 scores in the lane, then the other lane half
