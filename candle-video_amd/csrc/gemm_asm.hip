@@ -460,6 +460,179 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #endif
 }
 
+// ---- conv mode of the 16x16x32 loop (round 5): 3x3x3 conv3d as an implicit GEMM with the activation rows re-staged per tap, tile
+// 256 x 256 - the VAE's 1024-channel mid block (M = 4992 voxels x N = 1024 x K = 27 x 1024: 80 tiles, cut into the shape rule's three
+// K ranges = one frame tap each), conv_in and the first upsampler.  Same K-step order (frame tap, 64-channel slice, in-plane tap),
+// same K partition and canonical sum of the parts as gemm_big's conv mode: bit-identical to it (tests/test_gpu_gemm_asm.py).
+// gemm_big's 16-wave 256 x 256 tile ran these at 0.38 of the MFMA peak (profiles/r4zf_*: 300 us per mid-block conv).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_asm16_conv_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, WGN = 2, WM = 128, WN = 128, NB = 8, AI = 8, BI = 8, STAGE = (BM + BN) * 128, RP = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, q = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int ntn = (g.N + BN - 1) / BN;
+    const int sf = g.sk_sf > 1 ? g.sk_sf : 1;
+    const int tile = (int)blockIdx.x / sf, part = (int)blockIdx.x - tile * sf;      // the parts of a tile are neighbours in the grid
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int KC = g.Cin / 64, nk = g.ntaps * KC;
+    const int kt0 = (int)((int64_t)part * nk / sf), kt1 = (int)((int64_t)(part + 1) * nk / sf);
+    // fetch state of the first K-step of the range
+    const int per_it = 9 * KC, it0 = kt0 / per_it, r2 = kt0 - it0 * per_it, kc0 = r2 / 9, hw0 = r2 - kc0 * 9, ih0 = hw0 / 3, iw0 = hw0 - ih0 * 3;
+    // the descriptor is based a little before the tile's first voxel (gemm_big.hip): every tap of every row lies at a non-negative
+    // 32-bit offset whatever the size of the tensor
+    const int64_t m_base = m0 > 2 * g.H * g.Wd + g.Wd + 1 ? (int64_t)m0 - (2 * g.H * g.Wd + g.Wd + 1) : 0;
+    const int lr = lane >> 3, pc = lane & 7;
+    const uint32_t frame_bytes = (uint32_t)g.H * (uint32_t)g.Wd * (uint32_t)g.Cin * 2u;
+    u32x16 dma0; u32x8 ab[3], vmask;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = 8 * (j * 4 + wave) + lr;
+        int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
+        const int w = m % g.Wd, t1 = m / g.Wd, h = t1 % g.H, t = (t1 / g.H) % g.T;
+        vmask[j] = (uint32_t)((h > 0 ? 1 : 0) | 2 | (h < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0));
+        const uint32_t a_off = ((uint32_t)(m - m_base) * (uint32_t)g.Cin + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                      // frame taps it0, it0 + 1, it0 + 2 (the last ones unused past the third)
+            int tt = t + (it0 + i) - g.pad_t; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);      // replicate pad on T (vae.rs:374-413)
+            ab[i][j] = a_off + (uint32_t)(tt - t) * frame_bytes;
+        }
+        dma0[j] = 0x80000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = 8 * (j * 4 + wave) + lr;
+        int n = n0 + row; if (n > g.N - 1) n = g.N - 1;
+        dma0[AI + j] = ((uint32_t)n * (uint32_t)g.K + (uint32_t)(pc ^ ((row >> 1) & 7)) * 8u) * 2u;
+    }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)asm_smem;
+    u32x8 rbase;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const uint32_t ch = (uint32_t)(((4 * kh + q) ^ ((rr >> 1) & 7)) << 4);
+            rbase[st * 2 + kh] = smem_base + st * STAGE + BM * 128 + (wn * WN + rr) * 128 + ch;
+            rbase[4 + st * 2 + kh] = smem_base + st * STAGE + (wm * WM + rr) * 128 + ch;
+        }
+    const uint64_t ap = (uint64_t)(uintptr_t)(reinterpret_cast<const bf16_t*>(g.A) + m_base * g.Cin), wp = (uint64_t)(uintptr_t)g.W;
+    const u32x4 ra = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ap), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ap >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
+    const u32x4 rw = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp >> 32)) & 0xffffu, 0x80000000u, 0x00020000u};
+    const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 1024u));
+    const uint32_t cinb = (uint32_t)g.Cin * 2u, rowb = (uint32_t)g.Wd * cinb, nk2 = (uint32_t)g.N * (uint32_t)g.K * 2u;
+    auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    f32x32 c[10];
+    gemm_asm16_conv_loop_256_256(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], rbase, dma0, ab[0], ab[1], ab[2], vmask, ra, rw,
+                                 __builtin_amdgcn_readfirstlane(kt1 - kt0), ldsw,
+                                 sgpr((uint32_t)iw0), sgpr((uint32_t)ih0), sgpr((uint32_t)kc0), sgpr((uint32_t)((ih0 - 1) * g.Wd + (iw0 - 1)) * cinb), sgpr((uint32_t)kc0 * 128u),
+                                 sgpr(((uint32_t)(it0 * 9 + hw0) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kc0 * 64u) * 2u),
+                                 sgpr(cinb), sgpr(nk2), sgpr(rowb - 3u * cinb), sgpr(0u - 3u * rowb), sgpr(128u - 9u * nk2), sgpr(9u * nk2 - (uint32_t)KC * 128u), sgpr((uint32_t)KC));
+
+    // Epilogue: the f32 accumulators pass through LDS in two row passes of 128 tile rows (as in the linear kernel); every thread
+    // then owns two 4-column groups of its rows and hands them to the shared epilogue() - the arithmetic of every other conv kernel.
+    // A split tile's parts leave their f32 rows in slabs; the part that draws the last ticket adds them in part order (the canonical
+    // sum of gemm_big.hip) and finishes.
+    const int r0 = tid >> 5, cg = tid & 31;
+    const int nA = n0 + 4 * cg, nB = nA + 128;
+    u32x8 ad;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+        const int chunk = (wn * WN + (nb < NB ? nb : 0) * 16 + 4 * q) >> 2;
+        ad[nb] = smem_base + (uint32_t)(rr * 1024 + ((chunk ^ rr) << 4));
+    }
+    float* slab = sf > 1 ? g.sk_ws + ((int64_t)tile * sf + part) * (BM * BN) : nullptr;
+#pragma unroll
+    for (int p = 0; p < BM / RP; ++p) {
+        __syncthreads();
+        AsmLoop16<256, 256, 2, 2>::store(p, wm, c, ad);
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < RP / 8; ++k) {
+            const int row = r0 + 8 * k, trow = p * RP + row, m = m0 + trow;
+            const unsigned char* rowp = asm_smem + row * 1024;
+            f32x4 vA = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
+            f32x4 vB = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
+            if (sf > 1) {
+                *reinterpret_cast<f32x4*>(slab + trow * BN + 4 * cg) = vA;
+                *reinterpret_cast<f32x4*>(slab + trow * BN + 128 + 4 * cg) = vB;
+            } else if (m < g.M) {
+                float a4[4] = {vA[0], vA[1], vA[2], vA[3]}, b4[4] = {vB[0], vB[1], vB[2], vB[3]};
+                if (nA < g.N) epilogue<bf16_t, EPI>(g, m, nA, a4);
+                if (nB < g.N) epilogue<bf16_t, EPI>(g, m, nB, b4);
+            }
+        }
+    }
+    if (sf > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(asm_smem);      // all LDS reads are behind the barrier above
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(g.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)sf - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // back at zero for the next launch on this stream
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        const float* base = g.sk_ws + (int64_t)tile * sf * (BM * BN);
+        // four rows per step, every load of the step (the parts' slab rows, the residual groups) issued before the first use: the
+        // reducer works alone on its tile while the other parts' CUs are already idle
+        constexpr int UR = 4;
+#pragma unroll 1
+        for (int k0 = 0; k0 < BM / 8; k0 += UR) {
+            f32x4 vA[UR], vB[UR];
+            bf16x4 qA[UR] = {}, qB[UR] = {};
+#pragma unroll
+            for (int j = 0; j < UR; ++j) {
+                const int trow = r0 + 8 * (k0 + j);
+                int m = m0 + trow; if (m > g.M - 1) m = g.M - 1;
+                const float* rp = base + trow * BN + 4 * cg;
+                vA[j] = *reinterpret_cast<const f32x4*>(rp); vB[j] = *reinterpret_cast<const f32x4*>(rp + 128);
+                if constexpr (EPI == EPI_RESID) {
+                    const bf16_t* rrow = reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m * g.ldr;
+                    if (nA < g.N) qA[j] = *reinterpret_cast<const bf16x4*>(rrow + nA);
+                    if (nB < g.N) qB[j] = *reinterpret_cast<const bf16x4*>(rrow + nB);
+                }
+            }
+            for (int pq = 1; pq < sf; ++pq) {                    // ((s0 + s1) + s2) + ...: the order every plan of the shape uses
+#pragma unroll
+                for (int j = 0; j < UR; ++j) {
+                    const float* rp = base + (int64_t)pq * (BM * BN) + (r0 + 8 * (k0 + j)) * BN + 4 * cg;
+                    vA[j] += *reinterpret_cast<const f32x4*>(rp); vB[j] += *reinterpret_cast<const f32x4*>(rp + 128);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UR; ++j) {
+                const int m = m0 + r0 + 8 * (k0 + j);
+                if (m >= g.M) continue;
+                float a4[4] = {vA[j][0], vA[j][1], vA[j][2], vA[j][3]}, b4[4] = {vB[j][0], vB[j][1], vB[j][2], vB[j][3]};
+                if constexpr (EPI == EPI_D2S) {
+                    if (nA < g.N) epilogue<bf16_t, EPI>(g, m, nA, a4);
+                    if (nB < g.N) epilogue<bf16_t, EPI>(g, m, nB, b4);
+                } else {                                          // epilogue()'s expressions for bias / residual, residual already here
+                    bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc;
+                    if (nA < g.N) {
+                        if (g.bias) { float bb[4]; load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nA, bb); for (int i = 0; i < 4; ++i) a4[i] += bb[i]; }
+                        if constexpr (EPI == EPI_RESID) for (int i = 0; i < 4; ++i) a4[i] += (float)qA[j][i];
+                        store4<bf16_t>(crow + nA, a4);
+                    }
+                    if (nB < g.N) {
+                        if (g.bias) { float bb[4]; load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nB, bb); for (int i = 0; i < 4; ++i) b4[i] += bb[i]; }
+                        if constexpr (EPI == EPI_RESID) for (int i = 0; i < 4; ++i) b4[i] += (float)qB[j][i];
+                        store4<bf16_t>(crow + nB, b4);
+                    }
+                }
+            }
+        }
+    }
+}
+
 struct AsmTile { int bm, bn; const char* name; };
 const AsmTile kAsmTiles[] = {{256, 256, "asm256x256"}, {320, 256, "asm320x256"}, {160, 256, "asm160x256"}};
 
@@ -574,6 +747,36 @@ int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s) {
     ltx_prof_kernel(LTX_PROFK_GEMM_ASM16);
     if (tile == 0) return launch_asm_epi<256, 256, 2, 2, true>(g, epi, s);
     return tile == 1 ? launch_asm_epi<160, 256, 1, 4, true>(g, epi, s) : launch_asm_epi<320, 256, 2, 2, true>(g, epi, s);
+}
+
+// What the conv-mode kernel needs of a call: bf16 3x3x3 conv with whole 64-channel slices, a plain / residual / depth-to-space
+// epilogue (no fused norm, no segmented output), more rows than the small-plane tiles serve, operands the 32-bit offsets reach.
+bool ltx_gemm_asm16_conv_fits(const GemmArgs& g, int epi) {
+    if (!g.conv || g.ntaps != 27 || g.kh != 3 || g.kw != 3 || g.pn_on || g.c_seg_shift || g.rowsq) return false;
+    if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
+    if (g.Cin % 64 != 0 || g.K != g.Cin || g.N % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || ((uintptr_t)g.C & 7)) return false;
+    if (g.bias && ((uintptr_t)g.bias & 7)) return false;
+    if (epi == EPI_RESID && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7) || g.ldc % 4 != 0)) return false;
+    if (epi == EPI_BIAS && g.ldc % 4 != 0) return false;
+    if (epi == EPI_D2S && (g.Cf % 4 != 0 || g.N != 8 * g.Cf)) return false;
+    if ((double)g.N * g.K * 2.0 * 10.0 >= 4294967296.0) return false;          // 9 N K 2 and its differences stay inside 32 bits
+    return g.M > 512 && g.N >= 256 && ltx_gemm_big_fits(g);
+}
+
+int ltx_launch_gemm_asm16_conv(const GemmArgs& g, int epi, hipStream_t s) {
+    if (!ltx_gemm_asm16_conv_fits(g, epi)) LTX_FAIL(LTX_ERR_ARG, "gemm_asm16 (conv): shape not eligible");
+    ltx_prof_kernel(LTX_PROFK_GEMM_ASM16);
+    constexpr int smem = 2 * (256 + 256) * 128;
+    static std::atomic<unsigned long long> devs[3] = {{0}, {0}, {0}};
+    void (*kern)(const GemmArgs) = epi == EPI_BIAS ? gemm_asm16_conv_kernel<EPI_BIAS> : (epi == EPI_RESID ? gemm_asm16_conv_kernel<EPI_RESID> : gemm_asm16_conv_kernel<EPI_D2S>);
+    LTX_TRY(ltx_set_max_dyn_smem(devs[epi == EPI_BIAS ? 0 : (epi == EPI_RESID ? 1 : 2)], reinterpret_cast<const void*>(kern), smem));
+    GemmArgs ga = g;
+    const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
+    LTX_TRY(ltx_gemm_split_workspace(&ga, tiles, 256, 256, s));       // the shape rule's K ranges + slabs / tickets (gemm_big.hip)
+    const int sf = ga.sk_sf > 1 ? ga.sk_sf : 1;
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)(tiles * sf)), dim3(256), smem, s, ga);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
 }
 
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s) {

@@ -631,6 +631,7 @@ namespace {
 constexpr int kPlanP8 = 100;
 constexpr int kPlanHalo = 200;           // + {0: BN=128, 1: BN=256} (conv_halo.hip)
 constexpr int kPlanAsm16 = 300;          // + {0: 256 x 256, 1: 160 x 256, 2: 320 x 256} (gemm_asm.hip, the 16x16x32 one-wave-per-SIMD kernel; linear layers)
+constexpr int kPlanAsm16Conv = 350;      // gemm_asm.hip's loop in conv mode, tile 256 x 256 (3x3x3 convs of many channels: the VAE mid block; split shapes too: it keeps gemm_big's K partition)
 constexpr int kPlanRing = 400;           // + tile index of gemm_ring.hip (small-M linear layers; split shapes too: it keeps gemm_big's K partition)
 struct PlanKey {
     int M, N, K, conv, ntaps, T, H, W;
@@ -643,6 +644,7 @@ std::mutex g_plan_mu;
 // it is used on (a stale or hand-edited plan file, or one saved under other LTX_* settings).
 bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
     if (plan >= kPlanRing) return plan < kPlanRing + ltx_gemm_ring_tiles() && N >= 32 && N % 4 == 0;
+    if (plan == kPlanAsm16Conv) return nk >= 2 && N >= 256 && N % 8 == 0;
     if (plan >= kPlanAsm16) return plan <= kPlanAsm16 + 2 && !split_shape && nk >= 2 && N >= 512 && N % 8 == 0;
     if (plan >= kPlanHalo) return plan <= kPlanHalo + 1 && !split_shape;
     if (plan >= kPlanP8) return plan <= kPlanP8 + 1 && !split_shape && nk >= 2 && N > 64 && !(plan == kPlanP8 && N <= 128);
@@ -652,6 +654,7 @@ bool plan_ok(const GemmArgs& g, int epi, int plan) {
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     if (!plan_shape_ok(plan, g.N, nk, ltx_gemm_split_factor(g) > 1)) return false;
     if (plan >= kPlanRing) return ltx_gemm_ring_fits(g, epi);
+    if (plan == kPlanAsm16Conv) return ltx_gemm_asm16_conv_fits(g, epi);
     if (plan >= kPlanAsm16) return ltx_gemm_asm16_fits(g, epi);
     if (plan >= kPlanHalo) return true;                    // run_plan checks the halo kernel's own eligibility (epilogue-dependent)
     if (plan >= kPlanP8) return ltx_gemm_p8_fits(g);
@@ -662,6 +665,7 @@ bool plan_ok(const GemmArgs& g, int epi, int plan) {
 int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
     if (!plan_ok(g, epi, plan)) plan = ltx_gemm_big_pick_tile(g.M, g.N);
     if (plan >= kPlanRing) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
+    if (plan == kPlanAsm16Conv) return ltx_launch_gemm_asm16_conv(g, epi, s);
     if (plan >= kPlanAsm16) return ltx_launch_gemm_asm16(g, epi, plan - kPlanAsm16, s);
     if (plan >= kPlanHalo) {
         const int bn = plan == kPlanHalo ? 128 : 256;
@@ -695,7 +699,10 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
             if (!plan_ok(g, EPI_BIAS, plan)) continue;
             // a ring tile is built for grids of about one round: skip the ones that would need more than three
             if ((int64_t)cdiv(g.M, ltx_gemm_ring_tile_bm(plan - kPlanRing)) * cdiv(g.N, ltx_gemm_ring_tile_bn(plan - kPlanRing)) * ltx_gemm_split_factor(g) > 768) continue;
-        } else if (plan >= kPlanAsm16 + 3) { plan = kPlanRing - 1; continue; }
+        } else if (plan > kPlanAsm16Conv) { plan = kPlanRing - 1; continue; }
+        else if (plan == kPlanAsm16Conv) {
+            if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
+        } else if (plan >= kPlanAsm16 + 3) { plan = kPlanAsm16Conv - 1; continue; }
         else if (plan >= kPlanAsm16) {
             if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
         } else if (plan >= kPlanHalo + 2) { plan = kPlanAsm16 - 1; continue; }
@@ -746,6 +753,7 @@ PlanKey plan_key(const GemmArgs& g) {
 }
 const char* plan_name(int plan) {
     if (plan >= kPlanRing) return ltx_gemm_ring_tile_name(plan - kPlanRing);
+    if (plan == kPlanAsm16Conv) return "asm16c:256x256";
     if (plan >= kPlanAsm16) return plan == kPlanAsm16 ? "asm16:256x256" : (plan == kPlanAsm16 + 1 ? "asm16:160x256" : "asm16:320x256");
     if (plan >= kPlanHalo) return plan == kPlanHalo ? "halo:128" : "halo:256";
     if (plan >= kPlanP8) return plan == kPlanP8 ? "p8:256" : "p8:128";
@@ -753,6 +761,7 @@ const char* plan_name(int plan) {
 }
 int plan_from_name(const char* n) {
     for (int i = 0; i < ltx_gemm_ring_tiles(); ++i) if (!strcmp(n, ltx_gemm_ring_tile_name(i))) return kPlanRing + i;
+    if (!strcmp(n, "asm16c:256x256")) return kPlanAsm16Conv;
     if (!strcmp(n, "asm16:256x256")) return kPlanAsm16; if (!strcmp(n, "asm16:160x256")) return kPlanAsm16 + 1; if (!strcmp(n, "asm16:320x256")) return kPlanAsm16 + 2;
     if (!strcmp(n, "halo:128")) return kPlanHalo; if (!strcmp(n, "halo:256")) return kPlanHalo + 1;
     if (!strcmp(n, "p8:256")) return kPlanP8; if (!strcmp(n, "p8:128")) return kPlanP8 + 1;
@@ -806,7 +815,7 @@ extern "C" int ltx_plan_load(const char* path) {
             GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = key.conv; g.ntaps = key.conv ? key.ntaps : 1;
             const int nk = (key.K + 63) / 64 * g.ntaps;
             const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && (!key.conv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0));
-            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && (key.conv || key.K % 8 || key.M > 2048)) || (plan >= kPlanAsm16 && plan < kPlanRing && (key.conv || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
+            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && (key.conv || key.K % 8 || key.M > 2048)) || (plan == kPlanAsm16Conv && (!key.conv || key.ntaps != 27 || key.K % 64)) || (plan >= kPlanAsm16 && plan < kPlanAsm16Conv && (key.conv || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
                 fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: plan not valid for its shape: ") + line);
             }
         }
@@ -838,16 +847,18 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
             bool ok = plan_ok(g, epi, forced);
             if (forced >= kPlanHalo && forced < kPlanAsm16) ok = ok && g.conv && ltx_conv_halo_eligible(g, epi, forced == kPlanHalo ? 128 : 256);
             if (forced >= kPlanP8 && forced < kPlanHalo) ok = ok && nk >= 2;
-            if (split_shape && forced < kPlanRing) ok = false;      // split shapes: gemm_big tiles or ring tiles (one K partition whatever the plan)
+            if (split_shape && forced < kPlanRing && forced != kPlanAsm16Conv) ok = false;      // split shapes: gemm_big tiles, ring tiles or the conv-mode asm16 tile (one K partition whatever the plan)
             if (!ok) forced = -1;
         }
     }
     const bool big_forced = forced >= 0 && forced < kNumTiles;
     if (forced >= kPlanRing) return ltx_launch_gemm_ring(g, epi, forced - kPlanRing, s);
+    if (forced == kPlanAsm16Conv) return ltx_launch_gemm_asm16_conv(g, epi, s);
     if (split_shape) {                                     // gemm_big tiles (or gemm_ring's, which keep their K partition): one partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
         if (!big_forced) (void)cached_or_tuned_plan(g, s, &plan);
         if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
+        if (plan == kPlanAsm16Conv && plan_ok(g, epi, plan)) return ltx_launch_gemm_asm16_conv(g, epi, s);
         if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)
         return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
     }

@@ -84,6 +84,8 @@ bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi);
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s);
 bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi);                       // the 16x16x32 one-wave-per-SIMD kernel (plan family asm16:*)
 int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s);
+bool ltx_gemm_asm16_conv_fits(const GemmArgs& g, int epi);                  // the same loop in conv mode (3x3x3, tile 256 x 256; plan "asm16c:256x256")
+int ltx_launch_gemm_asm16_conv(const GemmArgs& g, int epi, hipStream_t s);
 int ltx_gemm_asm_pick_tile(int M, int N);
 const char* ltx_gemm_asm_tile_name(int i);
 int ltx_gemm_big_pick_tile(int M, int N);   // index into gemm_big.hip's tile table

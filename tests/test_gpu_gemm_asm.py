@@ -80,3 +80,56 @@ def test_asm16_gate_residual_and_segmented_output_bit_identical(hip, tile):
     for got in (wide, narrow):
         for a, r in zip(got, ref):
             assert torch.equal(a.view(torch.int16), r.view(torch.int16))
+
+
+def _cl(x): return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,causal,what", [
+    (1, 13, 16, 24, 1024, 1024, False, "the VAE mid block at C2's latent size: the shape rule cuts K into three ranges = one frame tap each"),
+    (1, 5, 33, 48, 128, 1152, False, "unsplit, ragged in M (30.9 tiles) and N (4.5 tiles)"),
+    (2, 3, 20, 20, 192, 512, True, "batch of two, causal padding, eight K ranges that start inside a frame tap and inside a channel slice"),
+    (1, 4, 9, 31, 64, 256, False, "one 64-channel slice, planes narrower than a tile row"),
+])
+def test_asm16_conv_mode_bit_identical_to_gemm_big(hip, B, T, H, W, Cin, Cout, causal, what):
+    """gemm_asm16_conv_kernel (the generated loop in conv mode: A rows re-staged per tap, validity masks and tap offsets rebuilt per
+    K-step, the fetch position carried in scalars) against gemm_big's conv mode: same K order, same K partition, same canonical sum
+    of the parts - the same bits, with a bias, with a residual, and (depth-to-space) on the upsampler; and within the bf16 bar of
+    f32 torch."""
+    g = torch.Generator().manual_seed(B + T + H + W + Cin)
+    x = torch.randn(B, Cin, T, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).bfloat16(); b = torch.randn(Cout, generator=g).bfloat16()
+    r = torch.randn(B, Cout, T, H, W, generator=g).bfloat16()
+    xc, rc = _cl(x).cuda(), _cl(r).cuda()
+    def run():
+        return hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal), hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc)
+    with hip.options(gemm_tune="0", gemm_off="asm16+halo+p8"):
+        ref = run()
+    hip.prof_enable(True)
+    with hip.options(gemm_plan="asm16c:256x256"):
+        got = run()
+    _, _, cnt = hip.prof_report_kernel(1, hip.PROF_KERNELS.index("gemm_asm16_kernel"))
+    hip.prof_enable(False)
+    assert cnt == 2, "the forced conv-mode plan did not serve the launches"
+    for a, c in zip(got, ref):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16)), what
+    pad = (0, 0, 0, 0, 2, 0) if causal else (0, 0, 0, 0, 1, 1)
+    xp = torch.nn.functional.pad(x.float(), pad, mode="replicate")
+    want = torch.nn.functional.conv3d(xp, w.float(), b.float(), padding=(0, 1, 1))
+    e = float((got[0].float().cpu().permute(0, 4, 1, 2, 3) - want).norm() / want.norm())
+    assert e < 4e-3, (what, e)
+
+
+def test_asm16_conv_mode_depth_to_space_epilogue(hip):
+    """The upsampler's conv (vae.rs:1090-1169: 8 x channels, depth-to-space, residual) on the conv-mode loop vs gemm_big."""
+    g = torch.Generator().manual_seed(11)
+    B, T, H, W, Cin = 1, 3, 20, 19, 128
+    x = torch.randn(B, Cin, T, H, W, generator=g).bfloat16()
+    w = (torch.randn(8 * Cin, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).bfloat16(); b = torch.randn(8 * Cin, generator=g).bfloat16()
+    xc = _cl(x).cuda()
+    with hip.options(gemm_tune="0", gemm_off="asm16+halo+p8"):
+        ref = hip.ops.upsample3d(xc, w.cuda(), b.cuda())
+    with hip.options(gemm_plan="asm16c:256x256"):
+        got = hip.ops.upsample3d(xc, w.cuda(), b.cuda())
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))

@@ -296,6 +296,48 @@ def gen16(BM, BN, WGM, WGN, opt=None):
     PGR = int(opt.get("pgr", 2))
     TRACE = int(opt.get("trace", 0)) and PGR == 2          # s_memtime stamps summed per segment of the K-step (tools/gemm_asm_tune.py trace)
     npieces = AI + BI
+    # ---- conv mode (conv=1; round 5): the A operand of a 3x3x3 conv3d as an implicit GEMM with the activation rows re-staged per tap
+    # (gemm_big's conv mode), K-steps in the canonical order of every bf16 conv kernel here - frame tap `it`, 64-channel slice `kc`,
+    # in-plane tap (ih, iw).  Per K-step the A pieces' lane offsets are rebuilt: offset = abase[it][piece] + kc * 128 + tap delta
+    # (32-bit wrap: the delta may be negative) where the tap's voxel lies inside the plane (6 validity bits per piece), else out of
+    # range (zeros: the H / W zero padding); the temporal replicate padding is inside abase (one set per frame tap).
+    # Registers: v[RB+24 : RB+32) abase of the CURRENT frame tap, [RB+32 : RB+40) / [RB+40 : RB+48) of the next two; v[RB+48 : RB+56)
+    # validity masks; v[RB+56], v[RB+57] temporaries.  The fetch state (iw, ih, kc, running offsets) lives in SGPR operands and is
+    # advanced once per K-step without branches, except the copy of the abase sets when `it` changes (twice per tile at most).
+    CONV = int(opt.get("conv", 0))
+    if CONV: assert PGR == 2 and not TRACE and AI == 8 and RB + 59 <= 256
+    CUR, NXT, NX2, VMK, VT0, VT1, VOOB = RB + 24, RB + 32, RB + 40, RB + 48, RB + 56, RB + 57, RB + 58      # VOOB: 0x80000000 (a literal and VCC cannot share an instruction's constant bus)
+
+    def conv_scalars():
+        """top of a fetch: the wave-uniform parts of the step being fetched (state = that step)"""
+        return ["s_add_u32 %[t0], %[kcoff], %[tapd]",                      # lane-offset addend of the A rows: slice + tap delta
+                "s_lshl_b32 %[t1], 1, %[ih]", "s_lshl_b32 %[t2], 8, %[iw]", "s_or_b32 %[vbit], %[t1], %[t2]",
+                "s_cmp_le_u32 %[cnt], %[livemin]",
+                "s_cselect_b32 %[asoff], 0x80000000, 0",
+                "s_cselect_b32 %[bsoff], 0x80000000, %[bso]"]
+
+    def conv_offsets():
+        """the AI A-piece offsets of the step being fetched: 4 VALU per piece, returned as AI groups"""
+        out = []
+        for j in range(AI):
+            out.append([f"v_add_u32_e32 v{VT0}, %[t0], v{CUR + j}",
+                        f"v_and_b32_e32 v{VT1}, %[vbit], v{VMK + j}",
+                        f"v_cmp_eq_u32_e32 vcc, %[vbit], v{VT1}",
+                        f"v_cndmask_b32_e32 v{RB + 8 + j}, v{VOOB}, v{VT0}, vcc"])
+        return out
+
+    def conv_advance():
+        """state of the NEXT step to fetch (three chunks of SALU, then the rare copy of the abase sets)"""
+        c1 = ["s_add_u32 %[iw], %[iw], 1", "s_add_u32 %[tapd], %[tapd], %[cinb]", "s_add_u32 %[bso], %[bso], %[nk2]",
+              "s_cmp_eq_u32 %[iw], 3", "s_cselect_b32 %[iw], 0, %[iw]", "s_cselect_b32 %[t1], %[fixw], 0", "s_cselect_b32 %[t2], 1, 0",
+              "s_add_u32 %[tapd], %[tapd], %[t1]", "s_add_u32 %[ih], %[ih], %[t2]"]
+        c2 = ["s_cmp_eq_u32 %[ih], 3", "s_cselect_b32 %[ih], 0, %[ih]", "s_cselect_b32 %[t1], %[fixh], 0", "s_cselect_b32 %[t2], %[fixkc], 0",
+              "s_cselect_b32 %[t3], 128, 0", "s_cselect_b32 %[t4], 1, 0",
+              "s_add_u32 %[tapd], %[tapd], %[t1]", "s_add_u32 %[bso], %[bso], %[t2]", "s_add_u32 %[kcoff], %[kcoff], %[t3]", "s_add_u32 %[kc], %[kc], %[t4]"]
+        c3 = ["s_cmp_eq_u32 %[kc], %[nkc]", "s_cselect_b32 %[kc], 0, %[kc]", "s_cselect_b32 %[kcoff], 0, %[kcoff]", "s_cselect_b32 %[t1], %[fixit], 0",
+              "s_cselect_b32 %[t2], 1, 0", "s_add_u32 %[bso], %[bso], %[t1]", "s_cmp_eq_u32 %[t2], 1", "s_cbranch_scc0 7f"]
+        c3 += [f"v_mov_b32_e32 v{CUR + j}, v{NXT + j}" for j in range(AI)] + [f"v_mov_b32_e32 v{NXT + j}, v{NX2 + j}" for j in range(AI)] + ["7:"]
+        return c1, c2, c3
 
     def kstep(stage):
         """pgr = 1: the DMA pieces of K-step t+1 go into the other stage during the first half, vmcnt(0) + barrier in the
@@ -345,9 +387,12 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         stalled the issue (s_memtime trace: 1056 cycles for a 592-cycle segment).  K-step t+1 (issued during t-1) is waited
         for with a COUNTED vmcnt late in the second half: a piece has more than a K-step to land."""
         g_rd = int(opt.get("rd_gaps", 1))                  # a fragment read every g_rd gaps
-        emit("s_cmp_le_u32 %[cnt], 2")
-        emit("s_cselect_b32 %[asoff], 0x80000000, %[ak]")
-        emit("s_cselect_b32 %[bsoff], 0x80000000, %[bk]")
+        if CONV:
+            for ins in conv_scalars(): emit(ins)
+        else:
+            emit("s_cmp_le_u32 %[cnt], 2")
+            emit("s_cselect_b32 %[asoff], 0x80000000, %[ak]")
+            emit("s_cselect_b32 %[bsoff], 0x80000000, %[bk]")
         nrd = NB + MB
         G = 2 * NT                                          # gaps of the K-step, half 0 then half 1
         slots = [[] for _ in range(G)]
@@ -379,6 +424,14 @@ def gen16(BM, BN, WGM, WGN, opt=None):
             slots[g - 1].append(m0)
             slots[g].append(ld)
         slots[gb2] = [f"s_waitcnt vmcnt({before_b2 + nres})"] + ([] if "nobar" in abl else ["s_barrier"]) + slots[gb2]
+        if CONV:
+            # the rebuilt A offsets in front of the first piece (from gap 2 on: the previous K-step's pieces were all issued inside it),
+            # the state advance behind the last one
+            flat = [ins for grp in conv_offsets() for ins in grp]           # two VALU per gap: what an MFMA's issue shadow holds
+            for i in range(0, len(flat), 2): slots[2 + i // 2] += flat[i:i + 2]
+            assert 2 + (len(flat) - 1) // 2 < b1 and b1 + 2 + dstep * (len(pcs) - 1) < G - 8
+            c1, c2, c3 = conv_advance()
+            slots[G - 7] += c1; slots[G - 6] += c2; slots[G - 5] += c3
         rd = reads(stage ^ 1, 0, 0)
         for i, r in enumerate(rd): slots[min(gb2 + 1 + rd2_step * i, G - 1)].append(r)
         if TRACE:
@@ -402,8 +455,9 @@ def gen16(BM, BN, WGM, WGN, opt=None):
                         emit(f"v_mfma_f32_16x16x32_bf16 {acc(nb, mb)}, {wfrag(kh, nb)}, {afrag(kh, mb)}, {acc(nb, mb)}")
                     for ins in slots[i]: emit(ins)
                     i += 1
-        emit("s_add_u32 %[ak], %[ak], 128")
-        emit("s_add_u32 %[bk], %[bk], 128")
+        if not CONV:
+            emit("s_add_u32 %[ak], %[ak], 128")
+            emit("s_add_u32 %[bk], %[bk], 128")
         wrap()
 
     def wrap():
@@ -415,16 +469,33 @@ def gen16(BM, BN, WGM, WGN, opt=None):
         emit("s_cselect_b32 %[bk], 0, %[bk]")
 
     emit("s_nop 15")
-    emit("s_mov_b32 %[asoff], %[ak]")
-    emit("s_mov_b32 %[bsoff], %[bk]")
-    for p in range(npieces):
-        d = dma(0, p)
-        if d:
-            emit(d[0]); emit("s_nop 0"); emit(d[1])
-    emit("s_add_u32 %[ak], %[ak], 128")
-    emit("s_add_u32 %[bk], %[bk], 128")
-    wrap()
-    if PGR == 2:                                            # K-step 1 into stage 1 (out of range when the problem has one K-step)
+    if CONV:
+        emit(f"v_mov_b32_e32 v{VOOB}, 0x80000000")
+        # K-steps 0 and 1 of the range into stages 0 and 1 (livemin = 0 / 1: a range of one step fetches nothing for the second)
+        for st in range(2):
+            emit(f"s_mov_b32 %[livemin], {st}")
+            for ins in conv_scalars(): emit(ins)
+            for grp in conv_offsets():
+                for ins in grp: emit(ins)
+            emit("s_nop 1")
+            for p in range(npieces):
+                d = dma(st, p)
+                if d:
+                    emit(d[0]); emit("s_nop 0"); emit(d[1])
+            for chunk in conv_advance():
+                for ins in chunk: emit(ins)
+        emit("s_mov_b32 %[livemin], 2")
+    else:
+        emit("s_mov_b32 %[asoff], %[ak]")
+        emit("s_mov_b32 %[bsoff], %[bk]")
+        for p in range(npieces):
+            d = dma(0, p)
+            if d:
+                emit(d[0]); emit("s_nop 0"); emit(d[1])
+        emit("s_add_u32 %[ak], %[ak], 128")
+        emit("s_add_u32 %[bk], %[bk], 128")
+        wrap()
+    if PGR == 2 and not CONV:                               # K-step 1 into stage 1 (out of range when the problem has one K-step)
         emit("s_cmp_le_u32 %[cnt], 1")
         emit("s_cselect_b32 %[asoff], 0x80000000, %[ak]")
         emit("s_cselect_b32 %[bsoff], 0x80000000, %[bk]")
@@ -471,7 +542,7 @@ def gen16(BM, BN, WGM, WGN, opt=None):
     if TRACE:
         for i in range(7): emit(f"s_mov_b32 %[t{i}], s{76 + i}")
         emit("s_mov_b32 %[t7], s88")
-    return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, FS=FS, RB=RB, TRACE=TRACE, RES=RES, RES_V=RES_V)
+    return L, dict(MB=MB, NB=NB, NT=NT, AI=AI, BI=BI, FS=FS, RB=RB, TRACE=TRACE, RES=RES, RES_V=RES_V, CONV=CONV)
 
 
 def c_function16(name, BM, BN, WGM, WGN, opt=None):
@@ -511,6 +582,35 @@ __device__ __forceinline__ void gemm_asm16_loop_{fname}({sig}, const u32x8& rbas
     asm volatile(
 {text}        : {outs}, [cnt] "+s"(cnt), [ak] "+s"(ak), [bk] "+s"(bk), [asoff] "=&s"(asoff), [bsoff] "=&s"(bsoff){trouts}{resouts}
         : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 8}:{RB + 23}]}}"(dma0){d1in}{resins}, [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), [kend] "s"(kend)
+        : {", ".join(clob)});
+}}
+"""
+
+
+def c_function16_conv(name, BM, BN, WGM, WGN, opt=None):
+    """The conv-mode loop (gen16 conv=1) as a C function.  State operands (in / out): the fetch position inside the canonical
+    K order - iw, ih (in-plane tap), kc (64-channel slice), tapd = ((ih - 1) * W + (iw - 1)) * Cin * 2, kcoff = kc * 128, bso = byte
+    offset of the weight rows of (frame tap, tap, slice) - and cnt = K-steps of this range.  Constants: cinb = Cin * 2, nk2 = N * K * 2,
+    fixw = W * Cin * 2 - 3 cinb, fixh = -3 W * Cin * 2, fixkc = 128 - 9 nk2, fixit = 9 nk2 - KC * 128, nkc = KC."""
+    lines, d = gen16(BM, BN, WGM, WGN, dict(opt or {}, conv=1))
+    NT, RB, FS = d["NT"], d["RB"], d["FS"]
+    assert 4 * NT <= 256
+    text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
+    n32 = (4 * NT + 31) // 32
+    sig = ", ".join(f"f32x32& c{i}" for i in range(n32))
+    outs = ", ".join(f'"={{a[{32 * i}:{32 * i + 31}]}}"(c{i})' for i in range(n32))
+    clob = [f'"v{i}"' for i in range(0, 2 * FS)] + [f'"v{RB + 56}"', f'"v{RB + 57}"', f'"v{RB + 58}"', '"vcc"', '"scc"', '"memory"']
+    st = ["iw", "ih", "kc", "tapd", "kcoff", "bso"]
+    tmps = ["t0", "t1", "t2", "t3", "t4", "vbit", "livemin", "asoff", "bsoff"]
+    consts = ["cinb", "nk2", "fixw", "fixh", "fixkc", "fixit", "nkc"]
+    return f"""// GENERATED by tools/gen_gemm_asm.py - do not edit.  {len(lines)} instructions: tile {BM} x {BN}, waves {WGM} x {WGN}, v_mfma_f32_16x16x32_bf16, conv mode (3x3x3 taps, A rows re-staged per tap).
+__device__ __forceinline__ void gemm_asm16_conv_loop_{name}({sig}, const u32x8& rbase, u32x16& dma0, u32x8& abase0, u32x8& abase1, u32x8& abase2, const u32x8& vmask,
+        const u32x4& ra, const u32x4& rw, int cnt, uint32_t ldsw, {", ".join("uint32_t " + x for x in st)}, {", ".join("uint32_t " + x for x in consts)}) {{
+    uint32_t {", ".join(tmps)};
+    asm volatile(
+{text}        : {outs}, [cnt] "+s"(cnt), {", ".join(f'[{x}] "+s"({x})' for x in st)}, {", ".join(f'[{x}] "=&s"({x})' for x in tmps)},
+          "+{{v[{RB + 8}:{RB + 23}]}}"(dma0), "+{{v[{RB + 24}:{RB + 31}]}}"(abase0), "+{{v[{RB + 32}:{RB + 39}]}}"(abase1), "+{{v[{RB + 40}:{RB + 47}]}}"(abase2)
+        : "{{v[{RB}:{RB + 7}]}}"(rbase), "{{v[{RB + 48}:{RB + 55}]}}"(vmask), [ra] "s"(ra), [rw] "s"(rw), [ldsw] "s"(ldsw), {", ".join(f'[{x}] "s"({x})' for x in consts)}
         : {", ".join(clob)});
 }}
 """
@@ -611,6 +711,9 @@ def main():
             f.write("\n")
             f.write(store_functions16(name.replace("x", "_"), BM, BN, WGM, WGN))
             f.write("\n")
+            if name == "256x256" and not int(o16.get("trace", 0)):
+                f.write(c_function16_conv(name.replace("x", "_"), BM, BN, WGM, WGN, o16))
+                f.write("\n")
             if name == "160x256" and not int(o16.get("trace", 0)):
                 f.write(c_function16(name.replace("x", "_"), BM, BN, WGM, WGN, dict(o16, res_rows=20)))
                 f.write("\n")
