@@ -61,6 +61,26 @@ extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int k
     return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
 }
 
+extern "C" int ltx_op_linear_split_factor(int M, int N, int K) {
+    GemmArgs g; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    return ltx_gemm_split_factor(g);
+}
+extern "C" int ltx_op_linear_deferred(const void* x, const void* w, float* parts, int M, int N, int K, ltx_stream stream) {
+    if (!x || !w || !parts) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_deferred: null tensor");
+    GemmArgs g; g.A = x; g.W = w; g.C = parts; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.defer_parts = parts;
+    if (!ltx_gemm_defer_ok(g, EPI_GATE_RESID)) LTX_FAIL(LTX_ERR_ARG, "ltx_op_linear_deferred: bf16 linear layers of at most 512 rows, N % 8 == 0, K % 8 == 0");
+    return ltx_launch_gemm(g, LTX_DT_BF16, EPI_BIAS, (hipStream_t)stream);
+}
+extern "C" int ltx_op_rownorm_deferred(const float* parts, int nparts, const void* bias, const void* resid, const float* gate, int gate_stride, void* h_out,
+                                       void* y, int64_t rows, int D, int kind, float eps, const float* scale, const float* shift, int64_t rows_per_batch,
+                                       int mod_stride, int dtype, ltx_stream stream) {
+    if (!parts || !resid || !h_out || !y) LTX_FAIL(LTX_ERR_ARG, "ltx_op_rownorm_deferred: null tensor");
+    RowNormArgs a; a.x = resid; a.y = y; a.rows = rows; a.D = D; a.ldx = D; a.ldy = D; a.kind = kind; a.eps = eps;
+    a.scale = scale; a.shift = shift; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; a.mod_stride = mod_stride;
+    a.parts = parts; a.nparts = nparts; a.part_stride = rows * D; a.d_bias = bias; a.d_gate = gate; a.d_gate_stride = gate_stride; a.x_out = h_out;
+    return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
+}
+
 extern "C" int ltx_op_rownorm_presum(const void* x, void* y, int64_t rows, int D, float eps, const void* weight,
                                      const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
                                      const float* presum, int presum_n, int dtype, ltx_stream stream) {

@@ -53,11 +53,11 @@ struct ltx_dit {
     struct { bool valid = false; const float* coords = nullptr; float rs[3] = {0, 0, 0}; bool has_rs = false; int B = 0, S = 0, F = 0, H = 0, W = 0; hipStream_t stream = nullptr; } rope_key;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
-    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq, hsq;
+    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq, hsq, parts;
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq, &hsq};
+        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq, &hsq, &parts};
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); e.kvc.release(); e.biasc.release(); e.kidx.release(); e.kcount.release(); }
         ctxs.clear();
@@ -258,6 +258,24 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h
+    // Few tokens (C1's 384: every linear layer is a latency-bound weight stream): ff2, the deepest one (K = 4 D), runs its K ranges as
+    // separate blocks (the shape rule: four ranges from K = 8192 up) and leaves their f32 sums in m->parts; the row norm that follows
+    // the block - the next block's norm1, or the final LayerNorm - adds them in part order, applies gate * y + h, writes h and goes on
+    // normalising the row it has just finished (GemmArgs::defer_parts / RowNormArgs::parts).  Same K partition and order as the
+    // in-launch reduction: the same bits.  ff2_defer=0: the in-launch reduction (A/B aid).
+    bool defer_ff2 = false; int ff2_parts = 1;
+    if (dt == LTX_DT_BF16 && !skip_layer_mask && ltx_opt().ff2_defer && !presum) {
+        GemmArgs gf; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.C = m->h.p; gf.M = (int)M; gf.N = m->blocks[0].ff2.out; gf.K = m->blocks[0].ff2.in; gf.lda = 4 * D; gf.ldc = D;
+        ff2_parts = ltx_gemm_split_factor(gf);
+        defer_ff2 = M <= 512 && ff2_parts > 1 && gf.N == D && ltx_gemm_defer_ok(gf, EPI_GATE_RESID);
+    }
+    if (defer_ff2) LTX_TRY(m->parts.ensure((size_t)ff2_parts * M * D * sizeof(float)));
+    const float* pend_gate = nullptr; const void* pend_bias = nullptr; bool pending = false;      // h's rows are still K-range sums in m->parts
+    auto take_pending = [&](RowNormArgs& rn) {
+        if (!pending) return;
+        rn.parts = m->parts.as<float>(); rn.nparts = ff2_parts; rn.part_stride = M * D; rn.d_bias = pend_bias; rn.d_gate = pend_gate; rn.d_gate_stride = 6 * D;
+        rn.x_out = m->h.p; pending = false;
+    };
     if (skip_layer_mask) LTX_TRY(m->orig.ensure(M * D * esz));
 
     // inputs -> model dtype (:1045-1047)
@@ -370,7 +388,9 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
+        take_pending(rn);
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        rn.parts = nullptr; rn.nparts = 0; rn.x_out = nullptr; rn.d_bias = nullptr; rn.d_gate = nullptr;
         // self attention
         // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
         // of two: the attention kernel reads K/V rows of a dense matrix 7-11 % faster than column slices of [M, 3D]
@@ -423,6 +443,12 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         LTX_TRY(ltx_linear(b.ff1, m->n.p, D, m->ff.p, 4 * D, (int)M, dt, EPI_GELU, s));
+        if (defer_ff2) {
+            GemmArgs g; g.A = m->ff.p; g.W = b.ff2.w; g.C = m->h.p; g.M = (int)M; g.N = b.ff2.out; g.K = b.ff2.in; g.lda = 4 * D; g.ldc = D;
+            g.defer_parts = m->parts.as<float>();
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
+            pending = true; pend_gate = ada + 5 * D; pend_bias = b.ff2.b;
+        } else
         LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S, presum ? m->hsq.as<float>() : nullptr));
         hsq_valid = presum;
         if (skip_layer_mask && any) { LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s)); hsq_valid = false; }
@@ -433,6 +459,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 1; rn.eps = 1e-6f; rn.shift = adaf; rn.scale = adaf + (size_t)B * D;
         rn.rows_per_batch = S; rn.mod_stride = D;
+        take_pending(rn);
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         void* dst = iodt == dt ? out : m->outT.p;
         LTX_TRY(ltx_linear(m->proj_out, m->n.p, D, dst, c.out_channels, (int)M, dt, EPI_BIAS, s));

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                     f32x4 gt = gate_one;
                     if (!one_batch) gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(m / g.rows_per_batch) * g.gate_stride + n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gt[i], v[i], r[i]);       // ONE rounding, spelled out: every kernel that finishes these rows must agree
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += r[i];

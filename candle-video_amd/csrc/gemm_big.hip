@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                                     if constexpr (EPI == EPI_GATE_RESID) {
                                         const f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(mc / g.rows_per_batch) * g.gate_stride + nb);
 #pragma unroll
-                                        for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+                                        for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gt[i], v[i], r[i]);       // ONE rounding, spelled out: every kernel that finishes these rows must agree
                                     } else {
 #pragma unroll
                                         for (int i = 0; i < 4; ++i) v[i] += r[i];
@@ -447,7 +447,11 @@ int ltx_gemm_split_factor(const GemmArgs& g) {
     // last arriver re-reading the slabs: tools/ring_trace.py).  Measured over 14 shapes with M = 128 .. 512
     // (tools/ring_split_probe.py, profiles/r4_ring_split_probe.jsonl): unsplit wins 12, ties one, loses 12 % on one (T5's wo,
     // K = 10240).  A function of (M, N, K) alone, like the rest of this rule.
-    if (!g.conv && g.M <= 512 && g.N >= 32 && g.N % 4 == 0 && g.K % 8 == 0 && ltx_exp("gemm_split_ring", 1)) return 1;
+    // Round 5: ... except the deepest ones (K >= 8192: the DiT's ff2 at C1's 384 tokens, T5-XXL's wo), cut into four ranges.  The
+    // DiT hands the ranges to the row norm that follows the layer (GemmArgs::defer_parts: no in-launch reduction at all, a block
+    // runs 32 K-steps instead of 128: ff2 33 -> ~20 us); a stand-alone call pays the in-launch reduction (ff2 +3 us, T5's wo -5 us:
+    // profiles/r4_ring_split_probe.jsonl).
+    if (!g.conv && g.M <= 512 && g.N >= 32 && g.N % 4 == 0 && g.K % 8 == 0 && ltx_exp("gemm_split_ring", 1)) return nk >= 128 && nk % 4 == 0 ? 4 : 1;
     if (!g.conv && g.M <= 1536 && ltx_exp("gemm_split_smallm", 1)) {
         // Small-M linear layers (C1's 384 tokens, the 128 text rows; round 3, tools/small_m_probe.py): these are latency-bound
         // weight streams - a K-step costs 0.4-0.75 us whatever it computes - and the in-launch reduction grows faster than
@@ -677,12 +681,19 @@ int run_plan(const GemmArgs& g, int epi, int plan, hipStream_t s) {
     return g.conv ? launch_tile<true>(g, epi, plan, s) : launch_tile<false>(g, epi, plan, s);
 }
 
-int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) {
+int tune_plan(const GemmArgs& g_in, int epi, hipStream_t s, int fallback, int* plan_out) {
     *plan_out = fallback;
-    GemmArgs g = g_in;                                   // plain bias epilogue into a scratch [M, N] output
+    // plain bias epilogue into a scratch [M, N] output - except the upsamplers' depth-to-space convs, measured with their own epilogue
+    // (its scattered 8-byte stores cost the kernels differently; the output, (2T - 1) x 2H x 2W x N / 8 rows, fits the same scratch)
+    const int tepi = (g_in.conv && epi == EPI_D2S) ? EPI_D2S : EPI_BIAS;
+    GemmArgs g = g_in;
     void* scratch = nullptr;
-    if (hipMalloc(&scratch, (size_t)g.M * g.N * sizeof(bf16_t)) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
+    // (a call that leaves its K ranges to the consumer - GemmArgs::defer_parts - is measured in that form, on the ring tiles that serve it)
+    const bool defer = g_in.defer_parts != nullptr;
+    const size_t scratch_bytes = defer ? (size_t)ltx_gemm_split_factor(g) * g.M * g.N * sizeof(float) : (size_t)g.M * g.N * sizeof(bf16_t);
+    if (hipMalloc(&scratch, scratch_bytes) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
     g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0; g.rowsq = nullptr;
+    g.defer_parts = defer ? reinterpret_cast<float*>(scratch) : nullptr;
     struct Guard {                                           // events and scratch are released on every return path
         void* scratch; hipEvent_t e0 = nullptr, e1 = nullptr;
         ~Guard() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (scratch) (void)hipFree(scratch); }
@@ -694,17 +705,17 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
     const bool p8_off = ltx_opt().gemm_off & LTX_FAM_P8, halo_off = ltx_opt().gemm_off & LTX_FAM_HALO;
     const bool split_shape = ltx_gemm_split_factor(g) > 1;     // split shapes run gemm_big tiles only (same K partition in every plan)
     const bool asm16_off = ltx_opt().gemm_off & LTX_FAM_ASM16;
-    for (int plan = 0; plan < kPlanRing + ltx_gemm_ring_tiles(); ++plan) {
+    for (int plan = defer ? kPlanRing : 0; plan < kPlanRing + ltx_gemm_ring_tiles(); ++plan) {
         if (plan >= kPlanRing) {
-            if (!plan_ok(g, EPI_BIAS, plan)) continue;
+            if (!plan_ok(g, tepi, plan)) continue;
             // a ring tile is built for grids of about one round: skip the ones that would need more than three
             if ((int64_t)cdiv(g.M, ltx_gemm_ring_tile_bm(plan - kPlanRing)) * cdiv(g.N, ltx_gemm_ring_tile_bn(plan - kPlanRing)) * ltx_gemm_split_factor(g) > 768) continue;
         } else if (plan > kPlanAsm16Conv) { plan = kPlanRing - 1; continue; }
         else if (plan == kPlanAsm16Conv) {
-            if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
+            if (asm16_off || !plan_ok(g, tepi, plan)) continue;
         } else if (plan >= kPlanAsm16 + 3) { plan = kPlanAsm16Conv - 1; continue; }
         else if (plan >= kPlanAsm16) {
-            if (asm16_off || !plan_ok(g, EPI_BIAS, plan)) continue;
+            if (asm16_off || !plan_ok(g, tepi, plan)) continue;
         } else if (plan >= kPlanHalo + 2) { plan = kPlanAsm16 - 1; continue; }
         else if (plan < kPlanP8) {
             if (plan >= kNumTiles) { plan = kPlanP8 - 1; continue; }
@@ -712,11 +723,11 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         } else if (plan < kPlanHalo) {
             if (plan >= kPlanP8 + 2) { plan = kPlanHalo - 1; continue; }
             if (split_shape || p8_off || nk < 2 || g.N <= 64 || (plan == kPlanP8 && g.N <= 128) || !ltx_gemm_p8_fits(g)) continue;
-        } else if (split_shape || halo_off || !ltx_conv_halo_eligible(g, EPI_BIAS, plan == kPlanHalo ? 128 : 256)) continue;
+        } else if (split_shape || halo_off || !ltx_conv_halo_eligible(g, tepi, plan == kPlanHalo ? 128 : 256)) continue;
         // warm launch (code object load, caches), timed on its own to size the measurement: ~1.5 ms of launches,
         // 3..16 of them, best of three rounds
         HIP_TRY(hipEventRecord(e0, s));
-        int rc = run_plan(g, EPI_BIAS, plan, s);
+        int rc = run_plan(g, tepi, plan, s);
         if (rc != LTX_OK) continue;
         HIP_TRY(hipEventRecord(e1, s));
         HIP_TRY(hipEventSynchronize(e1));
@@ -730,7 +741,7 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
         for (int round = 0; round < 3; ++round) {
             HIP_TRY(hipEventRecord(e0, s));
             bool ok = true;
-            for (int i = 0; i < n; ++i) ok = ok && run_plan(g, EPI_BIAS, plan, s) == LTX_OK;
+            for (int i = 0; i < n; ++i) ok = ok && run_plan(g, tepi, plan, s) == LTX_OK;
             HIP_TRY(hipEventRecord(e1, s));
             HIP_TRY(hipEventSynchronize(e1));
             HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -745,9 +756,9 @@ int tune_plan(const GemmArgs& g_in, hipStream_t s, int fallback, int* plan_out) 
 namespace {
 std::atomic<int> g_autotune{1};      // ltx_set_autotune(0): never measure inside a call (cached / loaded plans, else the static model)
 
-PlanKey plan_key(const GemmArgs& g) {
+PlanKey plan_key(const GemmArgs& g, int epi) {
     PlanKey key; memset(&key, 0, sizeof(key));
-    key.M = g.M; key.N = g.N; key.K = g.K; key.conv = g.conv;
+    key.M = g.M; key.N = g.N; key.K = g.K; key.conv = g.conv ? (epi == EPI_D2S ? 2 : 1) : (g.defer_parts ? 3 : 0);      // 2: a depth-to-space conv, 3: a linear layer with deferred K ranges (their own measurements)
     if (g.conv) { key.ntaps = g.ntaps; key.T = g.T; key.H = g.H; key.W = g.Wd; }
     return key;
 }
@@ -769,15 +780,15 @@ int plan_from_name(const char* n) {
     return -1;
 }
 // *plan holds the static model's choice on entry; replaced by the cached plan, or by a fresh measurement when allowed
-int cached_or_tuned_plan(const GemmArgs& g, hipStream_t s, int* plan) {
+int cached_or_tuned_plan(const GemmArgs& g, int epi, hipStream_t s, int* plan) {
     if (!ltx_opt().gemm_tune) return LTX_OK;
-    const PlanKey key = plan_key(g);
+    const PlanKey key = plan_key(g, epi);
     std::lock_guard<std::mutex> lock(g_plan_mu);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
         if (!g_autotune.load()) return LTX_OK;
         int tuned = *plan;
-        LTX_TRY(tune_plan(g, s, *plan, &tuned));
+        LTX_TRY(tune_plan(g, epi, s, *plan, &tuned));
         it = g_plans.emplace(key, tuned).first;
     }
     *plan = it->second;
@@ -812,10 +823,11 @@ extern "C" int ltx_plan_load(const char* path) {
         const int plan = plan_from_name(name);
         if (plan < 0) { fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: unknown plan name: ") + name); }
         {   // the shape-level predicates of tune_plan (run_plan re-checks the call's own operands and falls back to the static model)
-            GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = key.conv; g.ntaps = key.conv ? key.ntaps : 1;
+            const bool kconv = key.conv == 1 || key.conv == 2;                                            // 2: a depth-to-space conv; 3: a linear layer with deferred K ranges
+            GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = kconv ? 1 : 0; g.ntaps = kconv ? key.ntaps : 1;
             const int nk = (key.K + 63) / 64 * g.ntaps;
-            const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && (!key.conv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0));
-            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && (key.conv || key.K % 8 || key.M > 2048)) || (plan == kPlanAsm16Conv && (!key.conv || key.ntaps != 27 || key.K % 64)) || (plan >= kPlanAsm16 && plan < kPlanAsm16Conv && (key.conv || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!key.conv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
+            const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && key.conv >= 0 && key.conv <= 3 && (!kconv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0)) && (key.conv != 3 || plan >= kPlanRing);
+            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && (kconv || key.K % 8 || key.M > 2048)) || (plan == kPlanAsm16Conv && (!kconv || key.ntaps != 27 || key.K % 64)) || (plan >= kPlanAsm16 && plan < kPlanAsm16Conv && (kconv || key.conv == 3 || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!kconv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
                 fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: plan not valid for its shape: ") + line);
             }
         }
@@ -831,6 +843,17 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     // XCD-contiguous tile order (measured, tools/microbench.py xcd: linear +3..19 %, conv +5 %)
     g.xcd_remap = ltx_exp("xcd_remap", 1);
     if (g.pn_on) return ltx_launch_conv_halo(g, epi, g.N, s);      // fused output norm: only that kernel's wide epilogue carries it
+    if (g.defer_parts) {                                   // K-range sums left to the consumer: gemm_ring.hip's tiles only (the caller asked ltx_gemm_defer_ok)
+        if (epi != EPI_BIAS || g.bias || g.conv || g.M > 512 || !ltx_gemm_ring_fits(g, EPI_BIAS)) LTX_FAIL(LTX_ERR_ARG, "gemm: defer_parts needs a bare linear layer of at most 512 rows (ltx_gemm_defer_ok)");
+        int plan = kPlanRing + ltx_gemm_ring_pick_tile(g);
+        if (ltx_opt().gemm_plan[0]) { const int f = plan_from_name(ltx_opt().gemm_plan); if (f >= kPlanRing && plan_ok(g, epi, f)) plan = f; }
+        else {
+            int cached = plan;
+            (void)cached_or_tuned_plan(g, epi, s, &cached);
+            if (cached >= kPlanRing && plan_ok(g, epi, cached)) plan = cached;
+        }
+        return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
+    }
     const LtxOptions& o = ltx_opt();
     const bool split_shape = ltx_gemm_split_factor(g) > 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
@@ -856,7 +879,7 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     if (forced == kPlanAsm16Conv) return ltx_launch_gemm_asm16_conv(g, epi, s);
     if (split_shape) {                                     // gemm_big tiles (or gemm_ring's, which keep their K partition): one partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
-        if (!big_forced) (void)cached_or_tuned_plan(g, s, &plan);
+        if (!big_forced) (void)cached_or_tuned_plan(g, epi, s, &plan);
         if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
         if (plan == kPlanAsm16Conv && plan_ok(g, epi, plan)) return ltx_launch_gemm_asm16_conv(g, epi, s);
         if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)
@@ -878,7 +901,7 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
             const int t = ltx_gemm_asm_pick_tile(g.M, g.N);              // 0: 256 x 256, 1: 320 x 256, 2: 160 x 256
             plan = kPlanAsm16 + (t == 0 ? 0 : (t == 1 ? 2 : 1));
         }
-        LTX_TRY(cached_or_tuned_plan(g, s, &plan));
+        LTX_TRY(cached_or_tuned_plan(g, epi, s, &plan));
     }
     return run_plan(g, epi, plan, s);
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
         const float* gp = g.gate + (int64_t)(m / g.rows_per_batch) * g.gate_stride + nb;
         f32x4 gt = *reinterpret_cast<const f32x4*>(gp);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gt[i], v[i], r[i]);       // ONE rounding, spelled out: every kernel that finishes these rows must agree
         store4<T>(C + (int64_t)m * g.ldc + nb, v);
     } else if constexpr (EPI == EPI_RESID) {
         float r[4];

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
     constexpr bool HAS_R = EPI == EPI_GATE_RESID || EPI == EPI_RESID;
     constexpr bool HAS_G = EPI == EPI_GATE_RESID;
     u32x2 pbias[FN], presid[HAS_R ? FM : 1][HAS_R ? FN : 1]; f32x4 pgate[HAS_G ? FM : 1][HAS_G ? FN : 1];
-    if (!producer) {
+    if (!producer && !g.defer_parts) {
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
             int nb = n0 + wn * WN + fn * 16 + 4 * fq; if (nb > g.N - 4) nb = g.N - 4;
@@ -227,6 +227,23 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is out of the ring
     }
 
+    if (g.defer_parts) {
+        // Deferred reduction: this range's f32 sums, row-major, and nothing else (the consumer adds the ranges in part order)
+        if (!producer) {
+            float* pp = g.defer_parts + (int64_t)part * g.M * g.N;
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = m0 + wm * WM + fm * 16 + frow;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+                    if (nb < g.N) *reinterpret_cast<f32x4*>(pp + (int64_t)m * g.N + nb) = acc[fm][fn];
+                }
+            }
+        }
+        return;
+    }
     if (sf > 1) {
         // In-launch reduction of a tile's parts (gemm_big.hip's protocol and order): f32 slabs, a ticket, the last arriver adds
         // ((s0 + s1) + s2) + ... and runs the epilogue
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
                 load4<bf16_t>(reinterpret_cast<const bf16_t*>(&presid[fm][fn]), r);
                 const f32x4 gt = pgate[fm][fn];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = r[i] + gt[i] * v[i];
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gt[i], v[i], r[i]);       // ONE rounding, spelled out: every kernel that finishes these rows must agree
             } else if constexpr (EPI == EPI_RESID) {
                 float r[4];
                 load4<bf16_t>(reinterpret_cast<const bf16_t*>(&presid[fm][fn]), r);
@@ -339,7 +356,8 @@ int launch_ring(const GemmArgs& g, hipStream_t s) {
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
-    LTX_TRY(ltx_gemm_split_workspace(&ga, tiles, BM, BN, s));
+    if (g.defer_parts) { ga.sk_sf = ltx_gemm_split_factor(g); ga.sk_full = 0; ga.sk_ws = nullptr; ga.sk_cnt = nullptr; }     // the caller's buffer takes the ranges
+    else LTX_TRY(ltx_gemm_split_workspace(&ga, tiles, BM, BN, s));
     ltx_prof_kernel(LTX_PROFK_GEMM_RING);
     LTX_LAUNCH_TIMED(kern, dim3((unsigned)(tiles * ga.sk_sf)), dim3(SPEC ? 512 : 256), smem, s, ga);
     LTX_CHECK_LAUNCH();
@@ -407,6 +425,14 @@ bool ltx_gemm_ring_fits(const GemmArgs& g, int epi) {
     if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
     if (g.bias && ((uintptr_t)g.bias & 7)) return false;
     return ltx_gemm_big_fits(g);
+}
+
+// Deferred reduction (GemmArgs::defer_parts) is this kernel's: bf16 linear layers of at most 512 rows that the ring serves, N in
+// whole 16-byte f32 groups.  The launch itself carries no epilogue (EPI_BIAS instantiation, no bias): the consumer finishes the rows.
+bool ltx_gemm_defer_ok(const GemmArgs& g_in, int epi) {
+    if (epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
+    GemmArgs g = g_in; g.bias = nullptr; g.resid = nullptr; g.gate = nullptr;
+    return g.M <= 512 && g.N % 8 == 0 && !g.rowsq && !g.c_seg_shift && ltx_gemm_ring_fits(g, EPI_BIAS);
 }
 
 int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s) {

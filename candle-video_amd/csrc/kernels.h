@@ -68,6 +68,10 @@ struct GemmArgs {
     const float* pn_scale = nullptr; const float* pn_shift = nullptr;   // f32 [B, pn_mod_stride] or null
     // gemm_big tail split (set by its launcher): tiles [0, sk_full) whole, the rest cut into sk_sf K-ranges each
     int sk_full = 0, sk_sf = 1, sk_plain = 0;     // sk_plain: round 3's publish protocol (plain stores + agent release), A/B aid
+    // Deferred reduction (gemm_ring.hip, linear layers of at most 512 rows): the K ranges of the shape rule leave their f32 sums in
+    // defer_parts[part][m][n] (row-major, leading dimension N) and the launch ends there - no ticket, no epilogue; the consumer
+    // (RowNormArgs::parts: the row norm that follows the layer) adds the ranges in part order and applies the epilogue's expression.
+    float* defer_parts = nullptr;
     float* sk_ws = nullptr;       // f32 slabs [tail tile][part][BM*BN]
     unsigned* sk_cnt = nullptr;   // arrival counters [tail tile], zeroed before the launch
 };
@@ -79,6 +83,7 @@ void ltx_gemm_rowsq_done();      // a GEMM kernel that wrote GemmArgs::rowsq its
 bool ltx_gemm_big_eligible(const GemmArgs& g, int dtype);
 int ltx_launch_gemm_big(const GemmArgs& g, int epi, hipStream_t s);
 int ltx_gemm_split_factor(const GemmArgs& g);   // gemm_big.hip: K-ranges a small-output shape is cut into (shape only)
+bool ltx_gemm_defer_ok(const GemmArgs& g, int epi);   // gemm_ring.hip: the call can leave its K-range sums to the consumer (GemmArgs::defer_parts)
 // gemm_asm.hip: one-wave-per-SIMD kernels with a generated asm K loop; eligibility is a function of the shape only
 bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi);
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s);
@@ -122,6 +127,12 @@ struct RowNormArgs {
     // RMS rows whose sum of squares is already known (GemmArgs::rowsq of the GEMM that produced x): presum[row * presum_n + g],
     // summed in ascending g.  The pass is then a pure elementwise map - no wave waits for a row (rownorm_presum_kernel).
     const float* presum = nullptr; int presum_n = 0;
+    // Rows that arrive as the K-range sums of the linear layer before them (GemmArgs::defer_parts: parts[p][row][D] f32): the row is
+    // first FINISHED the way that layer's gate / residual epilogue would have - h = resid + gate * (((p0 + p1) + ...) + bias),
+    // rounded to T, resid = x (read), h written back to x_out (may alias x) - and then normalised as usual.  WIDE rows only
+    // (one wave per row); gate f32 [batch, gate_stride] or null (then h = resid + sum + bias).
+    const float* parts = nullptr; int nparts = 0; int64_t part_stride = 0;
+    const void* d_bias = nullptr; const float* d_gate = nullptr; int d_gate_stride = 0; void* x_out = nullptr;
 };
 int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s);
 

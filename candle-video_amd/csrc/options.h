@@ -22,6 +22,7 @@ struct LtxOptions {
     int attn_q64_big = -1;        // attn_q64: number of 256-query blocks per head (-1: the launcher's split)
     int vae_tile_batch = 0;       // leaves per decoder call of the tiled decode (0: sized by free memory)
     int prof_kernel_events = 1;   // 0: stream-level event brackets in the per-class timing
+    int ff2_defer = 1;            // 0: small-M ff2 reduces its K ranges in the launch instead of leaving them to the next row norm
     // ---- another algorithm (rounding differs; each is a tested A/B arm)
     int gemm_splitk = 1;          // 0: small outputs keep one K range
     int q2_fold = 1;              // 0: stand-alone cross-attention q-norm pass; 2: fold whatever the shape

@@ -100,8 +100,48 @@ __device__ __forceinline__ void load_chunk_operands(const RowNormArgs& a, int c,
     }
 }
 
-// MODE 0: WIDE (row cached in registers), 1: NARROW (NSLOT rows per lane group), 2: re-read fallback
-template <typename T, int MODE>
+// RowNormArgs::parts: chunk c of a row that arrives as the K-range sums of the linear layer before it - finished with the layer's
+// epilogue expression (gemm_common.h epilogue<>: v = sum + bias, then resid + gate * v or v + resid), rounded to T, written back
+// as the new residual stream and returned for the norm.  Ranges added in part order: ((p0 + p1) + p2) + ... (gemm_big.hip).
+template <typename T>
+__device__ __forceinline__ Chunk16 deferred_chunk(const RowNormArgs& a, int64_t row, int64_t b, int c, bool active) {
+    constexpr int CH = ElemTraits<T>::CHUNK;
+    float v[CH];
+    const float* pp = a.parts + row * a.D + c * CH;
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pp + 4 * q); v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3]; }
+    for (int p = 1; p < a.nparts; ++p) {
+        const float* pq = pp + (int64_t)p * a.part_stride;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pq + 4 * q); v[4 * q] += t[0]; v[4 * q + 1] += t[1]; v[4 * q + 2] += t[2]; v[4 * q + 3] += t[3]; }
+    }
+    if (a.d_bias) {
+        Chunk16 bc; bc.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.d_bias) + c * CH);
+        float bf[CH]; chunk_to_f32<T>(bc, bf);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] += bf[i];
+    }
+    Chunk16 rc; rc.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.x) + row * a.ldx + c * CH);
+    float r[CH]; chunk_to_f32<T>(rc, r);
+    if (a.d_gate) {
+        const float* gp = a.d_gate + b * a.d_gate_stride + c * CH;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            const f32x4 gt = *reinterpret_cast<const f32x4*>(gp + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * q + i] = __builtin_fmaf(gt[i], v[4 * q + i], r[4 * q + i]);      // gemm_common.h epilogue<>: one rounding
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] += r[i];
+    }
+    Chunk16 o; f32_to_chunk<T>(v, o);
+    if (active) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.x_out) + row * a.ldx + c * CH) = o.u;
+    return o;
+}
+
+// MODE 0: WIDE (row cached in registers), 1: NARROW (NSLOT rows per lane group), 2: re-read fallback; DEFER (MODE 0): RowNormArgs::parts
+template <typename T, int MODE, bool DEFER = false>
 __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -173,7 +213,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int l
             for (int i = 0; i < NSLOT; ++i) {
                 int c = sub + i * lpr;
                 v[i].u = (u32x4){0u, 0u, 0u, 0u};
-                if (c < nch) v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
+                if constexpr (DEFER) { if (c < nch) v[i] = deferred_chunk<T>(a, rr, b, c, active); }
+                else if (c < nch) v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
             }
             float mean = 0.f;
             if (a.kind == 1) {
@@ -745,7 +786,8 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
             static std::atomic<unsigned long long> occ_devs{0};
             (void)ltx_set_max_dyn_smem(occ_devs, reinterpret_cast<const void*>(&rownorm_kernel<T, 0>), 163840);
         }
-        if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), shm, s, a, lpr);
+        if (a.parts) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0, true>), grid, dim3(256), 0, s, a, lpr);       // (launcher-checked: WIDE rows)
+        else if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), shm, s, a, lpr);
         else LTX_LAUNCH_TIMED((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
     }
 }
@@ -758,6 +800,13 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     if (a.D % ch != 0 || a.ldx % ch != 0 || a.ldy % ch != 0) LTX_FAIL(LTX_ERR_ARG, "rownorm: D/ld must be multiples of the 16-byte chunk");
     if ((a.scale == nullptr) != (a.shift == nullptr)) LTX_FAIL(LTX_ERR_ARG, "rownorm: scale and shift go together");
     const int nch = a.D / ch, lpr = pick_lpr(nch);
+    if (a.parts) {
+        const int rpw = 64 / lpr;
+        const bool narrow = nch <= lpr && a.rows >= (int64_t)rpw * NSLOT * 4 * 64;
+        if (a.presum || narrow || nch > NSLOT * lpr || a.nparts < 1 || a.nparts > 16 || !a.x_out || a.part_stride < a.rows * a.D || a.D % 8 ||
+            ((uintptr_t)a.parts & 15) || (a.d_gate && (((uintptr_t)a.d_gate & 15) || a.d_gate_stride % 4)))
+            LTX_FAIL(LTX_ERR_ARG, "rownorm: deferred rows need whole-row lanes (D of at most 64 x 8 chunks), 1..16 parts of [rows, D] f32 and an output for the finished rows");
+    }
     // (every argument check sits in front of ltx_prof_begin: a failure after it would leave the timing record open)
     if (a.presum && (a.kind != 0 || a.presum_n < 4 || a.presum_n % 4 != 0 || nch > 256 || (nch & (nch - 1)) || a.rows >= 2147483647LL || a.rows_per_batch >= 2147483647LL))
         LTX_FAIL(LTX_ERR_ARG, "rownorm: presum serves RMS rows of a power-of-two number (<= 256) of 16-byte chunks with a multiple of 4 partials");

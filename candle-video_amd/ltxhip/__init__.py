@@ -118,6 +118,8 @@ _SIGS = {
     "ltx_op_linear_packed": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ltx_op_rownorm_presum": [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp],
     "ltx_op_linear_rowsq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], "ltx_op_rowsq": [_vp, _i64, _i, _i, _vp, _i, _vp],
+    "ltx_op_linear_split_factor": [_i, _i, _i], "ltx_op_linear_deferred": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "ltx_op_rownorm_deferred": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _i64, _i, _i, _vp],
     "ltx_op_attention_compact": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp, _vp],
     "ltx_op_attention_rowsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _f, _vp],
     "ltx_op_rownorm": [_vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
@@ -1054,6 +1056,26 @@ class ops:
         _check(lib.ltx_op_rownorm(_ptr(x.contiguous()), _ptr(y), C.c_int64(rows), D, kind, C.c_float(eps), _ptr(weight),
                                   _ptr(scale), _ptr(shift), C.c_int64(rows_per_batch), ms, act, _dt(x.dtype), _stream()))
         return y
+
+    @staticmethod
+    def linear_deferred(x, w):
+        """x @ w^T as UN-reduced K ranges (the library's shape rule): parts [P, M, N] f32 (bf16 layers of at most 512 rows)"""
+        M, K = x.shape
+        N = w.shape[0]
+        P = lib.ltx_op_linear_split_factor(M, N, K)
+        parts = torch.empty(P, M, N, dtype=torch.float32, device=x.device)
+        _check(lib.ltx_op_linear_deferred(_ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(parts), M, N, K, _stream()))
+        return parts
+
+    @staticmethod
+    def rownorm_deferred(parts, bias, resid, gate=None, kind=0, eps=1e-6, scale=None, shift=None, rows_per_batch=1):
+        """finish the rows of ops.linear_deferred (h = resid + gate * (sum of the parts + bias)) and normalise them: (h, y)"""
+        P, rows, D = parts.shape
+        h = torch.empty_like(resid); y = torch.empty_like(resid)
+        ms = scale.shape[-1] if scale is not None else 0
+        _check(lib.ltx_op_rownorm_deferred(_ptr(parts), P, _ptr(bias), _ptr(resid.contiguous()), _ptr(gate), gate.shape[-1] if gate is not None else 0, _ptr(h),
+                                           _ptr(y), C.c_int64(rows), D, kind, C.c_float(eps), _ptr(scale), _ptr(shift), C.c_int64(rows_per_batch), ms, _dt(resid.dtype), _stream()))
+        return h, y
 
     @staticmethod
     def rownorm_presum(x, presum, eps=1e-6, weight=None, scale=None, shift=None, rows_per_batch=1, act=0):

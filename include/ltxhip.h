@@ -257,6 +257,8 @@ int ltx_plan_load(const char* path);
  *   norm_lean=0            the general RMS-norm map kernel instead of the DiT-specialised one
  *   vae_tile_batch=N       at most N leaves per decoder call of the tiled decode (-1: one)
  *   prof_kernel_events=0   stream-level event brackets in the ltx_prof_* timing
+ *   ff2_defer=0            at <= 512 tokens the DiT's ff2 reduces its K ranges inside the launch instead of leaving them to the
+ *                          row norm that follows (same partition and order either way)
  *  another ALGORITHM - results differ in rounding (each is a tested A/B arm against the oracle):
  *   gemm_off=big           every GEMM on the 128 x 128 kernel (small outputs then keep one K range)
  *   gemm_splitk=0          small outputs keep one K range (another f32 summation order)

@@ -45,6 +45,17 @@ int ltx_op_rownorm_presum(const void* x, void* y, int64_t rows, int D, float eps
                           const float* scale, const float* shift, int64_t rows_per_batch, int mod_stride, int act,
                           const float* presum, int presum_n, int dtype, ltx_stream stream);
 
+/* A linear layer of at most 512 rows whose K ranges (the shape rule of the library: ltx_op_linear_split_factor(M, N, K), four from
+ * K = 8192 up) are left UN-reduced: parts[p][M][N] f32 = x @ w[:, range p]^T, no bias, no epilogue (gemm_ring.hip; the DiT's ff2
+ * at few tokens, LtxVideoTransformerBlock::forward ltx_transformer.rs:929-934).  ltx_op_rownorm_deferred finishes the rows:
+ * h = resid + gate_b * (((p0 + p1) + ...) + bias) (gate NULL: resid + sum + bias), rounded to the dtype, written to h_out, then
+ * y = the row norm of ltx_op_rownorm on h.  Together they return the bits of ltx_op_linear(epi 2 / 3) followed by ltx_op_rownorm. */
+int ltx_op_linear_split_factor(int M, int N, int K);
+int ltx_op_linear_deferred(const void* x, const void* w, float* parts, int M, int N, int K, ltx_stream stream);
+int ltx_op_rownorm_deferred(const float* parts, int nparts, const void* bias, const void* resid, const float* gate, int gate_stride, void* h_out,
+                            void* y, int64_t rows, int D, int kind, float eps, const float* scale, const float* shift, int64_t rows_per_batch,
+                            int mod_stride, int dtype, ltx_stream stream);
+
 /* RmsNorm / LayerNormNoParams + AdaLN modulate (+SiLU) on rows (ltx_transformer.rs:72-119, 874-889;
  * vae.rs:148-153, 711-739): y = act(norm(x)[*weight]*(1+scale_b)+shift_b). kind 0 RMS / 1 LN. */
 int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int kind, float eps, const void* weight,
