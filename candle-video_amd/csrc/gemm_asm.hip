@@ -760,7 +760,10 @@ bool ltx_gemm_asm16_conv_fits(const GemmArgs& g, int epi) {
     if (epi == EPI_BIAS && g.ldc % 4 != 0) return false;
     if (epi == EPI_D2S && (g.Cf % 4 != 0 || g.N != 8 * g.Cf)) return false;
     if ((double)g.N * g.K * 2.0 * 10.0 >= 4294967296.0) return false;          // 9 N K 2 and its differences stay inside 32 bits
-    return g.M > 512 && g.N >= 256 && ltx_gemm_big_fits(g);
+    // from 1024 output channels up: below that the halo-staged kernel (one staging of the activation per nine taps, tiles as wide as
+    // the output) is the better structure, and a plan is measured with a bias epilogue only - on one box the 256-channel stage's
+    // residual convs were handed to this kernel at 955 us against 755 (profiles/r5z_bench_c2_kernel_stats.md, launches 24-32)
+    return g.M > 512 && g.N >= 1024 && ltx_gemm_big_fits(g);
 }
 
 int ltx_launch_gemm_asm16_conv(const GemmArgs& g, int epi, hipStream_t s) {

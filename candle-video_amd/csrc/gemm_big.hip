@@ -648,7 +648,7 @@ std::mutex g_plan_mu;
 // it is used on (a stale or hand-edited plan file, or one saved under other LTX_* settings).
 bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
     if (plan >= kPlanRing) return plan < kPlanRing + ltx_gemm_ring_tiles() && N >= 32 && N % 4 == 0;
-    if (plan == kPlanAsm16Conv) return nk >= 2 && N >= 256 && N % 8 == 0;
+    if (plan == kPlanAsm16Conv) return nk >= 2 && N >= 1024 && N % 8 == 0;
     if (plan >= kPlanAsm16) return plan <= kPlanAsm16 + 2 && !split_shape && nk >= 2 && N >= 512 && N % 8 == 0;
     if (plan >= kPlanHalo) return plan <= kPlanHalo + 1 && !split_shape;
     if (plan >= kPlanP8) return plan <= kPlanP8 + 1 && !split_shape && nk >= 2 && N > 64 && !(plan == kPlanP8 && N <= 128);
@@ -712,7 +712,10 @@ int tune_plan(const GemmArgs& g_in, int epi, hipStream_t s, int fallback, int* p
             if ((int64_t)cdiv(g.M, ltx_gemm_ring_tile_bm(plan - kPlanRing)) * cdiv(g.N, ltx_gemm_ring_tile_bn(plan - kPlanRing)) * ltx_gemm_split_factor(g) > 768) continue;
         } else if (plan > kPlanAsm16Conv) { plan = kPlanRing - 1; continue; }
         else if (plan == kPlanAsm16Conv) {
-            if (asm16_off || !plan_ok(g, tepi, plan)) continue;
+            // a candidate from 1024 input channels up only: at 512 / 256 it ties with / loses to the halo-staged kernel in the
+            // pipeline (1637-1675 vs 1617-1623 us, 3572 vs 3365-3462) while back-to-back repeats of the measurement favour it
+            // (profiles/r5zz_bench_c2_kernel_stats.md, launches 22 and 33); gemm_plan=asm16c:256x256 still forces it
+            if (asm16_off || g.Cin < 1024 || !plan_ok(g, tepi, plan)) continue;
         } else if (plan >= kPlanAsm16 + 3) { plan = kPlanAsm16Conv - 1; continue; }
         else if (plan >= kPlanAsm16) {
             if (asm16_off || !plan_ok(g, tepi, plan)) continue;

@@ -88,8 +88,8 @@ def _cl(x): return x.permute(0, 2, 3, 4, 1).contiguous()
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout,causal,what", [
     (1, 13, 16, 24, 1024, 1024, False, "the VAE mid block at C2's latent size: the shape rule cuts K into three ranges = one frame tap each"),
     (1, 5, 33, 48, 128, 1152, False, "unsplit, ragged in M (30.9 tiles) and N (4.5 tiles)"),
-    (2, 3, 20, 20, 192, 512, True, "batch of two, causal padding, eight K ranges that start inside a frame tap and inside a channel slice"),
-    (1, 4, 9, 31, 64, 256, False, "one 64-channel slice, planes narrower than a tile row"),
+    (2, 3, 20, 20, 192, 1024, True, "batch of two, causal padding, K ranges that start inside a frame tap and inside a channel slice"),
+    (1, 4, 9, 31, 64, 1024, False, "one 64-channel slice, planes narrower than a tile row"),
 ])
 def test_asm16_conv_mode_bit_identical_to_gemm_big(hip, B, T, H, W, Cin, Cout, causal, what):
     """gemm_asm16_conv_kernel (the generated loop in conv mode: A rows re-staged per tap, validity masks and tap offsets rebuilt per
