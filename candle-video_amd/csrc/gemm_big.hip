@@ -657,7 +657,7 @@ bool plan_shape_ok(int plan, int N, int nk, bool split_shape) {
 bool plan_ok(const GemmArgs& g, int epi, int plan) {
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     if (!plan_shape_ok(plan, g.N, nk, ltx_gemm_split_factor(g) > 1)) return false;
-    if (plan >= kPlanRing) return ltx_gemm_ring_fits(g, epi);
+    if (plan >= kPlanRing) return ltx_gemm_ring_tile_fits(g, epi, plan - kPlanRing);
     if (plan == kPlanAsm16Conv) return ltx_gemm_asm16_conv_fits(g, epi);
     if (plan >= kPlanAsm16) return ltx_gemm_asm16_fits(g, epi);
     if (plan >= kPlanHalo) return true;                    // run_plan checks the halo kernel's own eligibility (epilogue-dependent)
@@ -830,7 +830,7 @@ extern "C" int ltx_plan_load(const char* path) {
             GemmArgs g; g.M = key.M; g.N = key.N; g.K = key.K; g.conv = kconv ? 1 : 0; g.ntaps = kconv ? key.ntaps : 1;
             const int nk = (key.K + 63) / 64 * g.ntaps;
             const bool dims_ok = key.M > 0 && key.N > 0 && key.K > 0 && key.conv >= 0 && key.conv <= 3 && (!kconv || (key.ntaps > 0 && key.T > 0 && key.H > 0 && key.W > 0)) && (key.conv != 3 || plan >= kPlanRing);
-            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && (kconv || key.K % 8 || key.M > 2048)) || (plan == kPlanAsm16Conv && (!kconv || key.ntaps != 27 || key.K % 64)) || (plan >= kPlanAsm16 && plan < kPlanAsm16Conv && (kconv || key.conv == 3 || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!kconv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
+            if (!dims_ok || !plan_shape_ok(plan, key.N, nk, ltx_gemm_split_factor(g) > 1) || (plan >= kPlanRing && ((kconv && (key.ntaps != 27 || key.conv == 2 || ltx_gemm_ring_tile_bn(plan - kPlanRing) < 64)) || key.K % 8 || key.M > 2048)) || (plan == kPlanAsm16Conv && (!kconv || key.ntaps != 27 || key.K % 64)) || (plan >= kPlanAsm16 && plan < kPlanAsm16Conv && (kconv || key.conv == 3 || key.K % 64)) || (plan >= kPlanHalo && plan < kPlanAsm16 && (!kconv || key.ntaps != 27 || key.K % 64 || key.N % (plan == kPlanHalo ? 128 : 256)))) {
                 fclose(f); LTX_FAIL(LTX_ERR_ARG, std::string("ltx_plan_load: plan not valid for its shape: ") + line);
             }
         }
@@ -882,7 +882,12 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
     if (forced == kPlanAsm16Conv) return ltx_launch_gemm_asm16_conv(g, epi, s);
     if (split_shape) {                                     // gemm_big tiles (or gemm_ring's, which keep their K partition): one partition whatever the plan
         int plan = ltx_gemm_big_pick_tile(g.M, g.N);
-        if (!big_forced) (void)cached_or_tuned_plan(g, epi, s, &plan);
+        if (!big_forced) {
+            // static model: convs over planes of at most 512 voxels (C1's mid block, an edge tile of the tiled decode) on the deep ring
+            // (72 -> 41 us at 384 voxels x 1024 channels, profiles/r5l_ring_conv_probe.jsonl)
+            if (g.conv && g.M <= 512 && ltx_gemm_ring_fits(g, epi)) plan = kPlanRing + ltx_gemm_ring_pick_tile(g);
+            (void)cached_or_tuned_plan(g, epi, s, &plan);
+        }
         if (plan >= kPlanRing && plan_ok(g, epi, plan)) return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
         if (plan == kPlanAsm16Conv && plan_ok(g, epi, plan)) return ltx_launch_gemm_asm16_conv(g, epi, s);
         if (plan >= kPlanP8) plan = ltx_gemm_big_pick_tile(g.M, g.N);     // (includes the halo and asm16 families)

@@ -48,8 +48,9 @@ __device__ unsigned g_ring_trace[1024 * 8];
 #define RSTAMP(i)
 #endif
 
-template <int BM, int BN, int NS, int EPI, bool SPEC>
+template <int BM, int BN, int NS, int EPI, bool SPEC, bool CONV = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmArgs g) {
+    static_assert(!CONV || SPEC, "conv mode: the stage bookkeeping lives in the producer waves");
     RSTAMP(0);
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16, NM = FM * FN;
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
     }
     const int mt = bid % ntm, rest = bid / ntm, part = rest % sf, nt = rest / sf;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = (g.K + 63) / 64;
+    const int ktiles = (g.K + 63) / 64;
+    const int nk = ktiles * (CONV ? g.ntaps : 1);        // conv: K-steps in the shared order (frame tap, 64-channel slice, in-plane tap)
     const int kt0 = sf > 1 ? (int)((int64_t)part * nk / sf) : 0, kt1 = sf > 1 ? (int)((int64_t)(part + 1) * nk / sf) : nk;
     const int n = kt1 - kt0;
 
@@ -85,24 +87,60 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
     // writes 16 bytes: row lr = lane >> 3, physical chunk pc = lane & 7 holds logical chunk pc ^ ((row >> 1) & 7)
     const int lr = lane >> 3, pc = lane & 7;
     uint32_t voff[P]; int klim[P];                                  // klim: first K position at which the lane's 16-byte chunk lies outside K
+    // conv mode (gemm_big.hip's addressing): an activation row is a voxel of the channels-last tensor, a K-step reads it shifted
+    // by a tap; ct = its frame (replicate padding clamps ct + dt, vae.rs:374-413), vmask = which of the 3 x 3 in-plane
+    // neighbours exist (zero padding: the others are out-of-range pieces, vae.rs:337-349)
+    int ct[CONV ? PA : 1], vmask[CONV ? PA : 1]; (void)ct; (void)vmask;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const bool isa = j < PA;
         const int row = 8 * (4 * (isa ? j : j - PA) + cw) + lr;
         const int chunk = pc ^ ((row >> 1) & 7);
         klim[j] = g.K - chunk * 8;
-        if (isa) { int m = m0 + row; if (m > g.M - 1) m = g.M - 1; voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk * 8) * 2u; }
+        if (isa) {
+            int m = m0 + row; if (m > g.M - 1) m = g.M - 1;
+            if constexpr (CONV) {
+                const int w = m % g.Wd, t1 = m / g.Wd, h = t1 % g.H, t2 = t1 / g.H;
+                ct[j] = t2 % g.T;
+                vmask[j] = (h > 0 ? 1 : 0) | 2 | (h < g.H - 1 ? 4 : 0) | (w > 0 ? 8 : 0) | 16 | (w < g.Wd - 1 ? 32 : 0);
+                voff[j] = ((uint32_t)m * (uint32_t)g.Cin + chunk * 8) * 2u;
+            } else voff[j] = ((uint32_t)m * (uint32_t)g.lda + chunk * 8) * 2u;
+        }
         else {
             int c = n0 + row; if (c > g.N - 1) c = g.N - 1;
             if (packed) { voff[j] = (uint32_t)(c >> 5) * (uint32_t)nk * 4096u + (uint32_t)(c & 31) * 128u + chunk * 16u; klim[j] = 0x3fffffff; }   // (K is zero padded there)
             else voff[j] = ((uint32_t)c * (uint32_t)g.K + chunk * 8) * 2u;
         }
     }
-    auto issue_piece = [&](int kpos, uint32_t kstep, unsigned char* base, auto j_tag) {
+    // what a stage's pieces share (wave-uniform): the K position its chunks are tested against, the scalar offsets of the two
+    // operands, and in conv mode the tap (frame delta, the validity bits it needs, its byte distance inside the plane)
+    struct Stg { int kpos; uint32_t a_soff, b_soff; int dt, vbit; };
+    const uint32_t frame_bytes = CONV ? (uint32_t)g.H * g.Wd * g.Cin * 2u : 0u;
+    auto stage_of = [&](int i) {
+        Stg c; c.dt = 0; c.vbit = 0;
+        if (i >= n) { c.kpos = 0x40000000; c.a_soff = 0u; c.b_soff = 0u; return c; }      // a dead stage lies beyond every klim
+        const int kt = kt0 + i;
+        if constexpr (CONV) {
+            const int per_it = ktiles * 9, it = kt / per_it, r2 = kt - it * per_it, kk = r2 / 9, hw = r2 - kk * 9;
+            const int ih = hw / 3, iw = hw - ih * 3, dh = ih - 1, dw = iw - 1;
+            c.kpos = kk * 64;
+            c.dt = it - g.pad_t;
+            c.vbit = (1 << (dh + 1)) | (8 << (dw + 1));
+            c.a_soff = (uint32_t)kk * 128u + (uint32_t)((dh * g.Wd + dw) * g.Cin * 2);     // may be "negative": added modulo 2^32 to the lane offset
+            c.b_soff = ((uint32_t)(it * 9 + hw) * (uint32_t)g.N * (uint32_t)g.K + (uint32_t)kk * 64u) * 2u;
+        } else { c.kpos = kt * 64; c.a_soff = (uint32_t)kt * 128u; c.b_soff = (uint32_t)kt * w_step; }
+        return c;
+    };
+    auto issue_piece = [&](const Stg& c, unsigned char* base, auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         constexpr bool isa = j < PA;
-        const uint32_t soff = kstep * (isa ? 128u : w_step);
-        uint32_t vo = kpos < klim[j] ? voff[j] : OOB;
+        uint32_t vo = c.kpos < klim[j] ? voff[j] : OOB;
+        uint32_t soff = isa ? c.a_soff : c.b_soff;
+        if constexpr (CONV && isa) {
+            int tt = ct[j] + c.dt; tt = tt < 0 ? 0 : (tt > g.T - 1 ? g.T - 1 : tt);
+            vo = (c.kpos < klim[j] && (vmask[j] & c.vbit) == c.vbit) ? voff[j] + (uint32_t)(tt - ct[j]) * frame_bytes + c.a_soff : OOB;
+            soff = 0u;
+        }
 #if RING_ABL & 4
         vo = lane * 16;
 #endif
@@ -110,9 +148,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(isa ? ra : rw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, (int)soff, 0, 0);
     };
     auto issue = [&](int i, int slot) {                             // stage i of this block's K range into ring slot `slot`, all pieces
-        const int kpos = i < n ? (kt0 + i) * 64 : 0x40000000;       // a dead stage lies beyond every klim
-        const uint32_t kstep = i < n ? (uint32_t)(kt0 + i) : 0u;
-        sfor_r<0, P>([&](auto j) { issue_piece(kpos, kstep, ring_smem + slot * STAGE, j); });
+        const Stg c = stage_of(i);
+        sfor_r<0, P>([&](auto j) { issue_piece(c, ring_smem + slot * STAGE, j); });
     };
 
     f32x4 acc[FM][FN];
@@ -210,13 +247,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
             if constexpr (SPEC) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NS - 2) * P) : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const int kpos = i + NS < n ? (kt0 + i + NS) * 64 : 0x40000000;
-            const uint32_t soff = i + NS < n ? (uint32_t)(kt0 + i + NS) : 0u;       // (the K-step; issue_piece scales it per operand)
+            const Stg nxt = SPEC ? Stg{} : stage_of(i + NS);
             unsigned char* const base = ring_smem + slot * STAGE;
             sfor_r<0, NSLOT>([&](auto t) {                          // (!SPEC) stage i + NS into the slot just freed, its pieces spread over the MFMAs
                 constexpr int k = decltype(t)::value;
                 if constexpr (k < FN + FM) read_frag(nslot, 0, t, w0, a0);
-                if constexpr (!SPEC && k < P) issue_piece(kpos, soff, base, t);
+                if constexpr (!SPEC && k < P) issue_piece(nxt, base, t);
                 if constexpr (k < NM) mma(t, w1, a1);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -348,11 +384,11 @@ const RingTile kRing[] = {
 };
 constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 
-template <int BM, int BN, int NS, int EPI, bool SPEC>
+template <int BM, int BN, int NS, int EPI, bool SPEC, bool CONV = false>
 int launch_ring(const GemmArgs& g, hipStream_t s) {
     constexpr int smem = NS * (BM + BN) * ROWB;
     static std::atomic<unsigned long long> attr_devs{0};
-    auto kern = gemm_ring_kernel<BM, BN, NS, EPI, SPEC>;
+    auto kern = gemm_ring_kernel<BM, BN, NS, EPI, SPEC, CONV>;
     LTX_TRY(ltx_set_max_dyn_smem(attr_devs, reinterpret_cast<const void*>(kern), smem));
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     GemmArgs ga = g;
@@ -366,13 +402,21 @@ int launch_ring(const GemmArgs& g, hipStream_t s) {
 template <int BM, int BN, int NS>
 int launch_ring_epi(const GemmArgs& g, int epi, hipStream_t s) {
 #ifdef LTX_EXPERIMENTS     // x_gemm_ring_spec=0: every wave loads and multiplies (256 threads), the first form of the kernel (A/B aid)
-    if (!ltx_exp("gemm_ring_spec", 1)) switch (epi) {
+    if (!g.conv && !ltx_exp("gemm_ring_spec", 1)) switch (epi) {
         case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, false>(g, s);
         case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, false>(g, s);
         case EPI_GATE_RESID: return launch_ring<BM, BN, NS, EPI_GATE_RESID, false>(g, s);
         case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, false>(g, s);
     }
 #endif
+    if constexpr (BN >= 64) {      // conv mode (3 x 3 x 3 convs over planes of a few hundred voxels): the tiles of at least 64 columns, bias / residual epilogues
+        if (g.conv) switch (epi) {
+            case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, true, true>(g, s);
+            case EPI_RESID: return launch_ring<BM, BN, NS, EPI_RESID, true, true>(g, s);
+            default: LTX_FAIL(LTX_ERR_ARG, "gemm_ring (conv): bad epilogue");
+        }
+    }
+    if (g.conv) LTX_FAIL(LTX_ERR_ARG, "gemm_ring (conv): tile not available");
     switch (epi) {
         case EPI_BIAS: return launch_ring<BM, BN, NS, EPI_BIAS, true>(g, s);
         case EPI_GELU: return launch_ring<BM, BN, NS, EPI_GELU, true>(g, s);
@@ -415,16 +459,27 @@ int ltx_gemm_ring_tile_bm(int i) { return i >= 0 && i < kNumRing ? kRing[i].bm :
 int ltx_gemm_ring_tile_bn(int i) { return i >= 0 && i < kNumRing ? kRing[i].bn : 1; }
 
 // Linear layers of at most 2048 rows (the plan measurement offers the family up to 512: ltx_gemm_split_factor) whose operands the 32-bit buffer offsets reach (gemm_big's own bound), K in whole 16-byte
-// chunks, 4-column output groups inside or outside N as a whole.
+// chunks, 4-column output groups inside or outside N as a whole.  Conv mode: 3 x 3 x 3 convs over at most 2048 voxels (the VAE's
+// first stages at C1's 4 x 8 x 12 latent, the edge tiles of the tiled decode), bias / residual epilogues, the whole activation
+// inside the 32-bit offsets.
 bool ltx_gemm_ring_fits(const GemmArgs& g, int epi) {
     if (ltx_opt().gemm_off & LTX_FAM_RING) return false;
-    if (g.conv || g.pn_on || g.M < 1 || g.M > 2048 || g.N < 32 || g.N % 4 || g.K % 8 || g.lda % 8) return false;
+    if (g.pn_on || g.M < 1 || g.M > 2048 || g.N < 32 || g.N % 4 || g.K % 8) return false;
+    if (g.conv) {
+        if (g.ntaps != 27 || g.kh != 3 || g.kw != 3 || g.K != g.Cin || g.N < 64 || g.defer_parts || g.rowsq || g.c_seg_shift) return false;
+        if (epi != EPI_BIAS && epi != EPI_RESID) return false;
+        if (g.T < 1 || g.H < 1 || g.Wd < 1 || g.M % (g.T * g.H * g.Wd) != 0 || ((uintptr_t)g.A & 15)) return false;
+        if ((double)g.M * g.Cin * 2.0 >= 2147483648.0 || g.ldc % 4 != 0) return false;
+    } else if (g.lda % 8) return false;
     if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     // the epilogue's prefetch loads 8 bytes of the residual row and 16 bytes of the gate row per lane (gemm_asm16's conditions)
     if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
     if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
     if (g.bias && ((uintptr_t)g.bias & 7)) return false;
     return ltx_gemm_big_fits(g);
+}
+bool ltx_gemm_ring_tile_fits(const GemmArgs& g, int epi, int tile) {
+    return tile >= 0 && tile < kNumRing && ltx_gemm_ring_fits(g, epi) && (!g.conv || kRing[tile].bn >= 64);
 }
 
 // Deferred reduction (GemmArgs::defer_parts) is this kernel's: bf16 linear layers of at most 512 rows that the ring serves, N in
@@ -436,7 +491,7 @@ bool ltx_gemm_defer_ok(const GemmArgs& g_in, int epi) {
 }
 
 int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s) {
-    if (!ltx_gemm_ring_fits(g, epi)) LTX_FAIL(LTX_ERR_ARG, "gemm_ring: shape not eligible");
+    if (!ltx_gemm_ring_tile_fits(g, epi, tile)) LTX_FAIL(LTX_ERR_ARG, "gemm_ring: shape not eligible");
     switch (tile) {
         case 0: return launch_ring_epi<96, 64, 8>(g, epi, s);
         case 1: return launch_ring_epi<96, 96, 6>(g, epi, s);
@@ -458,6 +513,7 @@ int ltx_gemm_ring_pick_tile(const GemmArgs& g) {
     const int sf = ltx_gemm_split_factor(g);
     double best = 1e30; int bi = 1;
     for (int i = 0; i < kNumRing; ++i) {
+        if (g.conv && kRing[i].bn < 64) continue;
         const int64_t blocks = (int64_t)cdiv(g.M, kRing[i].bm) * cdiv(g.N, kRing[i].bn) * sf;
         // a block's time ~ its bytes through the CU's load path, (bm + bn) per K element
         const double cost = (double)cdiv64(blocks, 256) * (double)(kRing[i].bm + kRing[i].bn);

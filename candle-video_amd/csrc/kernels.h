@@ -99,6 +99,7 @@ bool ltx_gemm_p8_fits(const GemmArgs& g);
 // gemm_ring.hip: small-M linear layers on small tiles with a deep ring of LDS stages (plan family ring:*); same K partition and
 // summation order as gemm_big (the split workspace below is gemm_big's: slabs + ticket counters per (device, stream))
 bool ltx_gemm_ring_fits(const GemmArgs& g, int epi);
+bool ltx_gemm_ring_tile_fits(const GemmArgs& g, int epi, int tile);      // conv mode runs on the tiles of at least 64 columns
 int ltx_launch_gemm_ring(const GemmArgs& g, int epi, int tile, hipStream_t s);
 int ltx_gemm_ring_tiles();
 const char* ltx_gemm_ring_tile_name(int i);

@@ -30,7 +30,7 @@ struct LtxOptions {
     int norm_lean = 1;            // 0: the general presum kernel (same bits as the lean one)
     int xattn_compact = 1;        // 0: cross attention multiplies every text key
     int dense_qkv = 1;            // 0: q | k | v as column slices of one [M, 3D] matrix
-    int vae_fuse_norm = 1;        // 0: the resnet's second norm as its own pass
+    int vae_fuse_norm = 1;        // 0: the resnet's second norm as its own pass; 2: fused on grids below one round of the chip too (tests)
     int t5_attn_mfma = 1;         // 0: the scalar T5 attention kernel
     unsigned attn_off = 0;        // attention kernels left out: "q64+q128+cross+pipe" (the next more general kernel serves)
     // gemm_off bit LTX_FAM_BIG: gemm.hip's 128 x 128 kernel for everything (un-split K)

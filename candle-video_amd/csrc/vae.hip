@@ -248,6 +248,10 @@ bool fuse_norm2(ltx_vae* v, const ConvW& cw, const Dims& d_all, int ch) {
     if (!o.vae_fuse_norm || !o.gemm_wide_epi || (o.gemm_off & (LTX_FAM_HALO | LTX_FAM_BIG))) return false;
     if (v->dtype != LTX_DT_BF16 || (ch != 128 && ch != 256) || cw.cout != ch) return false;
     const GemmArgs g = conv_args(v, cw, d);
+    // the fused epilogue needs the whole channel row in one tile (BN == channels), i.e. a grid of M / 256 blocks: below about
+    // one round of the chip the unfused conv on a plan with more, smaller tiles + the stand-alone norm is faster (C1's
+    // 256-channel stage, 78 tiles: 168 us fused vs 108 + 13; decode 5.7 -> 5.45 ms, profiles/r5k_c1_vae_fused_norm_ab.jsonl)
+    if ((g.M + 255) / 256 < 192 && o.vae_fuse_norm < 2) return false;
     return ltx_gemm_big_eligible(g, v->dtype) && ltx_conv_halo_eligible(g, EPI_BIAS, ch);
 }
 

@@ -266,7 +266,8 @@ int ltx_plan_load(const char* path);
  *   norm_presum=0 | 2      row-reducing RMS norms | sums of squares from the producing GEMM whatever the shape
  *   xattn_compact=0        cross attention multiplies every text key (differs from the default only for non-prefix masks)
  *   dense_qkv=0            q | k | v as column slices of one [M, 3D] matrix (same bits; another memory layout)
- *   vae_fuse_norm=0        the resnet's second norm as its own pass
+ *   vae_fuse_norm=0        the resnet's second norm as its own pass (1, default: fused where the conv's grid is about one round of
+ *                          the chip or more; 2: fused on smaller grids too)
  *   t5_attn_mfma=0         the scalar T5 attention kernel
  *   attn_off=a+b           attention kernels left out: q64, q128, cross, pipe (the next more general kernel serves)
  * Measured-negative experiments and tuning knobs ("x_name=int") exist only in builds made with -DLTX_EXPERIMENTS

@@ -22,14 +22,14 @@ def hip():
     return ltxhip
 
 
-def _arms(hip, tile, fn):
-    """fn() on gemm_big's static tile (ring family off, plan cache bypassed), then on the forced ring tile."""
-    with hip.options(gemm_off="ring+asm16", gemm_tune="0"):
+def _arms(hip, tile, fn, kind=0):
+    """fn() on gemm_big's static tile (every other family off, plan cache bypassed), then on the forced ring tile (kind: 0 linear, 1 conv)."""
+    with hip.options(gemm_off="ring+asm16+halo+p8", gemm_tune="0"):
         ref = fn(False)
     with hip.options(gemm_plan=tile):
         hip.prof_enable(True)
         got = fn(True)
-        ms, _, cnt = hip.prof_report_kernel(0, hip.PROF_KERNELS.index("gemm_ring_kernel"))
+        ms, _, cnt = hip.prof_report_kernel(kind, hip.PROF_KERNELS.index("gemm_ring_kernel"))
         hip.prof_enable(False)
     torch.cuda.synchronize()
     assert cnt >= 1, "the forced ring tile did not run"
@@ -149,3 +149,36 @@ def test_ring_fuzz_random_shapes_tiles_and_epilogues(hip):
         if epi == 0:
             ref32 = x.float() @ w.float().t() + (b.float() if b is not None else 0)
             assert (got.float() - ref32).norm() / ref32.norm() < 4e-3, (it, M, N, K, tile)
+
+
+def _cl(x): return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+CONV_TILES = [t for t in RING_TILES if int(t.split("x")[1]) >= 64]
+
+
+@pytest.mark.parametrize("tile", CONV_TILES)
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,causal,what", [
+    (1, 4, 8, 12, 1024, 1024, False, "the VAE mid block at C1's latent size (384 voxels): eight K ranges of 54 steps"),
+    (2, 2, 6, 8, 512, 1024, True, "an edge tile of the tiled decode, batch of two, causal padding"),
+    (1, 3, 5, 7, 192, 200, False, "ragged everywhere: 105 voxels, 200 output channels, three 64-channel slices"),
+    (1, 1, 16, 24, 128, 128, True, "one frame (every frame tap is the replicated frame), conv_in-like"),
+])
+def test_ring_conv_mode_bit_identical_to_gemm_big(hip, tile, B, T, H, W, Cin, Cout, causal, what):
+    """gemm_ring's conv mode (planes of a few hundred voxels: an activation row per voxel re-read per tap through the deep ring, the
+    tap bookkeeping in the producer waves) against gemm_big's conv mode: same K order, K partition and part sum -> the same bits,
+    with a bias and with a residual; and a convolution (f32 torch within the bf16 bar)."""
+    g = torch.Generator().manual_seed(B + T + H + W + Cin)
+    x = torch.randn(B, Cin, T, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).bfloat16(); b = torch.randn(Cout, generator=g).bfloat16()
+    r = torch.randn(B, Cout, T, H, W, generator=g).bfloat16()
+    xc, rc = _cl(x).cuda(), _cl(r).cuda()
+    ref, got = _arms(hip, tile, lambda forced: (hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal), hip.ops.conv3d(xc, w.cuda(), b.cuda(), causal, resid=rc)), kind=1)
+    for a, c in zip(got, ref):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16)), what
+    pad = (0, 0, 0, 0, 2, 0) if causal else (0, 0, 0, 0, 1, 1)
+    xp = torch.nn.functional.pad(x.float(), pad, mode="replicate")
+    want = torch.nn.functional.conv3d(xp, w.float(), b.float(), padding=(0, 1, 1))
+    e = float((got[0].float().cpu().permute(0, 4, 1, 2, 3) - want).norm() / want.norm())
+    assert e < 4e-3, (what, e)

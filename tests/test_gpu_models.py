@@ -125,6 +125,7 @@ def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch, blocks, laye
     outs = {}
     for dt in (torch.bfloat16, torch.float32):
         model = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**cfgd), wd, dt)
+        hip.set_option("vae_fuse_norm", "2")         # these planes are far below one round of the chip: the default would not fuse
         outs[dt] = model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu()
         if dt == torch.bfloat16:
             assert torch.equal(outs[dt], model.decode(z.to(DEV), torch.tensor([0.05])).float().cpu())
@@ -134,6 +135,7 @@ def test_vae_resnet_norm_fused_into_conv_epilogue(hip, monkeypatch, blocks, laye
                 sep_no_t = model.decode(z.to(DEV), None).float().cpu()
             assert rel_l2(outs[dt], sep) <= bar, rel_l2(outs[dt], sep)
             assert rel_l2(no_t, sep_no_t) <= bar
+            assert not torch.equal(outs[dt], sep)        # (the fused arm really ran the other algorithm)
         del model
     assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) <= 3e-2
 
