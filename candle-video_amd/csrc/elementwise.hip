@@ -191,6 +191,21 @@ __global__ void postprocess_kernel(float* x, int64_t n) {
     GRID_STRIDE(i, n) x[i] = fminf(fmaxf(x[i] * 0.5f + 0.5f, 0.0f), 1.0f) * 255.0f;   // t2v_pipeline.rs:146-155
 }
 
+// LtxVideoResnetBlock3d::maybe_inject_noise (vae.rs:741-753) on a channels-last tensor: y = x + noise[h, w] * scale[c], the
+// reference's roundings in the model dtype (noise cast first, the product rounded, the sum rounded), then optionally the block's
+// shortcut (vae.rs:811-819: result = h + x, one more rounding)
+template <typename T>
+__global__ void noise_inject_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ noise, const T* __restrict__ scale,
+                                    const T* __restrict__ resid, int64_t n, int C, int64_t HW) {
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C); const int64_t hw = (i / C) % HW;
+        const float p = to_f32((T)(to_f32((T)noise[hw]) * to_f32(scale[c])));
+        T v = (T)(to_f32(x[i]) + p);
+        if (resid) v = (T)(to_f32(v) + to_f32(resid[i]));
+        y[i] = v;
+    }
+}
+
 inline dim3 grid_for(int64_t n) { int64_t b = cdiv64(n, 256); if (b > 16384) b = 16384; if (b < 1) b = 1; return dim3((unsigned)b); }
 
 }  // namespace
@@ -198,6 +213,13 @@ inline dim3 grid_for(int64_t n) { int64_t b = cdiv64(n, 256); if (b > 16384) b =
 int ltx_launch_sinusoid(void* out, int dtype, const TimeVec& tv, const float* tab, int half, int round_t, float tmul, hipStream_t s) {
     if (tv.n < 1 || tv.n > LTX_MAX_BATCH) LTX_FAIL(LTX_ERR_ARG, "batch must be 1..16");
     hipLaunchKernelGGL(sinusoid_kernel, grid_for(tv.n * 2 * half), dim3(256), 0, s, out, dtype, tv, tab, half, round_t, tmul);
+    LTX_CHECK_LAUNCH(); return LTX_OK;
+}
+int ltx_launch_noise_inject(const void* x, void* y, const float* noise, const void* scale, const void* resid, int64_t rows, int C, int64_t HW, int dtype, hipStream_t s) {
+    if (!x || !y || !noise || !scale || rows < 1 || C < 1 || HW < 1 || rows % HW != 0) LTX_FAIL(LTX_ERR_ARG, "noise_inject: bad arguments");
+    const int64_t n = rows * C;
+    if (dtype == LTX_DT_BF16) hipLaunchKernelGGL(noise_inject_kernel<bf16_t>, grid_for(n), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, noise, (const bf16_t*)scale, (const bf16_t*)resid, n, C, HW);
+    else hipLaunchKernelGGL(noise_inject_kernel<float>, grid_for(n), dim3(256), 0, s, (const float*)x, (float*)y, noise, (const float*)scale, (const float*)resid, n, C, HW);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }
 int ltx_launch_silu(const void* x, void* y, int64_t n, int dtype, hipStream_t s) {

@@ -95,12 +95,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
         int t = t2 % g.T; int b = t2 / g.T;
         int s = nb / g.Cf, co = nb - s * g.Cf;
         int st = s >> 2, sh = (s >> 1) & 1, sw = s & 1;
-        int to = 2 * t + st - 1;
+        int to = g.d2s_sp ? t : 2 * t + st - 1;  // (1, 2, 2): s = sh*2 + sw, frames kept as they are (:1225-1236)
         if (to < 0) return;                      // drop first frame (:1161)
         if (g.resid) {
             const T* x = reinterpret_cast<const T*>(g.resid) + (int64_t)m * g.Cin;
+            const int nsub = g.d2s_sp ? 4 : 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += to_f32(x[((co + i) % g.Cr) * 8 + s]);
+            for (int i = 0; i < 4; ++i) v[i] += to_f32(x[((co + i) % g.Cr) * nsub + s]);
         }
         int64_t o = ((((int64_t)b * g.To + to) * g.Ho + (2 * h + sh)) * g.Wo + (2 * w + sw)) * g.Cf + co;
         store4<T>(C + o, v);

@@ -45,6 +45,7 @@ struct GemmArgs {
     int ntaps = 1, kh = 1, kw = 1, pad_t = 0;   // pad_t: frames of left temporal replicate padding
     // D2S / UNPATCH
     int Cf = 0, Cr = 0, To = 0, Ho = 0, Wo = 0, post = 0;
+    int d2s_sp = 0;                 // EPI_D2S: 1 = the spatial-only (1, 2, 2) depth-to-space of an up-block without temporal scaling (N = 4 Cf, To = T, no frame dropped; vae.rs:1225-1236)
     // EPI_BIAS only: output split into column segments of width 1 << c_seg_shift, segment j a dense [M, ldc] matrix at
     // C + j * c_seg_stride elements (fused q|k|v projection -> three contiguous matrices); 0 = one [M, ldc] matrix
     int c_seg_shift = 0; int64_t c_seg_stride = 0;
@@ -202,6 +203,8 @@ struct TimeVec { float t[LTX_MAX_BATCH]; int n; };
 int ltx_launch_gguf_dequant(const void* blocks_dev, int ggml_type, int64_t numel, void* dst, int dst_dtype, hipStream_t s);
 int ltx_launch_sinusoid(void* out, int dtype, const TimeVec& tv, const float* tab, int half, int round_t, float tmul, hipStream_t s);
 int ltx_launch_silu(const void* x, void* y, int64_t n, int dtype, hipStream_t s);
+// y = x + noise[hw] * scale[c] (+ resid), channels-last [rows = B T HW, C], the roundings of vae.rs:741-753 in the model dtype
+int ltx_launch_noise_inject(const void* x, void* y, const float* noise, const void* scale, const void* resid, int64_t rows, int C, int64_t HW, int dtype, hipStream_t s);
 int ltx_launch_cast(const void* x, int xdt, void* y, int ydt, int64_t n, hipStream_t s);
 // ada[l][b][j] = table_l[j] + temb[b][j]  (j < width), tables given as nl pointers packed contiguously [nl][width] (T), out f32
 int ltx_launch_ada(float* out, const void* tables, const void* temb, int nl, int B, int width, int dtype, hipStream_t s);

@@ -16,14 +16,17 @@
 #include "model_util.h"
 #include "options.h"
 
+extern "C" int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out_host);   // host/pipeline.hip (utils/deterministic_rng.rs)
+
 struct ConvW {
     void* w = nullptr;   // [27][N][Cin] model dtype (N possibly permuted)
     void* b = nullptr;   // [N]
     int cin = 0, cout = 0;
+    int nsub = 8;        // depth-to-space convs: output channels per final channel, 8 = (2, 2, 2), 4 = (1, 2, 2)
 };
 struct TimeEmbW { LinearW l1, l2; int dim = 0; };
-struct ResnetW { ConvW c1, c2; void* sst = nullptr; };
-struct UpBlockW { ConvW up; TimeEmbW te; std::vector<ResnetW> res; int ch = 0, cin = 0; bool residual = true; };
+struct ResnetW { ConvW c1, c2; void* sst = nullptr; void *pcs1 = nullptr, *pcs2 = nullptr; };   // pcs: per_channel_scale{1,2} [C] where the block injects noise (vae.rs:676-689)
+struct UpBlockW { ConvW up; TimeEmbW te; std::vector<ResnetW> res; int ch = 0, cin = 0; bool residual = true, temporal = true; };
 
 struct ltx_vae {
     ltx_vae_config cfg{};
@@ -43,11 +46,15 @@ struct ltx_vae {
     // timestep alone (a pipeline decodes every video at the same decode_timestep), 5 launches per resnet when recomputed
     struct ModEntry { const void* sst = nullptr; float t[LTX_MAX_BATCH] = {0}; int n = 0; hipStream_t stream = nullptr; uint64_t used = 0; DevBuf buf; };
     std::deque<ModEntry> mods; uint64_t mod_clock = 0;
+    // noise injection (vae.rs:741-753): the reference draws an [H, W] plane from the device RNG per injection; here plane k of the
+    // handle's life is Pcg32::new(noise_seed, k).randn(H * W) (utils/deterministic_rng.rs), k restarted by ltx_vae_set_noise_seed
+    uint64_t noise_seed = 0, noise_ctr = 0; bool any_inject = false;
+    DevBuf noise_plane; std::vector<float> noise_host;
     size_t act_bytes_reserved() const { return X.bytes + Y.bytes + N.bytes + C.bytes; }   // activation buffers a decoder call re-uses
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats, &predec};
+        DevBuf* bs[] = {&zin, &X, &Y, &N, &C, &tproj, &e1, &te, &mod, &tiles[0], &tiles[1], &tile_lat, &stats, &predec, &noise_plane};
         for (DevBuf* b : bs) b->release();
         for (auto& b : tilebufs) b.release();
         for (auto& e : mods) e.buf.release();
@@ -60,12 +67,12 @@ namespace {
 enum { PERM_NONE = LTX_PERM_NONE, PERM_D2S = LTX_PERM_D2S, PERM_UNPATCH = LTX_PERM_UNPATCH };
 
 // dst[tap][n'][i] = src[o][i][tap] ; bias'[n'] = bias[o]
-__global__ void pack_conv_kernel(const void* src, int sdt, void* dst, int ddt, int O, int I, int ntaps, int mode, int Cf) {
+__global__ void pack_conv_kernel(const void* src, int sdt, void* dst, int ddt, int O, int I, int ntaps, int mode, int Cf, int nsub) {
     const int64_t n = (int64_t)O * I * ntaps;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         int i = (int)(idx % I); int64_t r = idx / I; int np = (int)(r % O); int tap = (int)(r / O);
         int o = np;
-        if (mode == PERM_D2S) { int s = np / Cf, c = np - s * Cf; o = c * 8 + s; }                    // n' = s*Cf + c'
+        if (mode == PERM_D2S) { int s = np / Cf, c = np - s * Cf; o = c * nsub + s; }                 // n' = s*Cf + c' (nsub = 8: (2,2,2), 4: (1,2,2))
         else if (mode == PERM_UNPATCH) { int c = np >> 4, oh = (np >> 2) & 3, ow = np & 3; o = (c * 4 + ow) * 4 + oh; }  // n' = (c*4+oh)*4+ow
         float v = sdt == LTX_DT_BF16 ? (float)reinterpret_cast<const bf16_t*>(src)[((int64_t)o * I + i) * ntaps + tap]
                                      : reinterpret_cast<const float*>(src)[((int64_t)o * I + i) * ntaps + tap];
@@ -88,8 +95,9 @@ __global__ void cl_window_kernel(const unsigned char* src, unsigned char* dst, i
 
 }  // namespace
 int ltx_pack_conv(const void* src_dev, int sdt, void* dst, int ddt, int O, int I, int ntaps, int mode, int Cf, hipStream_t s) {
+    const int nsub = (mode == PERM_D2S && Cf > 0) ? O / Cf : 8;
     int64_t n = (int64_t)O * I * ntaps; int64_t blocks = cdiv64(n, 256); if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src_dev, sdt, dst, ddt, O, I, ntaps, mode, Cf);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src_dev, sdt, dst, ddt, O, I, ntaps, mode, Cf, nsub);
     LTX_CHECK_LAUNCH();
     return LTX_OK;
 }
@@ -97,6 +105,8 @@ namespace {
 int load_conv(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int cin, int cout, int mode, int Cf, ConvW* c) {
     const int dt = v->dtype; const size_t esz = ltx_dt_size(dt);
     c->cin = cin; c->cout = cout;
+    const int nsub = (mode == PERM_D2S && Cf > 0) ? cout / Cf : 8;
+    c->nsub = nsub;
     const ltx_weight* w = wm.find(prefix + ".conv.weight");
     const ltx_weight* b = wm.find(prefix + ".conv.bias");
     if (!w) LTX_FAIL(LTX_ERR_MISSING_WEIGHT, "missing weight '" + prefix + ".conv.weight'");
@@ -109,12 +119,12 @@ int load_conv(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int ci
     LTX_TRY(ltx_stage_src(w, &src, &tmp));
     int64_t n = (int64_t)cout * cin * 27; int64_t blocks = cdiv64(n, 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, src, w->dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32,
-                       c->w, dt, cout, cin, 27, mode, Cf);
+                       c->w, dt, cout, cin, 27, mode, Cf, nsub);
     hipError_t e = hipDeviceSynchronize(); if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) { ltx_set_error(std::string("pack conv: ") + hipGetErrorString(e)); return LTX_ERR_HIP; }
     LTX_TRY(ltx_stage_src(b, &src, &tmp));
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)cdiv(cout, 256)), dim3(256), 0, 0, src, b->dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32,
-                       c->b, dt, cout, 1, 1, mode, Cf);
+                       c->b, dt, cout, 1, 1, mode, Cf, nsub);
     e = hipDeviceSynchronize(); if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) { ltx_set_error(std::string("pack bias: ") + hipGetErrorString(e)); return LTX_ERR_HIP; }
     return LTX_OK;
@@ -129,9 +139,20 @@ int load_temb(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int di
     return LTX_OK;
 }
 
-int load_resnet(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int ch, ResnetW* r) {
+int load_resnet(ltx_vae* v, const WeightMap& wm, const std::string& prefix, int ch, bool inject, ResnetW* r) {
     LTX_TRY(load_conv(v, wm, prefix + ".conv1", ch, ch, PERM_NONE, 0, &r->c1));
     LTX_TRY(load_conv(v, wm, prefix + ".conv2", ch, ch, PERM_NONE, 0, &r->c2));
+    if (inject) {
+        // vae.rs:676-689: vb.pp("per_channel_scaleN").get((C, 1, 1), "weight").ok() - a scale that is absent from the checkpoint
+        // under exactly that name is no injection, not an error
+        for (int k = 0; k < 2; ++k) {
+            const std::string nm = prefix + ".per_channel_scale" + std::to_string(k + 1) + ".weight";
+            if (!wm.find(nm)) continue;
+            void** dst = k ? &r->pcs2 : &r->pcs1;
+            LTX_TRY(ltx_load_tensor(wm, nm, ch, v->dtype, dst)); v->owned.push_back(*dst);
+            v->any_inject = true;
+        }
+    }
     if (v->cfg.timestep_conditioning) {
         LTX_TRY(ltx_load_tensor(wm, prefix + ".scale_shift_table", 4 * (int64_t)ch, v->dtype, &r->sst));
         v->owned.push_back(r->sst);
@@ -161,7 +182,7 @@ int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
     LTX_TRY(load_conv(v, wm, "conv_in", c.latent_channels, v->mid_ch, PERM_NONE, 0, &v->conv_in));
     if (c.timestep_conditioning) LTX_TRY(load_temb(v, wm, "mid_block.time_embedder", 4 * v->mid_ch, &v->mid_te));
     v->mid.resize(lpb[0]);
-    for (int i = 0; i < lpb[0]; ++i) LTX_TRY(load_resnet(v, wm, "mid_block.resnets." + std::to_string(i), v->mid_ch, &v->mid[i]));
+    for (int i = 0; i < lpb[0]; ++i) LTX_TRY(load_resnet(v, wm, "mid_block.resnets." + std::to_string(i), v->mid_ch, c.decoder_inject_noise[nb] != 0, &v->mid[i]));   // inject list reversed: entry nb is the mid block (vae.rs:1514-1515, 1541)
     v->ups.resize(nb);
     int cur = v->mid_ch;
     for (int bi = 0; bi < nb; ++bi) {
@@ -171,11 +192,13 @@ int build(ltx_vae* v, const ltx_weight* weights, size_t n_weights) {
         u.ch = boc[bi] / upf[bi];                       // vae.rs:1548
         u.cin = u.ch * upf[bi];                         // upsampler in-channels (vae.rs:1215)
         if (u.cin != cur) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder up-block channel chain mismatch");
-        if ((u.ch * 8) % u.cin != 0 || u.cin % 8 != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "upsampler residual repeat must be integral");
-        LTX_TRY(load_conv(v, wm, p + ".upsamplers.0.conv", u.cin, u.ch * 8, PERM_D2S, u.ch, &u.up));
+        u.temporal = c.decoder_spatiotemporal_scaling[nb - 1 - bi] != 0;   // reversed too (vae.rs:1509-1510); false: the (1, 2, 2) upsampler (:1225-1236)
+        const int nsub = u.temporal ? 8 : 4;
+        if ((u.ch * nsub) % u.cin != 0 || u.cin % nsub != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "upsampler residual repeat must be integral");
+        LTX_TRY(load_conv(v, wm, p + ".upsamplers.0.conv", u.cin, u.ch * nsub, PERM_D2S, u.ch, &u.up));
         if (c.timestep_conditioning) LTX_TRY(load_temb(v, wm, p + ".time_embedder", 4 * u.ch, &u.te));
         u.res.resize(lpb[bi + 1]);
-        for (int i = 0; i < lpb[bi + 1]; ++i) LTX_TRY(load_resnet(v, wm, p + ".resnets." + std::to_string(i), u.ch, &u.res[i]));
+        for (int i = 0; i < lpb[bi + 1]; ++i) LTX_TRY(load_resnet(v, wm, p + ".resnets." + std::to_string(i), u.ch, c.decoder_inject_noise[nb - 1 - bi] != 0, &u.res[i]));   // inj[bi + 1] of the reversed list (vae.rs:1561)
         cur = u.ch;
     }
     v->last_ch = cur;
@@ -260,7 +283,8 @@ int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, i
     const int64_t per = (int64_t)d.T * d.H * d.W;
     const int nb = conv_chunk(v, cw, d);
     size_t out_b, res_b = 0;                              // bytes per sample of the output / residual tensor
-    if (epi == EPI_D2S) { out_b = (size_t)(2 * d.T - 1) * (2 * d.H) * (2 * d.W) * (cw.cout / 8) * esz; res_b = (size_t)per * cw.cin * esz; }
+    const int To = cw.nsub == 4 ? d.T : 2 * d.T - 1;      // frames a depth-to-space conv writes
+    if (epi == EPI_D2S) { out_b = (size_t)To * (2 * d.H) * (2 * d.W) * (cw.cout / cw.nsub) * esz; res_b = (size_t)per * cw.cin * esz; }
     else if (epi == EPI_UNPATCH) out_b = (size_t)(cw.cout / 16) * d.T * (4 * d.H) * (4 * d.W) * sizeof(float);
     else { out_b = (size_t)per * cw.cout * esz; res_b = out_b; }
     for (int b0 = 0; b0 < d.B; b0 += nb) {
@@ -277,7 +301,7 @@ int conv3d(ltx_vae* v, const ConvW& cw, const void* x, void* y, const Dims& d, i
         g.ntaps = 27; g.kh = 3; g.kw = 3;
         g.pad_t = v->cfg.decoder_causal ? 2 : 1;          // vae.rs:383-412
         g.post = post;
-        if (epi == EPI_D2S) { g.Cf = cw.cout / 8; g.Cr = cw.cin / 8; g.To = 2 * d.T - 1; g.Ho = 2 * d.H; g.Wo = 2 * d.W; }
+        if (epi == EPI_D2S) { g.Cf = cw.cout / cw.nsub; g.Cr = cw.cin / cw.nsub; g.To = To; g.Ho = 2 * d.H; g.Wo = 2 * d.W; g.d2s_sp = cw.nsub == 4; }
         LTX_TRY(ltx_launch_gemm(g, v->dtype, epi, s));
     }
     return LTX_OK;
@@ -306,6 +330,17 @@ int time_mod(ltx_vae* v, const TimeEmbW& te, const void* sst, const TimeVec& tv,
     return LTX_OK;
 }
 
+// one injection: the next plane of the handle's noise stream, y = x + plane[h, w] * scale[c] (+ shortcut)
+int inject_noise(ltx_vae* v, const void* x, void* y, const void* scale, const void* shortcut, const Dims& d, int ch, hipStream_t s) {
+    const int64_t hw = (int64_t)d.H * d.W;
+    v->noise_host.resize((size_t)hw);
+    LTX_TRY(ltx_pcg32_randn(v->noise_seed, v->noise_ctr++, (size_t)hw, v->noise_host.data()));
+    LTX_TRY(v->noise_plane.ensure((size_t)hw * sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(s));                       // the plane buffer and its host image are re-used by the next injection
+    HIP_TRY(hipMemcpyAsync(v->noise_plane.p, v->noise_host.data(), (size_t)hw * sizeof(float), hipMemcpyHostToDevice, s));
+    return ltx_launch_noise_inject(x, y, v->noise_plane.as<float>(), scale, shortcut, d.vox(), ch, hw, v->dtype, s);
+}
+
 int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims& d, const TimeVec* tv, hipStream_t s) {
     const int dt = v->dtype;
     const float* mod = nullptr;
@@ -316,7 +351,7 @@ int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims&
     LTX_TRY(ltx_launch_rownorm(rn, dt, s));
     // norm2 + modulation + SiLU inside conv1's epilogue where one conv tile spans all channels (128 / 256): no pass of
     // its own over the stage's largest tensor
-    if (fuse_norm2(v, r.c1, d, ch)) {
+    if (!r.pcs1 && !r.pcs2 && fuse_norm2(v, r.c1, d, ch)) {
         PostNorm pn; pn.on = 1; pn.eps = rn.eps; pn.act = 1; pn.mod_stride = 4 * ch;
         if (mod) { pn.shift = mod + 2 * ch; pn.scale = mod + 3 * ch; }
         LTX_TRY(conv3d(v, r.c1, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s, &pn));
@@ -324,9 +359,14 @@ int resnet(ltx_vae* v, const ResnetW& r, const TimeEmbW& te, int ch, const Dims&
         return LTX_OK;
     }
     LTX_TRY(conv3d(v, r.c1, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s));
+    if (r.pcs1) LTX_TRY(inject_noise(v, v->C.p, v->C.p, r.pcs1, nullptr, d, ch, s));        // vae.rs:784
     rn.x = v->C.p;
     if (mod) { rn.shift = mod + 2 * ch; rn.scale = mod + 3 * ch; }
     LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+    if (r.pcs2) {                                                                           // vae.rs:807-819: h = conv2(h); h += noise * scale; h + x
+        LTX_TRY(conv3d(v, r.c2, v->N.p, v->C.p, d, EPI_BIAS, nullptr, 0, s));
+        return inject_noise(v, v->C.p, v->X.p, r.pcs2, v->X.p, d, ch, s);
+    }
     LTX_TRY(conv3d(v, r.c2, v->N.p, v->X.p, d, EPI_RESID, v->X.p, 0, s));   // X = conv2(..) + X, in place
     return LTX_OK;
 }
@@ -340,7 +380,7 @@ int decoder_forward(ltx_vae* v, const void* z, int B, int F, int H, int W, const
     int64_t max_elems = d.vox() * v->mid_ch;
     {
         Dims q = d;
-        for (auto& u : v->ups) { q.T = 2 * q.T - 1; q.H *= 2; q.W *= 2; int64_t e = q.vox() * u.ch; if (e > max_elems) max_elems = e; }
+        for (auto& u : v->ups) { if (u.temporal) q.T = 2 * q.T - 1; q.H *= 2; q.W *= 2; int64_t e = q.vox() * u.ch; if (e > max_elems) max_elems = e; }
     }
     LTX_TRY(v->X.ensure(max_elems * esz)); LTX_TRY(v->Y.ensure(max_elems * esz));
     LTX_TRY(v->N.ensure(max_elems * esz)); LTX_TRY(v->C.ensure(max_elems * esz));
@@ -354,7 +394,8 @@ int decoder_forward(ltx_vae* v, const void* z, int B, int F, int H, int W, const
     for (auto& u : v->ups) {
         LTX_TRY(conv3d(v, u.up, v->X.p, v->Y.p, d, EPI_D2S, u.residual ? v->X.p : nullptr, 0, s));   // vae.rs:1164-1168
         std::swap(v->X, v->Y);
-        d.T = 2 * d.T - 1; d.H *= 2; d.W *= 2;
+        if (u.temporal) d.T = 2 * d.T - 1;
+        d.H *= 2; d.W *= 2;
         for (auto& r : u.res) LTX_TRY(resnet(v, r, u.te, u.ch, d, tvc, s));
     }
     // norm_out + global scale/shift + SiLU (vae.rs:1687-1723), conv_out + unpatchify
@@ -485,6 +526,7 @@ int batched_leaf_decode(ltx_vae* v, const void* z, int B, int F, int H, int W, c
     // many leaves, down to one.  Option vae_tile_batch=n: at most n leaves per call (-1: one).
     int max_n = LTX_MAX_BATCH / B; if (max_n < 1) max_n = 1;
     if (const int n_opt = ltx_opt().vae_tile_batch) max_n = n_opt < 0 ? 1 : std::min(max_n, n_opt);
+    if (v->any_inject) max_n = 1;        // a decoder call draws ONE noise plane per injection for its whole batch (vae.rs:741-753): leaves keep their own draws
     std::vector<char> done(leaves.size(), 0);
     float* cursor = v->predec.as<float>();
     for (size_t a = 0; a < leaves.size(); ++a) {
@@ -612,15 +654,6 @@ extern "C" int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weigh
         if (cfg->decoder_upsample_factor[i] < 1 || cfg->decoder_block_out_channels[i] % (8 * cfg->decoder_upsample_factor[i]) != 0)
             LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder channels must be multiples of 8*upsample_factor");
     }
-    {
-        const ltx_vae_config& c = *cfg; const int nb = c.n_blocks;
-    // what this decoder does not implement is refused, not ignored: noise injection draws from the device RNG
-        // (vae.rs:741-753, not reproducible), spatial-only up-blocks use a (1,2,2) depth-to-space (vae.rs:1225-1236)
-        for (int i = 0; i <= nb; ++i)
-            if (c.decoder_inject_noise[i]) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder_inject_noise[" + std::to_string(i) + "] is set: noise injection inside the resnets is not supported");
-        for (int i = 0; i < nb; ++i)
-            if (!c.decoder_spatiotemporal_scaling[i]) LTX_FAIL(LTX_ERR_UNSUPPORTED, "decoder_spatiotemporal_scaling[" + std::to_string(i) + "] is false: spatial-only (1,2,2) up-blocks are not supported");
-    }
     HIP_TRY(hipSetDevice(device));
     ltx_vae* v = new ltx_vae();
     v->cfg = *cfg; v->dtype = model_dtype == LTX_BF16 ? LTX_DT_BF16 : LTX_DT_F32; v->device = device;
@@ -634,6 +667,11 @@ extern "C" void ltx_vae_destroy(ltx_vae* v) {
     (void)hipSetDevice(v->device); (void)hipDeviceSynchronize();
     v->free_all(); delete v;
 }
+extern "C" int ltx_vae_set_noise_seed(ltx_vae* v, uint64_t seed) {
+    if (!v) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_set_noise_seed: null handle");
+    v->noise_seed = seed; v->noise_ctr = 0; return LTX_OK;
+}
+extern "C" int ltx_vae_injects_noise(const ltx_vae* v) { return v && v->any_inject ? 1 : 0; }
 extern "C" int ltx_vae_get_config(const ltx_vae* v, ltx_vae_config* out) {
     if (!v || !out) LTX_FAIL(LTX_ERR_ARG, "ltx_vae_get_config: null argument");
     *out = v->cfg; return LTX_OK;

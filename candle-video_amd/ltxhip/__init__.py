@@ -92,6 +92,7 @@ _SIGS = {
     "ltx_dit_set_skip_blocks": [_vp, _vp, _i], "ltx_dit_context_cache": [_vp, _i], "ltx_dit_get_config": [_vp, _vp],
     "ltx_dit_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ltx_vae_create": [_vp, _vp, _sz, _i, _i, _vp], "ltx_vae_destroy": [_vp], "ltx_vae_get_config": [_vp, _vp],
+    "ltx_vae_set_noise_seed": [_vp, C.c_uint64], "ltx_vae_injects_noise": [_vp],
     "ltx_vae_latents_mean": [_vp], "ltx_vae_latents_std": [_vp],
     "ltx_vae_decode": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "ltx_vae_decode_tokens": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
@@ -441,9 +442,9 @@ class AutoencoderKLLtxVideoConfig:               # vae.rs:32-103 (decoder side)
     scaling_factor: float = 1.0
     spatial_compression_ratio: int = 32
     temporal_compression_ratio: int = 8
-    decoder_inject_noise: Tuple[bool, ...] = (False, False, False, False)     # vae.rs:87 (any True: refused by the engine)
+    decoder_inject_noise: Tuple[bool, ...] = (False, False, False, False)     # vae.rs:87; blocks whose resnets add noise[h, w] * per_channel_scale (set_noise_seed)
     decoder_upsample_residual: Tuple[bool, ...] = (True, True, True)            # vae.rs:88
-    decoder_spatiotemporal_scaling: Tuple[bool, ...] = (True, True, True)       # vae.rs:78 (any False: refused)
+    decoder_spatiotemporal_scaling: Tuple[bool, ...] = (True, True, True)       # vae.rs:78; False: that up-block's upsampler is the spatial-only (1, 2, 2) form
     resnet_eps: float = 1e-6                                                    # vae.rs:83 (norm3 only: unused by the decoder)
 
 
@@ -507,6 +508,15 @@ class AutoencoderKLLtxVideo:
         self.config = self._config_py(self.get_config())       # a vae/config.json beside the weights replaces `config` (main.rs:525-534)
         self._tiling_defaults()
         return self
+
+    def set_noise_seed(self, seed: int) -> None:
+        """Noise injection (decoder_inject_noise, vae.rs:741-753): plane k of this handle's life is Pcg32(seed, k).randn(H * W);
+        restarts k at 0 (ltx_vae_set_noise_seed)."""
+        _check(lib.ltx_vae_set_noise_seed(self._h, C.c_uint64(seed)))
+
+    def injects_noise(self) -> bool:
+        """whether any resnet of this decoder injects noise (the flag AND a per_channel_scaleN.weight in the checkpoint, vae.rs:676-689)"""
+        return bool(lib.ltx_vae_injects_noise(self._h))
 
     def get_config(self) -> "VaeConfigC":
         """the engine's effective config (ltx_vae_get_config)"""

@@ -346,7 +346,8 @@ def decode_tile_sharded(decode_tile: Callable[[torch.Tensor], torch.Tensor], ble
 
     decode_tile(z_crop [B,C,t,h,w]) -> f32 [B,3,8t-7,32h,32w] (one `decoder.forward`);
     blend(a, b, extent, dim) -> b blended against a (blend_t/v/h, vae.rs:1927-2006).
-    Every rank returns the full video; the result is bit-identical to the single-rank tiled decode.
+    Every rank returns the full video; the result is bit-identical to the single-rank tiled decode (a noise-injecting decoder
+    excepted: each rank's handle continues its own plane stream, ltx_vae_set_noise_seed).
     Framewise decoding (the 52-leaf case at C2) distributes whole temporal tiles and gathers only finished frames
     (_decode_temporal_sharded); the spatial-only mode has four leaves at C2, which are dealt round-robin and gathered whole."""
     _, _, F, H, W = z.shape

@@ -72,12 +72,15 @@ typedef struct {
     int decoder_causal;
     float scaling_factor;
     int spatial_compression_ratio, temporal_compression_ratio;
-    /* vae.rs:51, 676-690, 741-753: per-channel noise from the device RNG inside the resnets.  n_blocks + 1 entries; any
-     * non-zero entry is refused by ltx_vae_create (LTX_ERR_UNSUPPORTED): the reference's draw is not reproducible. */
+    /* vae.rs:51, 676-690, 741-753: resnets of a flagged block add noise[h, w] * per_channel_scaleN[c] after conv1 / conv2 - where the
+     * checkpoint holds "<resnet>.per_channel_scaleN.weight" (the reference's lookup; absent = no injection, as there).  n_blocks + 1
+     * entries in the config's (encoder-side) order like the other lists.  The reference draws each [H, W] plane from the device RNG
+     * (not reproducible); the engine draws plane k of a handle's life as Pcg32::new(seed, k).randn(H * W) - ltx_vae_set_noise_seed. */
     int decoder_inject_noise[5];
     /* vae.rs:52-53, 1103-1129, 1164-1168: whether an up-block's depth-to-space output gets the tiled-repeat residual. */
     int decoder_upsample_residual[4];
-    /* vae.rs:40-41, 1212-1236: 1 = (2,2,2) upsampler; 0 = the spatial-only (1,2,2) form, refused (LTX_ERR_UNSUPPORTED). */
+    /* vae.rs:40-41, 1212-1236: 1 = (2,2,2) upsampler; 0 = the spatial-only (1,2,2) form (frames kept, conv to 4 x channels);
+     * temporal_compression_ratio is the caller's to set accordingly, as in the reference (vae.rs:2358-2434 reads the config). */
     int decoder_spatiotemporal_scaling[4];
     /* vae.rs:46-47: eps of the resnets' norm3 LayerNorm, which exists only where in_channels != out_channels (vae.rs:655-676)
      * - never in the decoder, whose resnets keep the channel count (vae.rs:1547-1549, 1242-1258).  Carried for
@@ -129,6 +132,11 @@ int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t 
                    ltx_dtype model_dtype, int device, ltx_vae** out);
 void ltx_vae_destroy(ltx_vae* v);
 int ltx_vae_get_config(const ltx_vae* v, ltx_vae_config* out);
+/* Noise injection (decoder_inject_noise): seed of the handle's plane stream, restarting the plane counter at 0.  Default seed 0.
+ * A tiled decode of an injecting decoder runs its leaves one per decoder call (each leaf its own planes, as in the reference). */
+int ltx_vae_set_noise_seed(ltx_vae* v, uint64_t seed);
+/* 1 if any resnet of the decoder injects noise (flag set AND the scale present in the checkpoint), else 0 */
+int ltx_vae_injects_noise(const ltx_vae* v);
 const float* ltx_vae_latents_mean(const ltx_vae* v);   /* device f32 [latent_channels] */
 const float* ltx_vae_latents_std(const ltx_vae* v);
 /* VaeLtxVideo::decode (t2v_pipeline.rs:102; vae.rs:2101-2136, 2459-2462).

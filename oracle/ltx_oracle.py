@@ -418,6 +418,8 @@ class VaeConfig:                      # vae.rs:32-103 (decoder-side fields)
     spatial_compression_ratio: int = 32
     temporal_compression_ratio: int = 8
     decoder_upsample_residual: Tuple[bool, ...] = (True, True, True)     # vae.rs:52-53, 88; reversed like the other lists (:1516-1517)
+    decoder_inject_noise: Tuple[bool, ...] = (False, False, False, False)    # vae.rs:51, 87; reversed (:1514-1515): entry [-1] is the mid block
+    decoder_spatiotemporal_scaling: Tuple[bool, ...] = (True, True, True)    # vae.rs:40-41, 78; reversed (:1509-1510); False = the (1, 2, 2) upsampler (:1225-1236)
     # tiling (vae.rs:1849-1854)
     tile_sample_min_height: int = 512
     tile_sample_min_width: int = 512
@@ -487,9 +489,33 @@ def rms_norm_channels_first(x: Tensor, eps: float = 1e-8) -> Tensor:
     return y.permute(0, 4, 1, 2, 3)
 
 
-def resnet_block(p, prefix: str, x: Tensor, temb: Optional[Tensor], is_causal: bool) -> Tensor:
-    """LtxVideoResnetBlock3d::forward (vae.rs:755-821), in==out channels,
-    no noise injection; maybe_apply_scale_shift (:711-739)."""
+class NoisePlanes:
+    """The [H, W] planes maybe_inject_noise draws (vae.rs:741-753).  The reference takes them from the device RNG
+    (Tensor::randn, unseeded: not reproducible); engine and oracle agree on plane k = Pcg32(seed, k).randn((H, W)),
+    k counting the injections of a decoder's life (include/ltxhip.h ltx_vae_set_noise_seed)."""
+
+    def __init__(self, seed: int = 0):
+        self.seed, self.k = seed, 0
+
+    def plane(self, h: int, w: int) -> Tensor:
+        t = Pcg32(self.seed, self.k).randn((h, w))
+        self.k += 1
+        return t
+
+
+def _inject_noise(h: Tensor, scale: Optional[Tensor], noise: Optional["NoisePlanes"]) -> Tensor:
+    """maybe_inject_noise (vae.rs:741-753): x + noise[1,1,1,H,W].to(dtype) * scale[1,C,1,1,1]; no scale in the checkpoint = no-op."""
+    if scale is None or noise is None:
+        return h
+    n = noise.plane(h.shape[3], h.shape[4]).to(h.dtype).reshape(1, 1, 1, h.shape[3], h.shape[4])
+    return h + n * scale.reshape(1, -1, 1, 1, 1).to(h.dtype)
+
+
+def resnet_block(p, prefix: str, x: Tensor, temb: Optional[Tensor], is_causal: bool,
+                 noise: Optional["NoisePlanes"] = None) -> Tensor:
+    """LtxVideoResnetBlock3d::forward (vae.rs:755-821), in==out channels;
+    maybe_apply_scale_shift (:711-739); noise injection (:741-753, 784, 809) when `noise` is given (the block's
+    inject flag) and the checkpoint holds per_channel_scaleN.weight (:676-689)."""
     tbl = p.get(prefix + "scale_shift_table")
 
     def mod(h, stage):
@@ -505,10 +531,12 @@ def resnet_block(p, prefix: str, x: Tensor, temb: Optional[Tensor], is_causal: b
     h = mod(h, 0)
     h = F.silu(h)
     h = causal_conv3d(h, p[prefix + "conv1.conv.weight"], p[prefix + "conv1.conv.bias"], is_causal)
+    h = _inject_noise(h, p.get(prefix + "per_channel_scale1.weight"), noise)
     h = rms_norm_channels_first(h)
     h = mod(h, 1)
     h = F.silu(h)
     h = causal_conv3d(h, p[prefix + "conv2.conv.weight"], p[prefix + "conv2.conv.bias"], is_causal)
+    h = _inject_noise(h, p.get(prefix + "per_channel_scale2.weight"), noise)
     return h + x
 
 
@@ -546,7 +574,7 @@ def unpatchify(x: Tensor, p_: int, pt: int) -> Tensor:
 
 
 def decoder_forward(p: Dict[str, Tensor], cfg: VaeConfig, z: Tensor, temb: Optional[Tensor],
-                    dtype: torch.dtype = torch.float32) -> Tensor:
+                    dtype: torch.dtype = torch.float32, noise: Optional[NoisePlanes] = None) -> Tensor:
     """LtxVideoDecoder3d::forward (vae.rs:1656-1726); `p` keys are relative to `decoder.`."""
     causal = cfg.decoder_causal
     z = z.to(dtype)
@@ -563,8 +591,11 @@ def decoder_forward(p: Dict[str, Tensor], cfg: VaeConfig, z: Tensor, temb: Optio
         e = time_embedder(p, "mid_block.time_embedder.", ts, h.dtype)
         te = e.reshape(h.shape[0], -1, 1, 1, 1)
     nres = list(reversed(cfg.decoder_layers_per_block))
+    inj = list(reversed(cfg.decoder_inject_noise))                 # vae.rs:1514-1515
+    sts = list(reversed(cfg.decoder_spatiotemporal_scaling))       # vae.rs:1509-1510
+    nz = lambda k: noise if (noise is not None and k < len(inj) and inj[k]) else None
     for i in range(nres[0]):
-        h = resnet_block(p, f"mid_block.resnets.{i}.", h, te, causal)
+        h = resnet_block(p, f"mid_block.resnets.{i}.", h, te, causal, nz(0))
     # up blocks (vae.rs:1274-1312)
     for bi, ch in enumerate(cfg.stage_channels()):
         pre = f"up_blocks.{bi}."
@@ -573,9 +604,10 @@ def decoder_forward(p: Dict[str, Tensor], cfg: VaeConfig, z: Tensor, temb: Optio
             e = time_embedder(p, pre + "time_embedder.", ts, h.dtype)
             te = e.reshape(h.shape[0], -1, 1, 1, 1)
         upr = list(reversed(cfg.decoder_upsample_residual))
-        h = upsampler(p, pre + "upsamplers.0.", h, ch, causal, residual=bool(upr[bi]) if bi < len(upr) else True)
+        stride = (2, 2, 2) if (bi >= len(sts) or sts[bi]) else (1, 2, 2)      # vae.rs:1212-1236
+        h = upsampler(p, pre + "upsamplers.0.", h, ch, causal, stride=stride, residual=bool(upr[bi]) if bi < len(upr) else True)
         for i in range(nres[bi + 1]):
-            h = resnet_block(p, pre + f"resnets.{i}.", h, te, causal)
+            h = resnet_block(p, pre + f"resnets.{i}.", h, te, causal, nz(bi + 1))
     h = rms_norm_channels_first(h)
     if ts is not None and cfg.timestep_conditioning:
         e = time_embedder(p, "time_embedder.", ts, h.dtype)
@@ -606,7 +638,7 @@ def _blend(a: Tensor, b: Tensor, extent: int, dim: int) -> Tensor:
     return torch.cat([mixed, b_tail], dim)
 
 
-def tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype) -> Tensor:
+def tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype, noise: Optional[NoisePlanes] = None) -> Tensor:
     """AutoencoderKLLtxVideo::tiled_decode (vae.rs:2225-2290)."""
     _, _, _, height, width = z.shape
     r = cfg.spatial_compression_ratio
@@ -619,7 +651,7 @@ def tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype) -> Tensor:
         row = []
         for j in range(0, width, ts_w):
             tile = z[:, :, :, i:min(i + tmin_h, height), j:min(j + tmin_w, width)]
-            row.append(decoder_forward(p, cfg, tile, temb, dtype))
+            row.append(decoder_forward(p, cfg, tile, temb, dtype, noise))
         rows.append(row)
     prev: List[Tensor] = []
     result_rows = []
@@ -641,7 +673,7 @@ def tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype) -> Tensor:
     return dec[:, :, :, :height * r, :width * r]
 
 
-def temporal_tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype, use_tiling: bool) -> Tensor:
+def temporal_tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype, use_tiling: bool, noise: Optional[NoisePlanes] = None) -> Tensor:
     """AutoencoderKLLtxVideo::temporal_tiled_decode (vae.rs:2358-2434)."""
     nf = z.shape[2]
     tr, r = cfg.temporal_compression_ratio, cfg.spatial_compression_ratio
@@ -654,9 +686,9 @@ def temporal_tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype, use_tiling:
     for li, i in enumerate(range(0, nf, tstride_t)):
         tile = z[:, :, i:min(i + tmin_t + 1, nf)]
         if use_tiling and (tile.shape[3] > tmin_h or tile.shape[4] > tmin_w):
-            dec = tiled_decode(p, cfg, tile, temb, dtype)
+            dec = tiled_decode(p, cfg, tile, temb, dtype, noise)
         else:
-            dec = decoder_forward(p, cfg, tile, temb, dtype)
+            dec = decoder_forward(p, cfg, tile, temb, dtype, noise)
         if li > 0 and dec.shape[2] > 1:
             dec = dec[:, :, :-1]
         row.append(dec)
@@ -671,17 +703,17 @@ def temporal_tiled_decode(p, cfg: VaeConfig, z: Tensor, temb, dtype, use_tiling:
 
 
 def vae_decode(p, cfg: VaeConfig, z: Tensor, temb: Optional[Tensor], dtype=torch.float32,
-               use_tiling: bool = False, use_framewise_decoding: bool = False) -> Tensor:
+               use_tiling: bool = False, use_framewise_decoding: bool = False, noise: Optional[NoisePlanes] = None) -> Tensor:
     """AutoencoderKLLtxVideo::decode -> decode_z (vae.rs:2101-2136, 2037-2066)."""
     z = z.to(dtype)
     t = temb.to(dtype) if temb is not None else None
     _, _, tt, hh, ww = z.shape
     r, tr = cfg.spatial_compression_ratio, cfg.temporal_compression_ratio
     if use_framewise_decoding and tt > cfg.tile_sample_min_num_frames // tr:
-        return temporal_tiled_decode(p, cfg, z, t, dtype, use_tiling)
+        return temporal_tiled_decode(p, cfg, z, t, dtype, use_tiling, noise)
     if use_tiling and (ww > cfg.tile_sample_min_width // r or hh > cfg.tile_sample_min_height // r):
-        return tiled_decode(p, cfg, z, t, dtype)
-    return decoder_forward(p, cfg, z, t, dtype)
+        return tiled_decode(p, cfg, z, t, dtype, noise)
+    return decoder_forward(p, cfg, z, t, dtype, noise)
 
 
 def vae_decoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
@@ -698,28 +730,33 @@ def vae_decoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
         s[name + ".timestep_embedder.linear_2.weight"] = (dim, dim)
         s[name + ".timestep_embedder.linear_2.bias"] = (dim,)
 
-    def resnet(name, c):
+    def resnet(name, c, inject=False):
         conv(name + ".conv1", c, c)
         conv(name + ".conv2", c, c)
         if cfg.timestep_conditioning:
             s[name + ".scale_shift_table"] = (4, c)
+        if inject:                                                 # vae.rs:676-689 (the name the reference looks up)
+            s[name + ".per_channel_scale1.weight"] = (c, 1, 1)
+            s[name + ".per_channel_scale2.weight"] = (c, 1, 1)
 
     mid = cfg.mid_channels
     nres = list(reversed(cfg.decoder_layers_per_block))
     upf = list(reversed(cfg.decoder_upsample_factor))
+    inj = list(reversed(cfg.decoder_inject_noise))
+    sts = list(reversed(cfg.decoder_spatiotemporal_scaling))
     conv("conv_in", cfg.latent_channels, mid)
     if cfg.timestep_conditioning:
         temb("mid_block.time_embedder", 4 * mid)
     for i in range(nres[0]):
-        resnet(f"mid_block.resnets.{i}", mid)
+        resnet(f"mid_block.resnets.{i}", mid, bool(inj[0]) if inj else False)
     cur = mid
     for bi, ch in enumerate(cfg.stage_channels()):
         pre = f"up_blocks.{bi}"
-        conv(pre + ".upsamplers.0.conv", ch * upf[bi], ch * 8)
+        conv(pre + ".upsamplers.0.conv", ch * upf[bi], ch * (8 if (bi >= len(sts) or sts[bi]) else 4))     # vae.rs:1063
         if cfg.timestep_conditioning:
             temb(pre + ".time_embedder", 4 * ch)
         for i in range(nres[bi + 1]):
-            resnet(pre + f".resnets.{i}", ch)
+            resnet(pre + f".resnets.{i}", ch, bool(inj[bi + 1]) if bi + 1 < len(inj) else False)
         cur = ch
     conv("conv_out", cur, cfg.out_channels * cfg.patch_size * cfg.patch_size)
     if cfg.timestep_conditioning:

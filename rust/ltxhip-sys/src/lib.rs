@@ -166,6 +166,8 @@ extern "C" {
     pub fn ltx_vae_create_from_files(cfg: *const ltx_vae_config, path: *const c_char, unified: c_int, model_dtype: c_int, device: c_int, out: *mut *mut ltx_vae) -> c_int;
     pub fn ltx_vae_destroy(v: *mut ltx_vae);
     pub fn ltx_vae_get_config(v: *const ltx_vae, out: *mut ltx_vae_config) -> c_int;
+    pub fn ltx_vae_set_noise_seed(v: *mut ltx_vae, seed: u64) -> c_int;
+    pub fn ltx_vae_injects_noise(v: *const ltx_vae) -> c_int;
     pub fn ltx_vae_latents_mean(v: *const ltx_vae) -> *const c_float;
     pub fn ltx_vae_latents_std(v: *const ltx_vae) -> *const c_float;
     pub fn ltx_vae_decode(v: *mut ltx_vae, latents: *const c_void, io_dtype: c_int, timestep: *const c_float, b: c_int, f: c_int, h: c_int, w: c_int,

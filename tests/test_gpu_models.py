@@ -310,9 +310,14 @@ def test_vae_upsample_residual_flags_and_config_json(hip, tmp_path):
     c2 = m2.get_config()
     assert list(c2.decoder_upsample_residual)[:3] == [0, 1, 1] and c2.latent_channels == 8 and c2.timestep_conditioning == 1
     assert rel_max(m2.decode(z.to(DEV), ts).cpu(), want) <= 1e-3
-    (vdir / "config.json").write_text(json.dumps({"decoder_inject_noise": [False, False, True, False]}))
-    with pytest.raises(hip.LtxError, match="decoder_inject_noise"):
-        hip.AutoencoderKLLtxVideo.from_files(hip.AutoencoderKLLtxVideoConfig(), str(vdir), unified=False, dtype=torch.float32)
+    # a config.json that asks for noise injection over a checkpoint without per_channel_scaleN.weight: accepted, and no injection
+    # (the reference's lookup is .ok(), vae.rs:676-689)
+    (vdir / "config.json").write_text(json.dumps({"latent_channels": 8, "decoder_block_out_channels": [32, 64, 128], "decoder_layers_per_block": [1, 1, 1, 2],
+                                                  "upsample_residual": [False, True, True], "timestep_conditioning": False,
+                                                  "decoder_inject_noise": [False, False, True, False]}))
+    m3 = hip.AutoencoderKLLtxVideo.from_files(hip.AutoencoderKLLtxVideoConfig(), str(vdir), unified=False, dtype=torch.float32)
+    assert list(m3.get_config().decoder_inject_noise)[:4] == [0, 0, 1, 0] and not m3.injects_noise()
+    assert rel_max(m3.decode(z.to(DEV), ts).cpu(), want) <= 1e-3
 
 
 def test_batches_beyond_eight_rows(hip):
@@ -592,3 +597,86 @@ def test_full_size_pipeline_bf16_vs_f32_psnr(hip):
     r = mod.run()
     assert r["video_psnr_db_bf16_vs_f32"] > 35.0 and r["latent_rel_l2"] < 2e-2, r
     assert 20.0 < r["video_std"] < 120.0, r          # the synthetic video is not degenerate (saturated or constant)
+
+
+VARIANT_CFG = dict(latent_channels=16, decoder_block_out_channels=(64, 128), decoder_layers_per_block=(2, 1, 1), decoder_upsample_factor=(2, 2),
+                   decoder_upsample_residual=(True, True), temporal_compression_ratio=4, spatial_compression_ratio=16)
+
+
+def _variant(hip, dt, **kw):
+    cfgd = dict(VARIANT_CFG, **kw)
+    cfg = O.VaeConfig(**cfgd)
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=21)
+    model = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**cfgd), {"decoder." + k: v.to(DEV) for k, v in w.items()}, dt)
+    return cfg, w, model
+
+
+@pytest.mark.parametrize("scaling", [(True, False), (False, True), (False, False)])
+def test_vae_spatial_only_up_blocks(hip, scaling):
+    """decoder_spatiotemporal_scaling with a False entry (vae.rs:1212-1236): that up-block's upsampler is the (1, 2, 2) depth-to-space
+    (conv to 4 x channels, frames kept, residual repeated 4 / upsample_factor times).  f32 mode vs the oracle, bf16 within its bar,
+    batch of two, with and without the residual."""
+    tr = 2 ** sum(scaling)
+    for resid in ((True, True), (False, True)):
+        cfg, w, model = _variant(hip, torch.float32, decoder_spatiotemporal_scaling=scaling, temporal_compression_ratio=tr, decoder_upsample_residual=resid)
+        z = torch.randn(2, 16, 3, 5, 6, generator=torch.Generator().manual_seed(5))
+        ts = torch.tensor([0.05, 0.0])
+        ref = O.decoder_forward(w, cfg, z, ts)
+        out = model.decode(z.to(DEV), ts).cpu()
+        assert out.shape == ref.shape == (2, 3, (3 - 1) * tr + 1, 80, 96)
+        assert rel_max(out, ref) <= 1e-3, rel_max(out, ref)
+    _, _, bf = _variant(hip, torch.bfloat16, decoder_spatiotemporal_scaling=scaling, temporal_compression_ratio=tr, decoder_upsample_residual=resid)
+    assert rel_l2(bf.decode(z.to(DEV), ts).float().cpu(), ref) <= 3e-2
+
+
+def test_vae_spatial_only_tiled_decode(hip):
+    """The tiled + framewise decode of a decoder whose temporal ratio is 2 (one spatial-only up-block) against the oracle's."""
+    cfg, w, model = _variant(hip, torch.float32, decoder_spatiotemporal_scaling=(True, False), temporal_compression_ratio=2)
+    for o in (cfg, model):
+        o.tile_sample_min_height = o.tile_sample_min_width = 64; o.tile_sample_stride_height = o.tile_sample_stride_width = 32
+        o.tile_sample_min_num_frames = 4; o.tile_sample_stride_num_frames = 2
+    model.use_tiling = model.use_framewise_decoding = True
+    z = torch.randn(1, 16, 5, 6, 7, generator=torch.Generator().manual_seed(6))
+    ref = O.vae_decode(w, cfg, z, torch.tensor([0.05]), use_tiling=True, use_framewise_decoding=True)
+    out = model.decode(z.to(DEV), torch.tensor([0.05])).cpu()
+    assert out.shape == ref.shape and rel_max(out, ref) <= 1e-3, rel_max(out, ref)
+
+
+def test_vae_noise_injection(hip):
+    """decoder_inject_noise (vae.rs:676-689, 741-753, 784, 809): resnets of a flagged block add plane[h, w] * per_channel_scaleN[c] after
+    conv1 and conv2.  Plane k of a handle = Pcg32(seed, k).randn(H * W) on both sides: f32 mode vs the oracle (untiled, batch 2: one
+    plane per injection for the whole batch; and tiled + framewise: every leaf its own planes, in the reference's leaf order); the seed
+    matters; the stream continues across calls; a checkpoint without the scales is the plain decoder (the reference's .ok())."""
+    inj = (True, False, True)
+    cfg, w, model = _variant(hip, torch.float32, decoder_inject_noise=inj)
+    assert model.injects_noise() and any("per_channel_scale2.weight" in k for k in w)
+    z = torch.randn(2, 16, 2, 5, 6, generator=torch.Generator().manual_seed(7)); ts = torch.tensor([0.05, 0.0])
+    noise = O.NoisePlanes(9)
+    ref1 = O.decoder_forward(w, cfg, z, ts, noise=noise); ref2 = O.decoder_forward(w, cfg, z, ts, noise=noise)
+    model.set_noise_seed(9)
+    out1 = model.decode(z.to(DEV), ts).cpu(); out2 = model.decode(z.to(DEV), ts).cpu()
+    assert rel_max(out1, ref1) <= 1e-3 and rel_max(out2, ref2) <= 1e-3, (rel_max(out1, ref1), rel_max(out2, ref2))
+    assert not torch.equal(out1, out2)                                          # the second call drew the next planes
+    model.set_noise_seed(9)
+    assert torch.equal(model.decode(z.to(DEV), ts).cpu(), out1)                  # same seed, same planes
+    plain = O.decoder_forward(w, cfg, z, ts)
+    assert rel_max(out1, plain) > 1e-2                                           # and the noise is not a rounding error
+    # tiled: leaves in the reference's order, one decoder call each
+    for o in (cfg, model):
+        o.tile_sample_min_height = o.tile_sample_min_width = 64; o.tile_sample_stride_height = o.tile_sample_stride_width = 32
+        o.tile_sample_min_num_frames = 8; o.tile_sample_stride_num_frames = 4
+    model.use_tiling = model.use_framewise_decoding = True
+    zt = torch.randn(1, 16, 4, 6, 7, generator=torch.Generator().manual_seed(8))
+    reft = O.vae_decode(w, cfg, zt, torch.tensor([0.05]), use_tiling=True, use_framewise_decoding=True, noise=O.NoisePlanes(4))
+    model.set_noise_seed(4)
+    outt = model.decode(zt.to(DEV), torch.tensor([0.05])).cpu()
+    assert outt.shape == reft.shape and rel_max(outt, reft) <= 1e-3, rel_max(outt, reft)
+    # bf16: the reference's roundings (noise cast, product, sum, shortcut) within the bf16 bar of the f32 oracle
+    _, _, bf = _variant(hip, torch.bfloat16, decoder_inject_noise=inj)
+    bf.set_noise_seed(9)
+    assert rel_l2(bf.decode(z.to(DEV), ts).float().cpu(), ref1) <= 3e-2
+    # the flag without the scales in the checkpoint: no injection
+    wd = {"decoder." + k: v.to(DEV) for k, v in w.items() if "per_channel_scale" not in k}
+    m2 = hip.AutoencoderKLLtxVideo(hip.AutoencoderKLLtxVideoConfig(**dict(VARIANT_CFG, decoder_inject_noise=inj)), wd, torch.float32)
+    assert not m2.injects_noise()
+    assert rel_max(m2.decode(z.to(DEV), ts).cpu(), plain) <= 1e-3

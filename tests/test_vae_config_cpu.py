@@ -30,16 +30,14 @@ def _create(c):
     return ltxhip.lib.ltx_vae_create(ctypes.byref(c), ctypes.byref(w), ctypes.c_size_t(0), 0, 0, ctypes.byref(h))
 
 
-def test_noise_injection_is_refused_by_name():
-    c = _default(); c.decoder_inject_noise[2] = 1
-    assert _create(c) == 4                                                      # LTX_ERR_UNSUPPORTED
-    assert b"decoder_inject_noise[2]" in ltxhip.lib.ltx_last_error()
-
-
-def test_spatial_only_up_block_is_refused_by_name():
-    c = _default(); c.decoder_spatiotemporal_scaling[0] = 0
-    assert _create(c) == 4
-    assert b"decoder_spatiotemporal_scaling[0]" in ltxhip.lib.ltx_last_error()
+def test_noise_injection_and_spatial_only_blocks_are_accepted():
+    """Round 5: both decoder variants are implemented (vae.rs:676-690 / 741-753 and :1212-1236), so creation goes on to the weights -
+    here, without a GPU, that is the device error (on a GPU box: the first missing weight), never the config field."""
+    for field, idx in (("decoder_inject_noise", 2), ("decoder_spatiotemporal_scaling", 0)):
+        c = _default(); getattr(c, field)[idx] = 1 if field == "decoder_inject_noise" else 0
+        rc = _create(c)
+        err = ltxhip.lib.ltx_last_error()
+        assert rc != 0 and rc != 4 and field.encode() not in err, (rc, err)
 
 
 def test_config_json_with_serde_names_and_aliases(tmp_path):

@@ -32,7 +32,9 @@ def classify(n):
         return "conv3d implicit GEMM" if len(a) > 5 and a[5] == "true" else "linear GEMM"
     if "gemm_asm16_conv_kernel" in n:
         return "conv3d implicit GEMM"
-    if "gemm_asm16_kernel" in n or "gemm_asm_kernel" in n or "gemm_ring_kernel" in n:
+    if "gemm_ring_kernel" in n:                  # <BM, BN, NS, EPI, SPEC, CONV>
+        return "conv3d implicit GEMM" if len(a) > 5 and a[5] == "true" else "linear GEMM"
+    if "gemm_asm16_kernel" in n or "gemm_asm_kernel" in n:
         return "linear GEMM"
     if "conv_halo_kernel" in n:
         return "conv3d implicit GEMM"
