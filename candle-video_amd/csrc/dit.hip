@@ -53,11 +53,11 @@ struct ltx_dit {
     struct { bool valid = false; const float* coords = nullptr; float rs[3] = {0, 0, 0}; bool has_rs = false; int B = 0, S = 0, F = 0, H = 0, W = 0; hipStream_t stream = nullptr; } rope_key;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
     // workspaces
-    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, outT, rsq, hsq, parts;
+    DevBuf xin, encin, h, n, qkv, attn, ff, c1, encp, kv2, tproj, e1, emb, embs, temb, ada, adaf, cosb, sinb, bias, orig, orig_hsq, outT, rsq, hsq, parts;
     void free_all() {
         for (void* p : owned) if (p) (void)hipFree(p);
         owned.clear();
-        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &outT, &rsq, &hsq, &parts};
+        DevBuf* bs[] = {&xin, &encin, &h, &n, &qkv, &attn, &ff, &c1, &encp, &kv2, &tproj, &e1, &emb, &embs, &temb, &ada, &adaf, &cosb, &sinb, &bias, &orig, &orig_hsq, &outT, &rsq, &hsq, &parts};
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); e.kvc.release(); e.biasc.release(); e.kidx.release(); e.kcount.release(); }
         ctxs.clear();
@@ -258,6 +258,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h
+    bool hsq_saved = false;                                 // m->orig_hsq holds the partials of m->orig (a layer some rows skip)
     // Few tokens (C1's 384: every linear layer is a latency-bound weight stream): ff2, the deepest one (K = 4 D), runs its K ranges as
     // separate blocks (the shape rule: four ranges from K = 8192 up) and leaves their f32 sums in m->parts; the row norm that follows
     // the block - the next block's norm1, or the final LayerNorm - adds them in part order, applies gate * y + h, writes h and goes on
@@ -380,7 +381,13 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         if (skip_layer_mask) {
             for (int b = 0; b < B; ++b) { mv.t[b] = skip_layer_mask[(size_t)l * B + b]; any |= mv.t[b] != 0.f; all &= mv.t[b] == 1.f; }
             if (all) continue;
-            if (any) HIP_TRY(hipMemcpyAsync(m->orig.p, m->h.p, M * D * esz, hipMemcpyDeviceToDevice, s));
+            if (any) {
+                HIP_TRY(hipMemcpyAsync(m->orig.p, m->h.p, M * D * esz, hipMemcpyDeviceToDevice, s));
+                // the row partials of the kept rows travel with them (restored after the blend): a batch whose rows skip different
+                // layers - the guidance branches of a step in one forward - then returns, row for row, the bits of separate forwards
+                hsq_saved = presum && hsq_valid;
+                if (hsq_saved) { LTX_TRY(m->orig_hsq.ensure(M * (D / 128) * sizeof(float))); HIP_TRY(hipMemcpyAsync(m->orig_hsq.p, m->hsq.p, M * (D / 128) * sizeof(float), hipMemcpyDeviceToDevice, s)); }
+            }
         }
         const DitBlock& b = m->blocks[l];
         const float* ada = ada_all + (size_t)l * B * 6 * D;
@@ -451,7 +458,16 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         } else
         LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S, presum ? m->hsq.as<float>() : nullptr));
         hsq_valid = presum;
-        if (skip_layer_mask && any) { LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s)); hsq_valid = false; }
+        if (skip_layer_mask && any) {
+            LTX_TRY(ltx_launch_skip_blend(m->h.p, m->orig.p, mv, S, D, dt, s));
+            bool binary = true;
+            for (int bb = 0; bb < B; ++bb) binary &= mv.t[bb] == 0.f || mv.t[bb] == 1.f;
+            if (hsq_valid && hsq_saved && binary) {            // rows with mask 1 are the block's input again: so are their partials
+                const size_t rowb = (size_t)S * (D / 128) * sizeof(float);
+                for (int bb = 0; bb < B; ++bb)
+                    if (mv.t[bb] == 1.f) HIP_TRY(hipMemcpyAsync((char*)m->hsq.p + bb * rowb, (const char*)m->orig_hsq.p + bb * rowb, rowb, hipMemcpyDeviceToDevice, s));
+            } else hsq_valid = false;
+        }
     }
 
     // final LayerNorm (no affine) + modulation (:1126-1161), proj_out (:1163)

@@ -277,6 +277,8 @@ int ltx_plan_load(const char* path);
  *   vae_fuse_norm=0        the resnet's second norm as its own pass (1, default: fused where the conv's grid is about one round of
  *                          the chip or more; 2: fused on smaller grids too)
  *   t5_attn_mfma=0         the scalar T5 attention kernel
+ *   guidance_batch=0       ltx_pipeline_call runs the guidance branches of a step (negative prompt / prompt / prompt with the STG
+ *                          blocks skipped) as separate forwards, the reference's call order (default: one forward of up to 8 rows; same bits)
  *   attn_off=a+b           attention kernels left out: q64, q128, cross, pipe (the next more general kernel serves)
  * Measured-negative experiments and tuning knobs ("x_name=int") exist only in builds made with -DLTX_EXPERIMENTS
  * (`make -C candle-video_amd experiments`, for tools/); the shipped library ignores them.  ltx_has_experiments() tells. */

@@ -117,6 +117,11 @@ def test_c3_preset_at_c2_geometry_bf16_vs_f32_mode(c3):
             runs.append((lat_f.float().cpu(), video[:, :, ::4, ::8, ::8].float().cpu()))
         if len(runs) == 2:
             assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        # the three guidance branches of a step run as ONE forward of three rows (option guidance_batch, default on): row for row
+        # the bits of the reference's three separate calls, in both modes
+        with hip.options(guidance_batch="0"):
+            lat_s, video_s = pipe.call(call, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV))
+        assert torch.equal(lat_s.float().cpu(), runs[0][0]) and torch.equal(video_s[:, :, ::4, ::8, ::8].float().cpu(), runs[0][1]), dt
         res[dt] = runs[0]
         del pipe, dit, vae
         torch.cuda.empty_cache()

@@ -308,3 +308,40 @@ def test_pcg32_gaussians_match_reference_test_rng_script(golden):
     want = golden("ref_rope_table.safetensors")["test_rng_values"]
     got = O.Pcg32(42, 1442695040888963407).randn((10,))
     assert (got.double() - want).abs().max() < 1e-5
+
+
+# ---------- round 5: the two decoder variants (vae.rs:1212-1236, 676-689 / 741-753) ----------
+def test_spatial_only_upsampler_vs_pixel_shuffle():
+    """The (1, 2, 2) upsampler: per frame it is torch's pixel_shuffle(2) (channel c*4 + sh*2 + sw -> pixel (2h + sh, 2w + sw)),
+    no frame dropped, residual = the same shuffle of x with its channels repeated 4 / upsample_factor times."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 16, 3, 4, 5, generator=g)
+    p = {"u.conv.conv.weight": torch.randn(32, 16, 3, 3, 3, generator=g) / 20, "u.conv.conv.bias": torch.randn(32, generator=g)}
+    y = O.upsampler(p, "u.", x, 8, False, stride=(1, 2, 2), residual=True)
+    h = O.causal_conv3d(x, p["u.conv.conv.weight"], p["u.conv.conv.bias"], False)
+    want = torch.stack([F.pixel_shuffle(h[:, :, t], 2) for t in range(3)], 2)
+    res = torch.stack([F.pixel_shuffle(x[:, :, t], 2) for t in range(3)], 2).repeat(1, 2, 1, 1, 1)     # 16 / 4 = 4 channels -> 8
+    assert y.shape == (2, 8, 3, 8, 10) and torch.allclose(y, want + res, atol=1e-6)
+    assert torch.allclose(O.upsampler(p, "u.", x, 8, False, stride=(1, 2, 2), residual=False), want, atol=1e-6)
+
+
+def test_noise_injection_formula_and_plane_stream():
+    """maybe_inject_noise: x + plane[h, w] * scale[c], one plane per injection broadcast over batch, channels and frames; the planes
+    are Pcg32(seed, k).randn((H, W)), k counting injections; no scale in the checkpoint or no stream = identity."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 3, 5, 6, generator=g); sc = torch.randn(4, 1, 1, generator=g)
+    n = O.NoisePlanes(11)
+    y0 = O._inject_noise(x, sc, n); y1 = O._inject_noise(x, sc, n)
+    p0, p1 = O.Pcg32(11, 0).randn((5, 6)), O.Pcg32(11, 1).randn((5, 6))
+    for y, pl in ((y0, p0), (y1, p1)):
+        assert torch.allclose(y, x + pl[None, None, None] * sc.reshape(1, 4, 1, 1, 1), atol=1e-6)
+    assert n.k == 2 and torch.equal(O._inject_noise(x, None, n), x) and torch.equal(O._inject_noise(x, sc, None), x) and n.k == 2
+    # a decoder whose flags are set: the shapes function names the scales the reference looks up, and only flagged blocks draw
+    cfg = O.VaeConfig(latent_channels=8, decoder_block_out_channels=(32, 64), decoder_layers_per_block=(1, 1, 1), decoder_upsample_factor=(2, 2),
+                      decoder_upsample_residual=(True, True), decoder_inject_noise=(True, False, False), timestep_conditioning=False)
+    w = O.synth_weights(O.vae_decoder_weight_shapes(cfg), seed=1)
+    assert sorted(k for k in w if "per_channel" in k) == ["up_blocks.1.resnets.0.per_channel_scale1.weight", "up_blocks.1.resnets.0.per_channel_scale2.weight"]
+    n = O.NoisePlanes(1)
+    z = torch.randn(1, 8, 2, 3, 3, generator=g)
+    out = O.decoder_forward(w, cfg, z, None, noise=n)
+    assert n.k == 2 and not torch.allclose(out, O.decoder_forward(w, cfg, z, None))
