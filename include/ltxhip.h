@@ -133,7 +133,8 @@ int ltx_vae_create(const ltx_vae_config* cfg, const ltx_weight* weights, size_t 
 void ltx_vae_destroy(ltx_vae* v);
 int ltx_vae_get_config(const ltx_vae* v, ltx_vae_config* out);
 /* Noise injection (decoder_inject_noise): seed of the handle's plane stream, restarting the plane counter at 0.  Default seed 0.
- * A tiled decode of an injecting decoder runs its leaves one per decoder call (each leaf its own planes, as in the reference). */
+ * A tiled decode of an injecting decoder runs its leaves one per decoder call (each leaf its own planes, as in the reference); a batch
+ * beyond 8 samples is decoded 8 at a time, each such call with planes of its own (the reference: one plane per injection for the batch). */
 int ltx_vae_set_noise_seed(ltx_vae* v, uint64_t seed);
 /* 1 if any resnet of the decoder injects noise (flag set AND the scale present in the checkpoint), else 0 */
 int ltx_vae_injects_noise(const ltx_vae* v);
