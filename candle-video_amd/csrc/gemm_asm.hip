@@ -327,8 +327,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias4[i];
             if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+                gelu_tanh4(v);
             } else if constexpr (HAS_R) {
                 const float r[4] = {(float)res[0], (float)res[1], (float)res[2], (float)res[3]};
                 if constexpr (EPI == EPI_GATE_RESID) {

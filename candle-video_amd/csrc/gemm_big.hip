@@ -366,8 +366,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(const GemmArgs
                                     for (int i = 0; i < 4; ++i) v[i] += b[i];
                                 }
                                 if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+                                    gelu_tanh4(v);
                                 } else if constexpr (HAS_R) {
                                     float r[4];
                                     load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), r);

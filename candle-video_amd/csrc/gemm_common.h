@@ -69,8 +69,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, int m, int nb, float
         if (g.c_seg_shift) { const int sg = nb >> g.c_seg_shift; C += sg * g.c_seg_stride; nb -= sg << g.c_seg_shift; }
         store4<T>(C + (int64_t)m * g.ldc + nb, v);
     } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+        gelu_tanh4(v);
         store4<T>(C + (int64_t)m * g.ldc + nb, v);
     } else if constexpr (EPI == EPI_GATE_RESID) {
         float r[4];

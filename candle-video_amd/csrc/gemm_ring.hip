@@ -352,8 +352,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmA
             if constexpr (EPI == EPI_BIAS) {
                 if (g.c_seg_shift) { const int sg = nb >> g.c_seg_shift; C += sg * g.c_seg_stride; nb -= sg << g.c_seg_shift; }
             } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh_f(v[i]);
+                gelu_tanh4(v);
             } else if constexpr (EPI == EPI_GATE_RESID) {
                 float r[4];
                 load4<bf16_t>(reinterpret_cast<const bf16_t*>(&presid[fm][fn]), r);
