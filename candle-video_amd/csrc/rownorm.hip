@@ -103,17 +103,35 @@ __device__ __forceinline__ void load_chunk_operands(const RowNormArgs& a, int c,
 // RowNormArgs::parts: chunk c of a row that arrives as the K-range sums of the linear layer before it - finished with the layer's
 // epilogue expression (gemm_common.h epilogue<>: v = sum + bias, then resid + gate * v or v + resid), rounded to T, written back
 // as the new residual stream and returned for the norm.  Ranges added in part order: ((p0 + p1) + p2) + ... (gemm_big.hip).
-template <typename T>
+// NP > 0: the number of ranges known at compile time (four: the shape rule's cut of K >= 8192 at <= 512 rows) - every range's loads are
+// issued before the first add, 8 x 16 bytes in flight per chunk instead of one dependent pair at a time (this pass is pure latency at
+// 384 rows: 14.6 us -> see docs/lab_notes.md R5.13); NP == 0: a.nparts at run time.  Same order of additions either way.
+template <typename T, int NP = 0>
 __device__ __forceinline__ Chunk16 deferred_chunk(const RowNormArgs& a, int64_t row, int64_t b, int c, bool active) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     float v[CH];
     const float* pp = a.parts + row * a.D + c * CH;
+    if constexpr (NP > 0) {
+        f32x4 t[NP][CH / 4];
 #pragma unroll
-    for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pp + 4 * q); v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3]; }
-    for (int p = 1; p < a.nparts; ++p) {
-        const float* pq = pp + (int64_t)p * a.part_stride;
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pq + 4 * q); v[4 * q] += t[0]; v[4 * q + 1] += t[1]; v[4 * q + 2] += t[2]; v[4 * q + 3] += t[3]; }
+            for (int q = 0; q < CH / 4; ++q) t[p][q] = *reinterpret_cast<const f32x4*>(pp + (int64_t)p * a.part_stride + 4 * q);
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            f32x4 acc = t[0][q];
+#pragma unroll
+            for (int p = 1; p < NP; ++p) acc += t[p][q];
+            v[4 * q] = acc[0]; v[4 * q + 1] = acc[1]; v[4 * q + 2] = acc[2]; v[4 * q + 3] = acc[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pp + 4 * q); v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3]; }
+        for (int p = 1; p < a.nparts; ++p) {
+            const float* pq = pp + (int64_t)p * a.part_stride;
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(pq + 4 * q); v[4 * q] += t[0]; v[4 * q + 1] += t[1]; v[4 * q + 2] += t[2]; v[4 * q + 3] += t[3]; }
+        }
     }
     if (a.d_bias) {
         Chunk16 bc; bc.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.d_bias) + c * CH);
@@ -141,7 +159,7 @@ __device__ __forceinline__ Chunk16 deferred_chunk(const RowNormArgs& a, int64_t 
 }
 
 // MODE 0: WIDE (row cached in registers), 1: NARROW (NSLOT rows per lane group), 2: re-read fallback; DEFER (MODE 0): RowNormArgs::parts
-template <typename T, int MODE, bool DEFER = false>
+template <typename T, int MODE, int DEFER = 0>          // DEFER: 0 no; 1: RowNormArgs::parts, a.nparts ranges; 4: four ranges (unrolled)
 __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int lpr) {
     constexpr int CH = ElemTraits<T>::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormArgs a, int l
             for (int i = 0; i < NSLOT; ++i) {
                 int c = sub + i * lpr;
                 v[i].u = (u32x4){0u, 0u, 0u, 0u};
-                if constexpr (DEFER) { if (c < nch) v[i] = deferred_chunk<T>(a, rr, b, c, active); }
+                if constexpr (DEFER != 0) { if (c < nch) v[i] = deferred_chunk<T, DEFER == 4 ? 4 : 0>(a, rr, b, c, active); }
                 else if (c < nch) v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
             }
             float mean = 0.f;
@@ -786,7 +804,8 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
             static std::atomic<unsigned long long> occ_devs{0};
             (void)ltx_set_max_dyn_smem(occ_devs, reinterpret_cast<const void*>(&rownorm_kernel<T, 0>), 163840);
         }
-        if (a.parts) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0, true>), grid, dim3(256), 0, s, a, lpr);       // (launcher-checked: WIDE rows)
+        if (a.parts && a.nparts == 4) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0, 4>), grid, dim3(256), 0, s, a, lpr);       // (launcher-checked: WIDE rows)
+        else if (a.parts) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0, 1>), grid, dim3(256), 0, s, a, lpr);
         else if (nch <= NSLOT * lpr) LTX_LAUNCH_TIMED((rownorm_kernel<T, 0>), grid, dim3(256), shm, s, a, lpr);
         else LTX_LAUNCH_TIMED((rownorm_kernel<T, 2>), grid, dim3(256), 0, s, a, lpr);
     }
