@@ -768,6 +768,67 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const T* x, int64_t rows, in
     }
 }
 
+// Few rows (C1's 384 tokens, the 128 text rows of T5): ONE ROW PER BLOCK, a chunk (two beyond 2048 columns) per thread.  With a wave per
+// row such a pass is 384 waves on 256 CUs, each walking a dependent chain of four chunks (and, finishing deferred K ranges, 1 KiB of
+// loads per lane): pure latency - 7.0 us plain, 14.6 us with four ranges.  Four waves per row quarter the chain and put 4 x the loads
+// in flight.  Row statistic: lane butterfly, then the four wave sums in wave order - the plain and the deferred form share it, so
+// finishing the ranges here returns the bits of in-launch reduction + this norm (tests/test_gpu_defer.py).
+template <typename T, int DEFER>          // DEFER: 0 no; 1: a.nparts ranges; 4: four ranges (unrolled)
+__global__ __launch_bounds__(256) void rownorm_block_kernel(const RowNormArgs a) {
+    constexpr int CH = ElemTraits<T>::CHUNK, NC = 2;
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int nch = a.D / CH;
+    const float invD = 1.0f / (float)a.D;
+    const T* x = reinterpret_cast<const T*>(a.x) + row * a.ldx;
+    T* y = reinterpret_cast<T*>(a.y) + row * a.ldy;
+    const int64_t b = row / a.rows_per_batch;
+    const float* sc = a.scale ? a.scale + b * a.mod_stride : nullptr;
+    const float* sh = a.shift ? a.shift + b * a.mod_stride : nullptr;
+    Chunk16 v[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
+        v[i].u = (u32x4){0u, 0u, 0u, 0u};
+        if (c < nch) {
+            if constexpr (DEFER != 0) v[i] = deferred_chunk<T, DEFER == 4 ? 4 : 0>(a, row, b, c, true);
+            else v[i].u = *reinterpret_cast<const u32x4*>(x + c * CH);
+        }
+    }
+    auto block_sum = [&](float t, int slot) {
+        t = group_sum(t, 64);
+        if (lane == 0) red[slot][wave] = t;
+        __syncthreads();
+        return ((red[slot][0] + red[slot][1]) + red[slot][2]) + red[slot][3];
+    };
+    float mean = 0.f;
+    if (a.kind == 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { float f[CH]; chunk_to_f32<T>(v[i], f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) t += f[j]; }
+        mean = block_sum(t, 0) * invD;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (tid + i * 256 < nch) {
+            float f[CH]; chunk_to_f32<T>(v[i], f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float d = f[j] - mean; ss += d * d; }
+        }
+    }
+    ss = block_sum(ss, 1);
+    const float rinv = 1.0f / sqrtf(ss * invD + a.eps);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) { float f[CH]; chunk_to_f32<T>(v[i], f); finish_chunk<T>(a, f, mean, rinv, c, sc, sh, y, true); }
+    }
+}
+
 int pick_lpr(int nch) {
     int lpr = 1;
     while (lpr < nch && lpr < 64) lpr <<= 1;
@@ -780,6 +841,11 @@ void launch_rownorm_t(const RowNormArgs& a, int lpr, int nch, hipStream_t s) {
     if (nch <= lpr && a.rows >= (int64_t)rpw * NSLOT * 4 * 64) {       // narrow rows, enough of them: NSLOT rows per lane group
         const int64_t rows_per_block = (int64_t)4 * rpw * NSLOT;
         LTX_LAUNCH_TIMED((rownorm_kernel<T, 1>), dim3((unsigned)cdiv64(a.rows, rows_per_block)), dim3(256), 0, s, a, lpr);
+    } else if (a.rows <= 512 && nch > 64 && nch <= 512) {                  // few wide rows: one row per block
+        const dim3 grid((unsigned)a.rows);
+        if (a.parts && a.nparts == 4) LTX_LAUNCH_TIMED((rownorm_block_kernel<T, 4>), grid, dim3(256), 0, s, a);
+        else if (a.parts) LTX_LAUNCH_TIMED((rownorm_block_kernel<T, 1>), grid, dim3(256), 0, s, a);
+        else LTX_LAUNCH_TIMED((rownorm_block_kernel<T, 0>), grid, dim3(256), 0, s, a);
     } else {
         // (measured and left out, round 3: four rows per wave with the scale / shift operands cached in registers - 312 blocks
         // instead of 1248 - ran the DiT's 4992 x 2048 rows in 15.9 us against 12.8 us: the pass is bound by how many row loads are
@@ -822,7 +888,8 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     if (a.parts) {
         const int rpw = 64 / lpr;
         const bool narrow = nch <= lpr && a.rows >= (int64_t)rpw * NSLOT * 4 * 64;
-        if (a.presum || narrow || nch > NSLOT * lpr || a.nparts < 1 || a.nparts > 16 || !a.x_out || a.part_stride < a.rows * a.D || a.D % 8 ||
+        const bool block_rows = a.rows <= 512 && nch > 64 && nch <= 512;          // one row per block (rownorm_block_kernel)
+        if (a.presum || narrow || (nch > NSLOT * lpr && !block_rows) || a.nparts < 1 || a.nparts > 16 || !a.x_out || a.part_stride < a.rows * a.D || a.D % 8 ||
             ((uintptr_t)a.parts & 15) || (a.d_gate && (((uintptr_t)a.d_gate & 15) || a.d_gate_stride % 4)))
             LTX_FAIL(LTX_ERR_ARG, "rownorm: deferred rows need whole-row lanes (D of at most 64 x 8 chunks), 1..16 parts of [rows, D] f32 and an output for the finished rows");
     }
@@ -856,6 +923,85 @@ int ltx_launch_rownorm(const RowNormArgs& a, int dtype, hipStream_t s) {
     return LTX_OK;
 }
 
+namespace {
+// Few rows (C1's 384 tokens; the text rows of the cached cross-attention keys): one row per block, a chunk (two beyond 2048 columns)
+// per thread and segment - the arithmetic of qknorm_rope_fused_kernel, the row statistics summed lane butterfly first, then the four
+// wave sums in wave order (see rownorm_block_kernel): 6.6 -> ~4 us per launch at 384 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_block_kernel(const QkNormRopeArgs a) {
+    constexpr int CH = ElemTraits<T>::CHUNK, NC = 2;
+    static_assert(CH == 8, "bf16 rows only");
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int nch = a.D / CH;
+    const bool rope = a.cos != nullptr;
+    const float* cs = rope ? a.cos + row * (a.D / 2) : nullptr;
+    const float* sn = rope ? a.sin + row * (a.D / 2) : nullptr;
+    T* x0 = reinterpret_cast<T*>(a.x) + row * a.ld;
+    const int64_t sst = a.seg_stride ? a.seg_stride : a.D;
+    Chunk16 v[2][NC];
+    f32x4 co[NC], si[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
+        const bool in = c < nch;
+        v[0][i].u = (u32x4){0u, 0u, 0u, 0u}; v[1][i].u = (u32x4){0u, 0u, 0u, 0u};
+        if (in) v[0][i].u = *reinterpret_cast<const u32x4*>(x0 + c * CH);
+        if (in && a.nseg == 2) v[1][i].u = *reinterpret_cast<const u32x4*>(x0 + sst + c * CH);
+        if (in && rope) { co[i] = *reinterpret_cast<const f32x4*>(cs + c * 4); si[i] = *reinterpret_cast<const f32x4*>(sn + c * 4); }
+    }
+    float ss[2] = {0.f, 0.f};
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { float f[CH]; chunk_to_f32<T>(v[seg][i], f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) ss[seg] += f[j] * f[j]; }
+        ss[seg] = group_sum(ss[seg], 64);
+        if (lane == 0) red[seg][wave] = ss[seg];
+    }
+    __syncthreads();
+    float rinv[2];
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const float t = ((red[seg][0] + red[seg][1]) + red[seg][2]) + red[seg][3];
+        rinv[seg] = (seg == 0 ? a.out_scale0 : 1.0f) / sqrtf(t / (float)a.D + a.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
+        if (c >= nch) continue;
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            if (seg >= a.nseg) break;
+            const T* w = reinterpret_cast<const T*>(seg == 0 ? a.w0 : a.w1);
+            float f[CH]; chunk_to_f32<T>(v[seg][i], f);
+            Chunk16 wc; wc.u = *reinterpret_cast<const u32x4*>(w + c * CH);
+            float wv[CH]; chunk_to_f32<T>(wc, wv);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) f[j] = f[j] * rinv[seg] * wv[j];
+            if (seg == 0 && a.w0b) {
+                Chunk16 wc2; wc2.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.w0b) + c * CH);
+                float wv2[CH]; chunk_to_f32<T>(wc2, wv2);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) f[j] *= wv2[j];
+            }
+            if (rope) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float re = f[2 * p], im = f[2 * p + 1];
+                    f[2 * p] = re * co[i][p] - im * si[i][p];
+                    f[2 * p + 1] = im * co[i][p] + re * si[i][p];
+                }
+            }
+            Chunk16 o; f32_to_chunk<T>(f, o);
+            *reinterpret_cast<u32x4*>(x0 + seg * sst + c * CH) = o.u;
+        }
+    }
+}
+}  // namespace
+
 int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     const int ch = dtype == LTX_DT_BF16 ? 8 : 4;
     if (a.rows <= 0) return LTX_OK;
@@ -866,7 +1012,8 @@ int ltx_launch_qknorm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t s) {
     dim3 grid((unsigned)cdiv64(a.rows, rows_per_block)), block(256);
     const bool cached = nch <= NSLOT * lpr;
     if (dtype == LTX_DT_BF16) {
-        if (nch <= 4 * lpr) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 4>), grid, block, 0, s, a, lpr);
+        if (a.rows <= 512 && nch > 64 && nch <= 512) hipLaunchKernelGGL((qknorm_rope_block_kernel<bf16_t>), dim3((unsigned)a.rows), block, 0, s, a);      // few wide rows: one row per block
+        else if (nch <= 4 * lpr) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 4>), grid, block, 0, s, a, lpr);
         // the 13B model's 4096-wide rows: eight chunks per lane, the table still read once for q and k (LTX_QKNORM_FUSED8=0: the two-pass kernel)
         else if (nch <= 8 * lpr && ltx_exp("qknorm_fused8", 1)) hipLaunchKernelGGL((qknorm_rope_fused_kernel<bf16_t, 8, 2>), grid, block, 0, s, a, lpr);
         else if (cached) hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t, true>), grid, block, 0, s, a, lpr);
