@@ -131,8 +131,8 @@ struct RowNormArgs {
     const float* presum = nullptr; int presum_n = 0;
     // Rows that arrive as the K-range sums of the linear layer before them (GemmArgs::defer_parts: parts[p][row][D] f32): the row is
     // first FINISHED the way that layer's gate / residual epilogue would have - h = resid + gate * (((p0 + p1) + ...) + bias),
-    // rounded to T, resid = x (read), h written back to x_out (may alias x) - and then normalised as usual.  WIDE rows only
-    // (one wave per row); gate f32 [batch, gate_stride] or null (then h = resid + sum + bias).
+    // rounded to T, resid = x (read), h written back to x_out (may alias x) - and then normalised as usual.  Rows held whole in
+    // registers only (one wave per row, or - at most 512 rows - one block per row); gate f32 [batch, gate_stride] or null (then h = resid + sum + bias).
     const float* parts = nullptr; int nparts = 0; int64_t part_stride = 0;
     const void* d_bias = nullptr; const float* d_gate = nullptr; int d_gate_stride = 0; void* x_out = nullptr;
 };
