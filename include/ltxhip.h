@@ -239,7 +239,8 @@ int ltx_stream_synchronize(ltx_stream stream);
 /* ---- start-up control (no reference counterpart; speed only, never results) ----
  * ltx_warmup: run one forward (B, F*H*W tokens, K text tokens) and one decode of that latent geometry on scratch buffers,
  *   so that plan measurement, workspace sizing and code loading happen here and not inside the caller's first call.
- *   Either handle may be NULL.  Blocks until done.
+ *   Either handle may be NULL.  Blocks until done.  A guided ltx_pipeline_call runs its guidance branches as one forward of
+ *   branches x B rows (option guidance_batch): warm that geometry up with B = branches x batch (and the decode's with the batch itself).
  * ltx_set_autotune(0): never measure inside a call - shapes without a cached/loaded plan use the static cost model.
  * ltx_plan_save / ltx_plan_load: the measured plans of this process as a text file ("M N K conv ntaps T H W plan" per
  *   line); a loaded file makes a later process start with the same plans and without measuring. */
