@@ -394,6 +394,8 @@ def main():
     # Initialisation, not a warm-up step: plan measurement, workspace sizing and code loading happen here (ltx_warmup), so
     # that the W warm-up steps and the K timed steps all run the steady-state path even when the driver passes --warmup 0.
     ltxhip.warmup(dit, vae if cfg["mode"] != "tiles" else None, 1, F, H, W, 128)
+    if fwd_per_step > 1 and plan["team_size"] == 1:
+        ltxhip.warmup(dit, None, fwd_per_step, F, H, W, 128)      # the guidance branches of a step run as one forward of that many rows
     if not plan["idle"]:
         step()
         for _ in range(a.warmup):
