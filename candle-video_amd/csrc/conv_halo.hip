@@ -76,7 +76,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char halo_smem[];
 // of pieces stalls the only instruction stream of a SIMD while the same pieces spread over the step cost almost nothing.
 template <int BN, int WGM, int WGN, int EPI, bool PIPE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArgs g) {
-    constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    // (the 64-wide tile serves conv_out's 48 columns: three 16-column blocks are multiplied, the fourth - zero weight rows - is not)
+    constexpr int NW = WGM * WGN, BM = PH * PW, WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = BN == 64 ? 3 : WN / 16;
     static_assert((NW == 8 || (NW == 4 && PIPE)) && WM % 16 == 0 && WN % 16 == 0, "wave layout");
     constexpr int NTHR = NW * 64;
     // loader waves: the first wave of every SIMD issues all LDS-DMA pieces, its partner (wave + 4) starts on its MFMAs at
@@ -565,7 +566,7 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
     if (!g.conv || g.ntaps != 27 || g.kh != 3 || g.kw != 3) return false;
     if (g.Cin % 64 != 0 || g.K != g.Cin) return false;
     if (bn == 64) {                                         // the narrow tile: conv_out (N = 48, unpatchify epilogue), one n tile
-        if (epi != EPI_UNPATCH || g.N > 64 || g.N % 4 != 0) return false;
+        if (epi != EPI_UNPATCH || g.N > 48 || g.N % 4 != 0) return false;
     } else {
         if (g.N % bn != 0) return false;
         if (epi != EPI_BIAS && epi != EPI_RESID && epi != EPI_D2S) return false;
