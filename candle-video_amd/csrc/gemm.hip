@@ -189,6 +189,9 @@ int ltx_launch_gemm(const GemmArgs& g, int dtype, int epi, hipStream_t s) {
     if (!g.conv && g.lda % ch != 0) LTX_FAIL(LTX_ERR_ARG, "gemm: lda must be 16-byte aligned");
     if ((epi == EPI_D2S || epi == EPI_UNPATCH) && !g.conv) LTX_FAIL(LTX_ERR_ARG, "gemm: d2s/unpatch need conv mode");
     if (g.rowsq && (g.conv || g.c_seg_shift || epi == EPI_D2S || epi == EPI_UNPATCH)) LTX_FAIL(LTX_ERR_ARG, "gemm: rowsq needs a dense linear output");
+    // K ranges left to the consumer are gemm_ring's (through gemm_big's plan dispatch); no other kernel honours the field
+    if (g.defer_parts && (ltx_gemm_asm_eligible(g, dtype, epi) || !ltx_gemm_big_eligible(g, dtype)))
+        LTX_FAIL(LTX_ERR_ARG, "gemm: defer_parts set on a call that is not routed to the ring tiles (ask ltx_gemm_defer_ok first)");
     t_rowsq_done = false;
     void* tok = nullptr;
     ltx_prof_begin(g.conv ? LTX_PROF_CONV : LTX_PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * (g.conv ? g.ntaps : 1), s, &tok);

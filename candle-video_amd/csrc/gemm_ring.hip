@@ -486,6 +486,9 @@ bool ltx_gemm_ring_tile_fits(const GemmArgs& g, int epi, int tile) {
 bool ltx_gemm_defer_ok(const GemmArgs& g_in, int epi) {
     if (epi != EPI_GATE_RESID && epi != EPI_RESID) return false;
     GemmArgs g = g_in; g.bias = nullptr; g.resid = nullptr; g.gate = nullptr;
+    // the ring is reached through ltx_launch_gemm_big's plan dispatch only: with that family switched off (gemm_off=big) the call
+    // would fall to gemm.hip's kernel, which knows nothing of defer_parts
+    if (!ltx_gemm_big_eligible(g, LTX_DT_BF16)) return false;
     return g.M <= 512 && g.N % 8 == 0 && !g.rowsq && !g.c_seg_shift && ltx_gemm_ring_fits(g, EPI_BIAS);
 }
 

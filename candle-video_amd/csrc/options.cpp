@@ -1,5 +1,6 @@
 // options.h: parsing of LTX_OPTIONS / ltx_set_option.
 #include "options.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,7 +12,7 @@
 namespace {
 std::mutex g_mu;
 LtxOptions g_opt;
-bool g_loaded = false;
+std::atomic<bool> g_loaded{false};                    // published with release / read with acquire: the first ltx_opt() of any thread sees a complete g_opt
 std::map<std::string, int> g_exp;                       // "x_name" -> value (read only under LTX_EXPERIMENTS)
 
 struct ListBit { const char* name; unsigned bit; };
@@ -86,12 +87,12 @@ void load_locked() {
     std::string bad;
     if (!parse_string(g_opt, getenv("LTX_OPTIONS"), &bad))
         fprintf(stderr, "[ltx] LTX_OPTIONS: entry '%s' not understood (see include/ltxhip.h); it and what follows it are ignored\n", bad.c_str());
-    g_loaded = true;
+    g_loaded.store(true, std::memory_order_release);
 }
 }  // namespace
 
 const LtxOptions& ltx_opt() {
-    if (!g_loaded) { std::lock_guard<std::mutex> lock(g_mu); if (!g_loaded) load_locked(); }
+    if (!g_loaded.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lock(g_mu); if (!g_loaded.load(std::memory_order_relaxed)) load_locked(); }
     return g_opt;
 }
 
@@ -107,6 +108,25 @@ extern "C" int ltx_set_option(const char* key, const char* value) {
     (void)ltx_opt();
     std::lock_guard<std::mutex> lock(g_mu);
     if (!set_one(g_opt, key, value)) LTX_FAIL(LTX_ERR_ARG, std::string("ltx_set_option: unknown option or bad value: ") + key + "=" + (value ? value : "(default)"));
+    return LTX_OK;
+}
+
+// The current value of an option as ltx_set_option would take it back (lists as "a+b", "" = none / default plan).
+extern "C" int ltx_get_option(const char* key, char* out, int n) {
+    if (!key || !out || n < 2) LTX_FAIL(LTX_ERR_ARG, "ltx_get_option: null key / buffer");
+    (void)ltx_opt();
+    std::lock_guard<std::mutex> lock(g_mu);
+    const std::string k(key);
+    std::string v; bool found = false;
+    for (const auto& f : kInts) if (k == f.name) { v = std::to_string(g_opt.*(f.field)); found = true; }
+    auto list = [&](unsigned bits, const ListBit* tab, size_t cnt) { for (size_t i = 0; i < cnt; ++i) if (bits & tab[i].bit) { if (!v.empty()) v += "+"; v += tab[i].name; } found = true; };
+    if (k == "gemm_plan") { v = g_opt.gemm_plan; found = true; }
+    if (k == "gemm_off") list(g_opt.gemm_off, kFam, sizeof(kFam) / sizeof(kFam[0]));
+    if (k == "attn_off") list(g_opt.attn_off, kAttn, sizeof(kAttn) / sizeof(kAttn[0]));
+    if (k.rfind("x_", 0) == 0) { auto it = g_exp.find(k); if (it == g_exp.end()) LTX_FAIL(LTX_ERR_ARG, "ltx_get_option: experiment knob not set: " + k); v = std::to_string(it->second); found = true; }
+    if (!found) LTX_FAIL(LTX_ERR_ARG, "ltx_get_option: unknown option: " + k);
+    if ((int)v.size() + 1 > n) LTX_FAIL(LTX_ERR_ARG, "ltx_get_option: buffer too small");
+    memcpy(out, v.c_str(), v.size() + 1);
     return LTX_OK;
 }
 

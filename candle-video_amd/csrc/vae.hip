@@ -333,10 +333,10 @@ int time_mod(ltx_vae* v, const TimeEmbW& te, const void* sst, const TimeVec& tv,
 // one injection: the next plane of the handle's noise stream, y = x + plane[h, w] * scale[c] (+ shortcut)
 int inject_noise(ltx_vae* v, const void* x, void* y, const void* scale, const void* shortcut, const Dims& d, int ch, hipStream_t s) {
     const int64_t hw = (int64_t)d.H * d.W;
+    HIP_TRY(hipStreamSynchronize(s));                       // the previous injection's copy may still be reading the (pageable) host image, its kernel the plane
     v->noise_host.resize((size_t)hw);
     LTX_TRY(ltx_pcg32_randn(v->noise_seed, v->noise_ctr++, (size_t)hw, v->noise_host.data()));
     LTX_TRY(v->noise_plane.ensure((size_t)hw * sizeof(float)));
-    HIP_TRY(hipStreamSynchronize(s));                       // the plane buffer and its host image are re-used by the next injection
     HIP_TRY(hipMemcpyAsync(v->noise_plane.p, v->noise_host.data(), (size_t)hw * sizeof(float), hipMemcpyHostToDevice, s));
     return ltx_launch_noise_inject(x, y, v->noise_plane.as<float>(), scale, shortcut, d.vox(), ch, hw, v->dtype, s);
 }

@@ -326,8 +326,11 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     // The guidance branches of a step (:860-940: up to three B-row forwards on the same latents - negative prompt, prompt, prompt with
     // the STG blocks skipped) as ONE forward of nbr * B rows where that fits the DiT's 8-row pass: branch rows are independent, every
     // plan of a GEMM shape returns the same bits, and a row that skips a layer keeps its row partials (dit.hip) - so each branch's
-    // prediction is, bit for bit, the separate forward's, at 2.5 instead of 3 rounds of the chip per attention launch and fewer
-    // one-round grids (one C3 step 61.8 -> 58.1 ms).  guidance_batch=0: the reference's three calls.
+    // prediction is, bit for bit, the separate forward's WHERE B * S and nbr * B * S rows take the same kernels and K partition
+    // (above 512 rows per branch: C2 / C3 / C5; at a few hundred tokens the split-K factor, the one-row-per-block norms and the
+    // deferred ff2 depend on the row count and the two forms agree to rounding only: tests/test_gpu_c3.py), at 2.5 instead of 3
+    // rounds of the chip per attention launch and fewer one-round grids (one C3 step 61.8 -> 58.1 ms).  guidance_batch=0: the
+    // reference's three calls.
     const int nbr = 1 + (do_cfg ? 1 : 0) + (do_stg ? 1 : 0);
     const bool gbatch = nbr > 1 && nbr * B <= 8 && ltx_opt().guidance_batch;
     const int Dt = dc.caption_channels;

@@ -107,7 +107,7 @@ _SIGS = {
     "ltx_device_alloc": [_sz, _i, _vp], "ltx_device_free": [_vp], "ltx_memcpy_h2d": [_vp, _vp, _sz, _vp], "ltx_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "ltx_stream_synchronize": [_vp],
     "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
-    "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_reset_options": [], "ltx_has_experiments": [],
+    "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_get_option": [C.c_char_p, C.c_char_p, C.c_int], "ltx_reset_options": [], "ltx_has_experiments": [],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -317,6 +317,9 @@ class LtxVideoTransformer3DModel:
                 raise LtxError("context_cache(True) needs encoder_hidden_states / encoder_attention_mask that are already contiguous and of "
                                "the dtype the call uses (hidden_states' dtype / float32): a temporary copy has no stable identity")
         vc = _dev(video_coords, torch.float32) if video_coords is not None else None
+        if getattr(self, "_ctx_cache", False) and vc is not None and vc.data_ptr() != video_coords.data_ptr():
+            raise LtxError("context_cache(True) needs video_coords that are already a contiguous float32 device tensor: the RoPE "
+                           "tables of the scope are kept per coords POINTER, a temporary copy has no stable identity")
         slm = None
         if skip_layer_mask is not None:
             slm = _floats(skip_layer_mask.detach().float().cpu().flatten().tolist())
@@ -922,14 +925,26 @@ def has_experiments() -> bool:
     return bool(lib.ltx_has_experiments())
 
 
+def get_option(key: str):
+    """ltx_get_option: the option's current value as text (None: an experiment knob that is not set)"""
+    buf = C.create_string_buffer(256)
+    if lib.ltx_get_option(key.encode(), buf, 256) != 0:
+        if key.startswith("x_"):
+            return None
+        _check(1)
+    return buf.value.decode()
+
+
 class options:
-    """with ltxhip.options(gemm_tune=0, gemm_off="asm16"): ...  - options set for the block, defaults restored after it"""
+    """with ltxhip.options(gemm_tune=0, gemm_off="asm16"): ...  - options set for the block, the PREVIOUS values (LTX_OPTIONS'
+    or an outer block's) restored after it"""
     def __init__(self, **kw): self.kw = kw
     def __enter__(self):
+        self.prev = {k: get_option(k) for k in self.kw}
         for k, v in self.kw.items(): set_option(k, v)
         return self
     def __exit__(self, *a):
-        for k in self.kw: set_option(k, None)
+        for k, v in self.prev.items(): set_option(k, v)
         return False
 
 

@@ -123,7 +123,9 @@ int ltx_dit_forward(ltx_dit* m, const void* hidden, const void* enc, const float
 /* Extension (no reference counterpart; results are identical): between enable=1 and enable=0 the caller promises
  * that an (enc pointer, enc_mask pointer, B, K) tuple identifies unchanged contents, so the caption projection
  * and the per-layer cross-attention K/V (which do not depend on timestep or latents, ltx_transformer.rs:1056,
- * 667-672) are computed once per tuple instead of once per forward.  ltx_pipeline_call uses it around its loop. */
+ * 667-672) are computed once per tuple instead of once per forward; likewise a (video_coords pointer - or NULL -, B, S, grid,
+ * rope_scale, stream) tuple identifies unchanged coordinates: the RoPE tables of the previous forward are kept while it repeats.
+ * Buffers whose contents change inside the scope must change address (or the scope be closed).  ltx_pipeline_call uses it around its loop. */
 int ltx_dit_context_cache(ltx_dit* m, int enable);
 
 /* ---- VaeLtxVideo (AutoencoderKLLtxVideo::new decoder side, vae.rs:1765-1869) ---- */
@@ -251,7 +253,9 @@ int ltx_plan_load(const char* path);
 
 /* ---- run-time options (A/B and diagnostic aids; the engine needs none of them) ----
  * One set of options per process: read ONCE, at first use, from the environment variable LTX_OPTIONS = "key=value,key=value",
- * changed with ltx_set_option (value NULL: the option's default), restored with ltx_reset_options (defaults + LTX_OPTIONS again).
+ * changed with ltx_set_option (value NULL: the option's default), read back with ltx_get_option (the text ltx_set_option takes),
+ * restored with ltx_reset_options (defaults + LTX_OPTIONS again).  Options are process state read by every launch WITHOUT a lock:
+ * change them only while no other thread is inside a library call (tests and A/B drivers do; a serving process sets them once).
  * No launch path reads the environment.  The only other environment variable of the library is LTX_RCCL_LIB (path of the
  * RCCL library ltxhip_team.h loads).
  *
@@ -280,11 +284,15 @@ int ltx_plan_load(const char* path);
  *                          the chip or more; 2: fused on smaller grids too)
  *   t5_attn_mfma=0         the scalar T5 attention kernel
  *   guidance_batch=0       ltx_pipeline_call runs the guidance branches of a step (negative prompt / prompt / prompt with the STG
- *                          blocks skipped) as separate forwards, the reference's call order (default: one forward of up to 8 rows; same bits)
+ *                          blocks skipped) as separate forwards, the reference's call order (default: one forward of up to 8 rows.
+ *                          The same bits where B * S and branches * B * S rows select the same kernels and K partition - every shape
+ *                          above 512 rows per branch, C2 / C3 / C5 among them; at a few hundred tokens the row-count-dependent
+ *                          choices (split-K factor, one-row-per-block norms, deferred ff2) differ and the two forms agree to rounding)
  *   attn_off=a+b           attention kernels left out: q64, q128, cross, pipe (the next more general kernel serves)
  * Measured-negative experiments and tuning knobs ("x_name=int") exist only in builds made with -DLTX_EXPERIMENTS
  * (`make -C candle-video_amd experiments`, for tools/); the shipped library ignores them.  ltx_has_experiments() tells. */
 int ltx_set_option(const char* key, const char* value);
+int ltx_get_option(const char* key, char* out, int out_bytes);
 int ltx_reset_options(void);
 int ltx_has_experiments(void);
 

@@ -73,3 +73,19 @@ def test_dit_with_few_tokens_defers_ff2_and_returns_the_same_bits(hip):
     want = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, Fr, H, W, None, coords)
     e = float((out.float().cpu() - want).norm() / want.norm())
     assert e <= 2e-2, e
+    # gemm_off=big (a documented A/B arm): gemm.hip's kernel serves the layer and knows nothing of deferred ranges - the
+    # deferral must switch itself off (ltx_gemm_defer_ok), not leave the row norm reading an unwritten parts buffer
+    with hip.options(gemm_off="big"):
+        alt = model.forward(*args)
+    e = float((alt.float().cpu() - want).norm() / want.norm())
+    assert e <= 2e-2, e
+
+
+def test_deferred_linear_is_refused_when_its_kernel_family_is_off(hip):
+    x = torch.randn(96, 8192).bfloat16().to(DEV); w = torch.randn(512, 8192).bfloat16().to(DEV)
+    with hip.options(gemm_off="big"):
+        with pytest.raises(hip.LtxError):
+            hip.ops.linear_deferred(x, w)
+    with hip.options(gemm_off="ring"):
+        with pytest.raises(hip.LtxError):
+            hip.ops.linear_deferred(x, w)

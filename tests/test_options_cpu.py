@@ -27,6 +27,25 @@ def test_set_reset_and_bad_entries():
     assert ltxhip.has_experiments() is False                    # the shipped library: measured-negative variants compiled out
 
 
+def test_get_option_reads_back_and_the_with_block_restores_previous_values():
+    import ltxhip
+    ltxhip.reset_options()
+    assert ltxhip.get_option("ff2_defer") == "1" and ltxhip.get_option("gemm_off") == "" and ltxhip.get_option("gemm_plan") == ""
+    ltxhip.set_option("gemm_off", "ring+big"); ltxhip.set_option("norm_presum", 2); ltxhip.set_option("gemm_plan", "asm16")
+    assert ltxhip.get_option("gemm_off") == "ring+big"
+    with ltxhip.options(gemm_off="asm16", norm_presum=0, gemm_plan="ring", x_knob=5):
+        assert ltxhip.get_option("gemm_off") == "asm16" and ltxhip.get_option("norm_presum") == "0" and ltxhip.get_option("x_knob") == "5"
+        with ltxhip.options(gemm_off=None):
+            assert ltxhip.get_option("gemm_off") == ""
+        assert ltxhip.get_option("gemm_off") == "asm16"
+    # the values from before the block, not the built-in defaults
+    assert ltxhip.get_option("gemm_off") == "ring+big" and ltxhip.get_option("norm_presum") == "2" and ltxhip.get_option("gemm_plan") == "asm16"
+    assert ltxhip.get_option("x_knob") is None
+    with pytest.raises(ltxhip.LtxError, match="unknown option"):
+        ltxhip.get_option("no_such_option")
+    ltxhip.reset_options()
+
+
 def test_no_environment_reads_outside_the_option_parser():
     """The product sources read the environment in exactly two places: options.cpp (LTX_OPTIONS, once) and the RCCL loader's
     library path."""
