@@ -237,6 +237,13 @@ extern "C" int ltx_pipeline_last_timing(float ms[4]) {
     return LTX_OK;
 }
 
+static thread_local int t_steps[2] = {0, 0};
+extern "C" int ltx_pipeline_last_steps(int* executed, int* requested) {
+    if (executed) *executed = t_steps[0];
+    if (requested) *requested = t_steps[1];
+    return LTX_OK;
+}
+
 namespace {
 // Device scratch of the denoise loop, kept per (thread, device) across calls: per-call hipMalloc/hipFree (an implicit
 // device sync each) and the coords rebuild + blocking upload cost ~1 ms per video for nothing.
@@ -367,7 +374,18 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
     struct CtxScope { ltx_dit* d; ~CtxScope() { (void)ltx_dit_context_cache(d, 0); } } ctx_scope{dit};
     LTX_TRY(ltx_dit_context_cache(dit, 1));     // embeddings/masks are step-invariant inside one call
     // denoising loop (:860-994)
+    const bool hooked = p->interrupt != nullptr || p->on_step != nullptr;
+    bool stopped = false; int steps_run = 0;
+    std::vector<hipEvent_t> done_ev;                        // e2 of every executed step (owned by sc.step_ev)
     for (int i = 0; i < N; ++i) {
+        // interrupt / per-step hook (:861-865).  The loop only ENQUEUES work: the host stays at most one step ahead of the device
+        // here, so that a flag raised while step k runs skips from step k + 2 on at the latest
+        if (hooked) {
+            if (done_ev.size() >= 2) HIP_TRY(hipEventSynchronize(done_ev[done_ev.size() - 2]));
+            if (!stopped && p->on_step && p->on_step(p->on_step_user, i, N, ts[i]) != 0) stopped = true;
+            if (stopped || (p->interrupt && *p->interrupt)) continue;
+        }
+        ++steps_run;
         float tvals[8]; for (int b = 0; b < 8; ++b) tvals[b] = (float)ts[i];       // Tensor::full(t as f32, (b,))
         hipEvent_t e0, e1, e2;
         LTX_TRY(sc.new_event(&e0)); LTX_TRY(sc.new_event(&e1)); LTX_TRY(sc.new_event(&e2));
@@ -392,7 +410,9 @@ extern "C" int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_
             LTX_TRY(ltx_guidance_step(sc.p_text, do_cfg ? sc.p_uncond : nullptr, do_stg ? sc.p_pert : nullptr, LTX_F32, latents, nullptr, B, n,
                                       p->guidance_scale, p->guidance_rescale, p->stg_scale, dts, sc.stats, s));
         HIP_TRY(hipEventRecord(e2, s));
+        done_ev.push_back(e2);
     }
+    t_steps[0] = steps_run; t_steps[1] = N;
     HIP_TRY(hipEventRecord(sc.ev[1], s));
     if (!p->output_latent) {
         // unpack + denormalize + noise mix + decode + postprocess (:1002-1070)

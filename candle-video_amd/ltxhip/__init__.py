@@ -81,7 +81,11 @@ class PipelineParamsC(C.Structure):
                 ("decode_timestep", C.c_float), ("decode_noise_scale", C.c_float),
                 ("output_latent", C.c_int), ("postprocess", C.c_int), ("tiling", C.POINTER(TilingC)),
                 ("shift_terminal", C.c_float), ("use_shift_terminal", C.c_int),
-                ("stochastic_sampling", C.c_int), ("step_noise", C.POINTER(C.c_float))]
+                ("stochastic_sampling", C.c_int), ("step_noise", C.POINTER(C.c_float)),
+                ("interrupt", C.POINTER(C.c_int)), ("on_step", C.c_void_p), ("on_step_user", C.c_void_p)]
+
+
+StepFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64)     # ltx_step_fn
 
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -107,7 +111,7 @@ _SIGS = {
     "ltx_device_alloc": [_sz, _i, _vp], "ltx_device_free": [_vp], "ltx_memcpy_h2d": [_vp, _vp, _sz, _vp], "ltx_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "ltx_stream_synchronize": [_vp],
     "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
-    "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_get_option": [C.c_char_p, C.c_char_p, C.c_int], "ltx_reset_options": [], "ltx_has_experiments": [],
+    "ltx_pipeline_last_steps": [C.POINTER(C.c_int), C.POINTER(C.c_int)], "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_get_option": [C.c_char_p, C.c_char_p, C.c_int], "ltx_reset_options": [], "ltx_has_experiments": [],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -756,9 +760,12 @@ class LtxPipeline:
 
     def call(self, args: PipelineCall, latents: torch.Tensor, prompt_embeds: torch.Tensor, prompt_attention_mask: torch.Tensor,
              negative_prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_attention_mask: Optional[torch.Tensor] = None,
-             decode_noise: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None):
+             decode_noise: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None,
+             interrupt=None, on_step=None):
         """Returns (final_latents [B,S,C] f32, video [B,3,frames,H,W] f32 or None).
-        step_noise [steps,B,S,C] f32: the per-step draws of the stochastic-sampling scheduler (required iff enabled)."""
+        step_noise [steps,B,S,C] f32: the per-step draws of the stochastic-sampling scheduler (required iff enabled).
+        interrupt: a ctypes.c_int the caller may set from another thread (LtxPipeline::interrupt, t2v_pipeline.rs:266, 861-863);
+        on_step(step, num_steps, timestep) -> truthy to stop: the per-step hook.  self.last_steps = (executed, requested)."""
         lat = _dev(latents, torch.float32).clone()
         pe = _dev(prompt_embeds, torch.float32)
         pm = _dev(prompt_attention_mask, torch.float32)
@@ -808,6 +815,18 @@ class LtxPipeline:
         if tl is not None:
             keep.append(tl)
             p.tiling = C.pointer(tl)
+        if interrupt is not None:
+            p.interrupt = C.pointer(interrupt)
+        hook_exc = []
+        if on_step is not None:
+            def _hook(_user, step, num_steps, timestep):
+                try:
+                    return 1 if on_step(step, num_steps, timestep) else 0
+                except BaseException as exc:                  # never unwind through the C frame: stop the loop, re-raise after the call
+                    hook_exc.append(exc)
+                    return 1
+            cb = StepFn(_hook); keep.append(cb)
+            p.on_step = C.cast(cb, C.c_void_p)
         video = None
         if not args.output_latent:
             if self.vae is None:
@@ -820,6 +839,11 @@ class LtxPipeline:
         ms = (C.c_float * 4)()
         _check(lib.ltx_pipeline_last_timing(ms))
         self.last_timing_ms = tuple(ms)
+        ex, rq = C.c_int(0), C.c_int(0)
+        _check(lib.ltx_pipeline_last_steps(C.byref(ex), C.byref(rq)))
+        self.last_steps = (ex.value, rq.value)
+        if hook_exc:
+            raise hook_exc[0]
         return lat, video
 
 

@@ -201,6 +201,10 @@ int ltx_pcg32_u32(uint64_t seed, uint64_t inc, size_t n, uint32_t* out_host);
 int ltx_build_video_coords(int F, int H, int W, int frame_rate, int ts_ratio, int sp_ratio, float* out_host);
 
 /* ---- LtxPipeline::call (t2v_pipeline.rs:627-1073) with embeddings supplied ---- */
+/* Per-step host hook: called on the calling thread before step `step` (0-based) of `num_steps` is enqueued, with the timestep the
+ * model will see (LtxPipeline::current_timestep, t2v_pipeline.rs:865).  Non-zero return = interrupt: this and every later step is
+ * skipped.  The hook must not call into the library on the same handles. */
+typedef int (*ltx_step_fn)(void* user, int step, int num_steps, int64_t timestep);
 typedef struct {
     int height, width, num_frames, frame_rate;
     int num_inference_steps;
@@ -216,6 +220,13 @@ typedef struct {
     int stochastic_sampling;        /* scheduler config (configs.rs:16; main.rs:550): stochastic step instead of Euler */
     const float* step_noise;        /* DEVICE f32 [num_inference_steps, B, S*C]: the per-step randn_like(sample) draws;
                                        required iff stochastic_sampling */
+    const volatile int* interrupt;  /* HOST flag or NULL = LtxPipeline::interrupt (t2v_pipeline.rs:266, 861-863): read before every
+                                       step; while non-zero the step is skipped (`continue`), the decode of the latents reached
+                                       so far still runs, as in the reference */
+    ltx_step_fn on_step;            /* NULL or the per-step hook above */
+    void* on_step_user;
+    /* With either of the two set, the host stays at most ONE step ahead of the device (it waits for step i-2 before polling for
+     * step i), so a raised flag costs at most two more steps; without them the whole loop is enqueued without a wait. */
 } ltx_pipeline_params;
 void ltx_pipeline_params_default(ltx_pipeline_params* p);
 /*   latents [B,S,128] f32 packed, updated in place;  prompt_embeds [B,K,4096] f32;  prompt_mask [B,K] f32;
@@ -228,6 +239,8 @@ int ltx_pipeline_call(ltx_dit* dit, ltx_vae* vae, const ltx_pipeline_params* p,
 /* per-stage wall time of the last ltx_pipeline_call on this thread, measured with hipEvents:
  * ms[0] = all DiT forwards, ms[1] = guidance+Euler, ms[2] = VAE decode (+denorm), ms[3] = total */
 int ltx_pipeline_last_timing(float ms[4]);
+/* denoise steps executed / requested by the last ltx_pipeline_call on this thread (they differ after an interrupt) */
+int ltx_pipeline_last_steps(int* executed, int* requested);
 
 /* ---- device memory for hosts without HIP bindings of their own (rust/hip_backend.rs keeps candle tensors on the CPU
  * device and moves the few MB per step itself; candle has no ROCm backend).  Copies are enqueued on `stream` and are

@@ -992,10 +992,13 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
                   neg_embeds: Optional[Tensor] = None, neg_mask: Optional[Tensor] = None,
                   decode_noise: Optional[Tensor] = None, dtype=torch.float32,
                   sched_cfg: SchedulerCfg = SchedulerCfg(), trajectory: Optional[list] = None,
-                  step_noise: Optional[Tensor] = None, timestep_cast: Optional[torch.dtype] = None) -> Tensor:
+                  step_noise: Optional[Tensor] = None, timestep_cast: Optional[torch.dtype] = None,
+                  interrupt_at: Optional[int] = None) -> Tensor:
     """LtxPipeline::call (t2v_pipeline.rs:627-1073) with embeddings supplied
     (text encoder out of scope) and the decode noise supplied explicitly (the
-    reference draws it from the device RNG, :1055)."""
+    reference draws it from the device RNG, :1055).  interrupt_at = k: `self.interrupt`
+    raised before step k - that and every later step is skipped (`continue`, :861-863),
+    the decode of the latents reached so far still runs."""
     do_cfg = args.guidance_scale > 1.0
     do_stg = args.stg_scale > 0.0
     skip_perm: Sequence[int] = ()
@@ -1023,7 +1026,9 @@ def pipeline_call(dit_p, dit_cfg: DitConfig, vae_p, vae_cfg: VaeConfig, latents_
                            None, coords, slm, skip_perm, dtype)
 
     trajectory_idx: list = []
-    for t in ts:
+    for i_step, t in enumerate(ts):
+        if interrupt_at is not None and i_step >= interrupt_at:
+            continue
         if do_cfg or do_stg:
             un = fwd(neg_embeds, neg_mask, t) if do_cfg else None
             tx = fwd(prompt_embeds, prompt_mask, t)

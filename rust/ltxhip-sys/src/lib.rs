@@ -119,6 +119,9 @@ pub struct ltx_pipeline_params {
     pub use_shift_terminal: c_int,
     pub stochastic_sampling: c_int,
     pub step_noise: *const c_float,
+    pub interrupt: *const c_int,
+    pub on_step: Option<unsafe extern "C" fn(user: *mut c_void, step: c_int, num_steps: c_int, timestep: i64) -> c_int>,
+    pub on_step_user: *mut c_void,
 }
 
 // ---- layout guard: (size, align) per struct on LP64, compared with tests/cabi_layout.c by tests/test_cabi_layout_cpu.py ----
@@ -126,7 +129,7 @@ pub const LAYOUT_LTX_WEIGHT: (usize, usize) = (72, 8);
 pub const LAYOUT_LTX_DIT_CONFIG: (usize, usize) = (40, 4);
 pub const LAYOUT_LTX_VAE_CONFIG: (usize, usize) = (148, 4);
 pub const LAYOUT_LTX_TILING: (usize, usize) = (32, 4);
-pub const LAYOUT_LTX_PIPELINE_PARAMS: (usize, usize) = (112, 8);
+pub const LAYOUT_LTX_PIPELINE_PARAMS: (usize, usize) = (136, 8);
 pub const LAYOUT_LTX_T5_CONFIG: (usize, usize) = (36, 4);
 const _: () = assert!(size_of::<ltx_weight>() == LAYOUT_LTX_WEIGHT.0 && align_of::<ltx_weight>() == LAYOUT_LTX_WEIGHT.1);
 const _: () = assert!(size_of::<ltx_dit_config>() == LAYOUT_LTX_DIT_CONFIG.0 && align_of::<ltx_dit_config>() == LAYOUT_LTX_DIT_CONFIG.1);
@@ -175,6 +178,8 @@ extern "C" {
 
     // whole LtxPipeline::call on the device (t2v_pipeline.rs:627-1073)
     pub fn ltx_pipeline_params_default(p: *mut ltx_pipeline_params);
+    pub fn ltx_pipeline_last_steps(executed: *mut c_int, requested: *mut c_int) -> c_int;
+    pub fn ltx_get_option(key: *const c_char, out: *mut c_char, out_bytes: c_int) -> c_int;
     pub fn ltx_pipeline_call(dit: *mut ltx_dit, vae: *mut ltx_vae, p: *const ltx_pipeline_params, latents: *mut c_float, prompt_embeds: *const c_float,
         prompt_mask: *const c_float, neg_embeds: *const c_float, neg_mask: *const c_float, decode_noise: *const c_float, b: c_int, k: c_int,
         out_video: *mut c_float, stream: ltx_stream) -> c_int;

@@ -33,7 +33,8 @@ int main(void) {
         F(ltx_pipeline_params, num_inference_steps); F(ltx_pipeline_params, sigmas); F(ltx_pipeline_params, guidance_scale); F(ltx_pipeline_params, guidance_rescale);
         F(ltx_pipeline_params, stg_scale); F(ltx_pipeline_params, skip_block_list); F(ltx_pipeline_params, n_skip_blocks); F(ltx_pipeline_params, decode_timestep);
         F(ltx_pipeline_params, decode_noise_scale); F(ltx_pipeline_params, output_latent); F(ltx_pipeline_params, postprocess); F(ltx_pipeline_params, tiling);
-        F(ltx_pipeline_params, shift_terminal); F(ltx_pipeline_params, use_shift_terminal); F(ltx_pipeline_params, stochastic_sampling); F(ltx_pipeline_params, step_noise); END();
+        F(ltx_pipeline_params, shift_terminal); F(ltx_pipeline_params, use_shift_terminal); F(ltx_pipeline_params, stochastic_sampling); F(ltx_pipeline_params, step_noise);
+        F(ltx_pipeline_params, interrupt); F(ltx_pipeline_params, on_step); F(ltx_pipeline_params, on_step_user); END();
     BEGIN(ltx_t5_config); F(ltx_t5_config, vocab_size); F(ltx_t5_config, d_model); F(ltx_t5_config, d_kv); F(ltx_t5_config, d_ff); F(ltx_t5_config, num_layers);
         F(ltx_t5_config, num_heads); F(ltx_t5_config, relative_attention_num_buckets); F(ltx_t5_config, relative_attention_max_distance); F(ltx_t5_config, layer_norm_epsilon); END();
     printf("}\n");
