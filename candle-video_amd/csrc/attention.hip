@@ -31,6 +31,15 @@
 #ifndef ATTN_TR_ASM
 #define ATTN_TR_ASM 1
 #endif
+// Diagnostic: launches of the gated exact pass that actually ran (attn_q128_kernel's fixed first-tile max overflowed) since the
+// last reset.  Touched only by such a launch.
+__device__ unsigned long long q128_exact_launches;
+int ltx_q128_fallback_read(unsigned long long* out, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(q128_exact_launches), sizeof(*out)));
+    if (reset) { const unsigned long long z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(q128_exact_launches), &z, sizeof(z))); }
+    return LTX_OK;
+}
+
 namespace {
 
 constexpr int BQ = 128, BKV = 64;
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? (PRE ? 2 : 1) : (HD == 64 ? 3 : 2
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * TILE_BYTES];
 
     if (a.gate_flag && *a.gate_flag != a.gate_ticket) return;     // exact pass behind attn_q128_kernel: only after an overflow in THAT launch
+    if (a.gate_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q128_exact_launches, 1ull);      // diagnostic (ltx_attention_fallback_counts)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // 1-D grid.  Blocks L and L+8 share an XCD (one L2): with heads % 8 == 0 every XCD is given WHOLE heads

@@ -65,6 +65,15 @@ extern "C" int ltx_dbg_q64_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+// Diagnostic: workgroups that took the exact-max second pass since the last reset (fixed first-tile max overflowed).  Touched only
+// on that path - the fast path never reads or writes it.
+__device__ unsigned long long q64_fallback_blocks;
+int ltx_q64_fallback_read(unsigned long long* out, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(q64_fallback_blocks), sizeof(*out)));
+    if (reset) { const unsigned long long z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(q64_fallback_blocks), &z, sizeof(z))); }
+    return LTX_OK;
+}
+
 namespace {
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
@@ -631,6 +640,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
         // l beyond 2^100 (or NaN): some p overflowed, or came within 2^27 of it - O^T is then not to be trusted either
         if (Q64_NO_FALLBACK || !block_any(bad)) return;
         need_exact = true;
+        if (tid == 0) atomicAdd(&q64_fallback_blocks, 1ull);
     }
 #endif
 
@@ -694,6 +704,7 @@ __device__ __forceinline__ void attn_q64_block(const AttnArgs& a, unsigned char*
                 for (int i = 0; i < 16; ++i) chk += acc_o[qb][0][i] * 0.f + acc_o[qb][1][i] * 0.f;
             }
             if (Q64_NO_FALLBACK || !block_any(!(chk == 0.f))) break;      // inf * 0 and NaN * 0 are NaN
+            if (tid == 0) atomicAdd(&q64_fallback_blocks, 1ull);
         }
     }
 

@@ -61,6 +61,12 @@ extern "C" int ltx_op_rownorm(const void* x, void* y, int64_t rows, int D, int k
     return ltx_launch_rownorm(a, dtc(dtype), (hipStream_t)stream);
 }
 
+extern "C" int ltx_attention_fallback_counts(unsigned long long counts[2], int reset) {
+    if (!counts) LTX_FAIL(LTX_ERR_ARG, "ltx_attention_fallback_counts: null output");
+    LTX_TRY(ltx_q64_fallback_read(&counts[0], reset));
+    return ltx_q128_fallback_read(&counts[1], reset);
+}
+
 extern "C" int ltx_op_linear_split_factor(int M, int N, int K) {
     GemmArgs g; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
     return ltx_gemm_split_factor(g);

@@ -187,6 +187,8 @@ struct AttnArgs {
 };
 bool ltx_attention_q128_fits(const AttnArgs& a);           // attn_q128.hip: head_dim 128 one-wave-per-SIMD kernel
 int ltx_launch_attention_q128(const AttnArgs& a, hipStream_t s, int** flag_out, int* ticket_out);
+int ltx_q64_fallback_read(unsigned long long* out, int reset);      // attn_q64.hip / attention.hip: diagnostic counters of the exact-max second passes
+int ltx_q128_fallback_read(unsigned long long* out, int reset);
 int ltx_attention_q128_prepare();   // allocate + zero the current device's overflow flags outside any launch path (create / warm-up)
 int ltx_launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s);   // attn_q64.hip: head_dim 64, q prescaled, 64 queries per wave (caller sets xcd_heads / wide_o)

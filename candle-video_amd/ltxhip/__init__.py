@@ -111,7 +111,7 @@ _SIGS = {
     "ltx_device_alloc": [_sz, _i, _vp], "ltx_device_free": [_vp], "ltx_memcpy_h2d": [_vp, _vp, _sz, _vp], "ltx_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "ltx_stream_synchronize": [_vp],
     "ltx_warmup": [_vp, _vp, _i, _i, _i, _i, _i, _vp], "ltx_set_autotune": [_i], "ltx_plan_save": [C.c_char_p], "ltx_plan_load": [C.c_char_p],
-    "ltx_pipeline_last_steps": [C.POINTER(C.c_int), C.POINTER(C.c_int)], "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_get_option": [C.c_char_p, C.c_char_p, C.c_int], "ltx_reset_options": [], "ltx_has_experiments": [],
+    "ltx_pipeline_last_steps": [C.POINTER(C.c_int), C.POINTER(C.c_int)], "ltx_attention_fallback_counts": [C.POINTER(C.c_ulonglong), C.c_int], "ltx_set_option": [C.c_char_p, C.c_char_p], "ltx_get_option": [C.c_char_p, C.c_char_p, C.c_int], "ltx_reset_options": [], "ltx_has_experiments": [],
     "ltx_build_video_coords": [_i, _i, _i, _i, _i, _i, _vp],
     "ltx_pipeline_params_default": [_vp],
     "ltx_pipeline_call": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -947,6 +947,13 @@ def reset_options():
 
 def has_experiments() -> bool:
     return bool(lib.ltx_has_experiments())
+
+
+def attention_fallback_counts(reset: bool = False):
+    """(head_dim-64 workgroups, head_dim-128 launches) that took the exact-max second pass since the last reset"""
+    out = (C.c_ulonglong * 2)()
+    _check(lib.ltx_attention_fallback_counts(out, int(reset)))
+    return int(out[0]), int(out[1])
 
 
 def get_option(key: str):

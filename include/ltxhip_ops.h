@@ -81,6 +81,10 @@ int ltx_op_rope_table(float* cos, float* sin, const float* coords, int B, int F,
 /* LtxAttention core (ltx_transformer.rs:699-741): o = softmax(scale q k^T + bias) v, q [B,Sq,heads*hd] etc. */
 int ltx_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int heads, int hd,
                      int ldq, int ldk, int ldv, int ldo, float scale, const float* key_bias, int dtype, ltx_stream stream);
+/* Diagnostic counters of the self-attention kernels' exact-max second pass (their fixed first-tile softmax max overflowed; the
+ * result is exact either way, the pass costs time): counts[0] = head_dim-64 workgroups that re-ran since the last reset,
+ * counts[1] = head_dim-128 launches whose gated exact pass ran.  Current device; blocks until the device copy is done. */
+int ltx_attention_fallback_counts(unsigned long long counts[2], int reset);
 /* Cross attention on UN-normalised queries (bf16, head_dim 64, Sk <= 128): softmax(r_i * scale * q_i . k_j + bias_j) v_j with
  * r_i = 1 / sqrt(sum_g q_rowsq[i*n + g] / D + eps), the RMS-norm scalar of query row i; the norm's weight is expected folded
  * into k by the caller (LtxAttention::forward with norm_q, ltx_transformer.rs:671-678, 719-740). */

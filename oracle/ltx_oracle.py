@@ -273,6 +273,9 @@ def rope_cos_sin(dim: int, batch: int, num_frames: int, height: int, width: int,
     return cos, sin
 
 
+ATTN_SCORE_BYTES = 8 << 30      # host budget for one pass of f32 attention scores (attention(): heads per pass)
+
+
 def attention(p: Dict[str, Tensor], prefix: str, heads: int, hidden: Tensor, enc: Optional[Tensor],
               mask_bias: Optional[Tensor], rope: Optional[Tuple[Tensor, Tensor]]) -> Tensor:
     """LtxAttention::forward manual (CPU / masked) path, ltx_transformer.rs:648-750."""
@@ -293,12 +296,19 @@ def attention(p: Dict[str, Tensor], prefix: str, heads: int, hidden: Tensor, enc
     kf = k.reshape(b, k_len, heads, hd).transpose(1, 2).contiguous().float()
     vf = v.reshape(b, k_len, heads, hd).transpose(1, 2).contiguous().float()
     scale = float(np.float32(1.0) / np.sqrt(np.float32(hd)))
-    att = qf @ kf.transpose(-1, -2)
-    att = att * scale
-    if mask_bias is not None:                       # [B,1,K] -> [B,1,1,K]  (:627-641)
-        att = att + mask_bias.float().unsqueeze(2)
-    att = torch.softmax(att, -1)
-    out = (att @ vf).to(dt)
+    # heads per pass: all of them unless the f32 score tensor would not fit the host (C5's S = 17556: 1.2 GB per head, 39 GB
+    # for 32); heads never interact and every head sees the same op sequence either way
+    hc = max(1, min(heads, int(ATTN_SCORE_BYTES // max(1, b * q_len * k_len * 4))))
+    outs = []
+    for h0 in range(0, heads, hc):
+        att = qf[:, h0:h0 + hc] @ kf[:, h0:h0 + hc].transpose(-1, -2)
+        att = att * scale
+        if mask_bias is not None:                   # [B,1,K] -> [B,1,1,K]  (:627-641)
+            att = att + mask_bias.float().unsqueeze(2)
+        att = torch.softmax(att, -1)
+        outs.append(att @ vf[:, h0:h0 + hc])
+        del att
+    out = (outs[0] if len(outs) == 1 else torch.cat(outs, 1)).to(dt)
     out = out.transpose(1, 2).contiguous().reshape(b, q_len, heads * hd)
     return linear(out, p[prefix + "to_out.0.weight"], p.get(prefix + "to_out.0.bias"))
 

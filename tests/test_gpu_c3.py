@@ -132,3 +132,52 @@ def test_c3_preset_at_c2_geometry_bf16_vs_f32_mode(c3):
     print(f"C3 preset at 512x768x97, 4 guided steps: bf16 vs f32 mode latent rel-L2 {e:.4f}, PSNR {p:.1f} dB")
     assert e <= 2e-2, e
     assert p >= 38.0, p
+
+
+def test_c3_at_its_own_geometry_vs_oracle_fixture(c3):
+    """BASELINE config C3 at 512x768x97 (S = 4992) against the CPU ORACLE (tests/golden/oracle_c3_full.safetensors, tools/gen_fixtures.py
+    c3full: ~15 minutes of host time): the 0.9.5 preset's guidance path - three forwards per step, CFG 3.0 + STG 1.0 through skip
+    block 19 + rescale 0.7 - for four steps whose timesteps are exact in bf16, + the untiled decode.  f32 mode rel-max <= 1e-3 on
+    latents and video; bf16 production kernels against the plain f32 oracle at C2's bars (latent rel-L2 <= 2e-2, PSNR >= 35 dB);
+    each with the guidance branches as one three-row forward (default) and as the reference's three calls."""
+    hip, g0, dw, vw = c3
+    g = load_file(os.path.join(os.path.dirname(GOLD), "oracle_c3_full.safetensors"))
+    assert torch.allclose(checksum(dw), g["dit_weights_checksum"], rtol=1e-9) and torch.allclose(checksum(vw), g["vae_weights_checksum"], rtol=1e-9)
+    F, H, W = 13, 16, 24
+    lat = hip.pack_latents(hip.pcg32_randn(42, (1, 128, F, H, W)))
+    _, pe, pm, _, mean, std = inputs()
+    ne = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(43)); nm = torch.zeros(1, 128); nm[:, :8] = 1
+    pre = hip.get_config_by_version("0.9.5")
+    call = pre.pipeline_call(512, 768, 97, postprocess=True)
+    call.num_inference_steps, call.sigmas = 4, [1.0, 0.8965, 0.6405, 0.1005]
+    assert (call.guidance_scale, call.stg_scale, list(call.skip_block_list)) == (3.0, 1.0, [19]) and call.decode_timestep == 0.0
+    vwd = {"decoder." + k: v.to(DEV) for k, v in vw.items()}
+    vwd["latents_mean"] = mean.to(DEV); vwd["latents_std"] = std.to(DEV)
+    report = {}
+    for dt in (torch.float32, torch.bfloat16):
+        dit = hip.LtxVideoTransformer3DModel(pre.transformer, {k: v.to(DEV) for k, v in dw.items()}, dt)
+        vae = hip.AutoencoderKLLtxVideo(pre.vae, vwd, dt)
+        pipe = hip.LtxPipeline(dit, vae)
+        for gb in ("1", "0"):
+            with hip.options(guidance_batch=gb):
+                lat_f, video = pipe.call(call, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV))
+            torch.cuda.synchronize()
+            l = lat_f.float().cpu(); vs = video[:, :, ::8, ::16, ::16].float().cpu()
+            assert torch.isfinite(l).all() and torch.isfinite(vs).all()
+            if dt == torch.float32:
+                e_lat, e_vid = rel_max(l[:, ::8], g["latents_sub"]), rel_max(vs, g["video_slice"])
+                report[("f32", gb)] = (e_lat, e_vid)
+                assert e_lat <= 1e-3, (gb, e_lat)
+                assert e_vid <= 1e-3, (gb, e_vid)
+                assert abs(float(l.double().abs().sum()) / float(g["latents_moments"][1]) - 1.0) <= 1e-4
+                assert abs(float(video.double().abs().sum()) / float(g["video_moments"][2]) - 1.0) <= 1e-4
+            else:
+                e, p = rel_l2(l[:, ::8], g["latents_sub"]), psnr(vs, g["video_slice"])
+                report[("bf16", gb)] = (e, p)
+                assert e <= 2e-2, (gb, e)
+                assert p >= 35.0, (gb, p)
+            del lat_f, video
+        del pipe, dit, vae
+        torch.cuda.empty_cache()
+    print("C3 at 512x768x97 vs oracle fixture:", {k: tuple(round(float(x), 6) for x in v) for k, v in report.items()})
+    assert float(g["video_moments"][1]) > 10.0 and rel_l2(g["latents_sub"], g["latents_step1_sub"]) > 1e-2      # a live, non-degenerate case

@@ -460,6 +460,86 @@ def c5vae_case():
                         "video_slice": "[:, :, ::2, ::16, ::16]; video_right: [:, :, ::2, ::8, 1184:1216:2]; video_bottom: [:, :, ::2, 672:704:2, ::8] of the [1,3,9,704,1216] video (before postprocess)"})
 
 
+C3_FULL_SIGMAS = [1.0, 0.8965, 0.6405, 0.1005]     # integer timesteps 1000, 896, 640, 100: exact in bf16 (ltx_transformer.rs:1051)
+
+
+def c3full_case():
+    """BASELINE config C3 at ITS OWN geometry, 512x768x97 (S = 4992): the 0.9.5 preset's guidance path (configs.rs:163-184: CFG 3.0
+    + STG 1.0 through skip block 19 + rescale 0.7 = three forwards per step, t2v_pipeline.rs:878-964) for four steps of a
+    custom schedule whose timesteps are exact in bf16, + the untiled decode; full 2B DiT + VAE decoder (weights of c1_case),
+    f32.  12 forwards at S = 4992 + 48 TFLOP of decode: about 15 minutes of host time.
+    Committed: every 8th token of the final latents and of the latents after step 1, moments, a strided slice + moments of the video."""
+    import time
+    dcfg, vcfg = O.DitConfig(), O.VaeConfig()
+    dw = O.synth_weights(O.dit_weight_shapes(dcfg), seed=31)
+    vw = O.synth_weights(O.vae_decoder_weight_shapes(vcfg), seed=32)
+    F, H, W = 13, 16, 24
+    lat = O.pack_latents(O.Pcg32(42, 1442695040888963407).randn((1, 128, F, H, W)))
+    _, pe, pm, _, mean, std = c1_inputs()
+    ne = torch.randn(1, 128, 4096, generator=torch.Generator().manual_seed(43))
+    nm = torch.zeros(1, 128); nm[:, :8] = 1
+    args = O.PipelineArgs(height=512, width=768, num_frames=97, num_inference_steps=4, sigmas=C3_FULL_SIGMAS,
+                          guidance_scale=3.0, guidance_rescale=0.7, stg_scale=1.0, skip_block_list=[19], decode_timestep=0.0, decode_noise_scale=0.0)
+    traj = []
+    t0 = time.time()
+    video = O.pipeline_call(dw, dcfg, vw, vcfg, mean, std, args, lat, pe, pm, ne, nm, None, torch.float32, trajectory=traj)
+    dt = time.time() - t0
+    l = traj[-1]
+    out = {"dit_weights_checksum": weights_checksum(dw), "vae_weights_checksum": weights_checksum(vw),
+           "latents_sub": l[:, ::8], "latents_step1_sub": traj[0][:, ::8],
+           "latents_moments": torch.tensor([float(l.double().sum()), float(l.double().abs().sum()), float(l.double().pow(2).sum())], dtype=torch.float64),
+           "video_slice": video[:, :, ::8, ::16, ::16],
+           "video_moments": torch.tensor([float(video.double().mean()), float(video.double().std()), float(video.double().abs().sum())], dtype=torch.float64),
+           "oracle_seconds": torch.tensor([dt], dtype=torch.float64)}
+    print(f"C3 at 512x768x97 oracle: {dt:.1f} s, {len(traj)} guided steps, video mean {float(video.mean()):.2f} std {float(video.std()):.2f}", flush=True)
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c3_full.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py pipeline_call, 0.9.5 preset's guidance (CFG 3.0 + STG 1.0 skip block 19, rescale 0.7), 4 steps, at 512x768x97 (S = 4992), synthetic weights seeds 31/32",
+                        "args": repr(args), "latents_sub": "[:, ::8] of the [1,4992,128] latents", "video_slice": "[:, :, ::8, ::16, ::16] of the [1,3,97,512,768] post-processed video"})
+
+
+C5_DIT_CFG = dict(in_channels=128, out_channels=128, num_attention_heads=32, attention_head_dim=128, cross_attention_dim=4096,
+                  num_layers=2, caption_channels=4096)
+
+
+def c5dit_inputs():
+    """Inputs of the two-layer 13B-width forward on C5's full grid; shared by the generator and tests/test_gpu_c5.py."""
+    F, H, W, K = 21, 22, 38, 128
+    g = torch.Generator().manual_seed(516)
+    hidden = torch.randn(1, F * H * W, 128, generator=g)
+    enc = torch.randn(1, K, 4096, generator=g)
+    mask = torch.zeros(1, K); mask[:, :45] = 1
+    t = torch.tensor([896.0])                        # exact in bf16
+    return F, H, W, K, hidden, enc, mask, t
+
+
+def c5dit_case():
+    """BASELINE config C5's DiT at its own launch sizes: a TWO-layer model with the 13B block shape (D = 4096, 32 heads x 128,
+    caption / cross-attention dim 4096; configs.rs:243-282) on the FULL 21 x 22 x 38 grid, S = 17556 - the head_dim-128 attention and
+    the K = 4096 / 16384 GEMM plans at the sizes the 48-layer model launches them with.  The oracle's attention runs the heads in
+    passes (1.2 GB of f32 scores per head).  Two runs: plain f32, and f32 arithmetic on bf16-rounded weights / inputs (the
+    reference for the bf16 production kernels).  Committed: every 16th token of each output + moments."""
+    import time
+    cfg = O.DitConfig(**C5_DIT_CFG)
+    w = O.synth_weights(O.dit_weight_shapes(cfg), seed=515)
+    F, H, W, K, hidden, enc, mask, t = c5dit_inputs()
+    coords = O.build_video_coords(1, F, H, W)
+    out = {"dit_weights_checksum": weights_checksum(w)}
+    for tag, rnd in (("f32", False), ("bf16in", True)):
+        ww = {k: v.bfloat16().float() for k, v in w.items()} if rnd else w
+        hh, ee = (hidden.bfloat16().float(), enc.bfloat16().float()) if rnd else (hidden, enc)
+        t0 = time.time()
+        y = O.dit_forward(ww, cfg, hh, ee, t, mask, F, H, W, None, coords)
+        dt = time.time() - t0
+        out[f"out_sub_{tag}"] = y[:, ::16]
+        out[f"out_moments_{tag}"] = torch.tensor([float(y.double().sum()), float(y.double().abs().sum()), float(y.double().pow(2).sum())], dtype=torch.float64)
+        out[f"oracle_seconds_{tag}"] = torch.tensor([dt], dtype=torch.float64)
+        print(f"C5 two-layer DiT oracle {tag}: {dt:.1f} s, out std {float(y.std()):.4f}", flush=True)
+        del y, ww
+    save_file({k: c(v) for k, v in out.items()}, os.path.join(GOLD, "oracle_c5dit.safetensors"),
+              metadata={"source": "oracle/ltx_oracle.py dit_forward, 2 layers at 13B width (D 4096, 32 x 128 heads) on the 21x22x38 grid (S = 17556), synthetic weights seed 515",
+                        "out_sub": "[:, ::16] of the [1,17556,128] output; bf16in = the same arithmetic on bf16-rounded weights / hidden / enc"})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -477,6 +557,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c5vae":
         c5vae_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c3full":
+        c3full_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5dit":
+        c5dit_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":
         ref_scripts(); ref_scripts_imported(); ref_rope_tables()
@@ -496,6 +582,8 @@ if __name__ == "__main__":
     c3_case()
     c4_case()
     c5vae_case()
+    c5dit_case()
     c2_case()           # the headline config in full: ~20 minutes of host time (two 10-minute oracle runs)
+    c3full_case()       # ~15 minutes
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("fixtures written:", sorted(os.listdir(GOLD)), f"{tot / 1e6:.1f} MB")
