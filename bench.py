@@ -117,7 +117,7 @@ def host_machine():
     return {"hostname": socket.gethostname(), "cpu_model": model, "logical_cpus": os.cpu_count()}
 
 
-def cpu_baseline(cfg, fl_job):
+def cpu_baseline(cfg, fl_job, calibrate=True):
     """The oracle (a torch-CPU port of the reference's CPU path - oneDNN / MKL kernels under an op-for-op restatement: f32,
     un-fused, materialised attention scores, conv3d as per-frame sums of conv2d; `kind: "port"` + `port_of`, NOT the reference binary
     and not the plain C++ backend SURVEY 8d sketched) timed on this box's host cores, two ways:

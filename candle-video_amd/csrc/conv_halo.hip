@@ -63,7 +63,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char halo_smem[];
 // two waves per SIMD both wait at the same barrier, then both wait for their first fragments); the weight tiles run three
 // deep (tile of step s + 2 issued in step s, counted vmcnt at the barrier of step s covers tile s + 1).  LDS-DMA counts per
 // step are made static: out-of-range dummy pieces (zeros into padding / free buffers) where the plain form issues nothing.
-// (round 5, built, bit-identical, measured and removed - tools/ab_round5/conv_halo_persistent_tile_loop.patch: a PERSISTENT tile loop, one
+// (round 5, built, bit-identical, measured and removed - tools/archive/ab_round5/conv_halo_persistent_tile_loop.patch: a PERSISTENT tile loop, one
 // block per CU, the next tile's halo image and first two weight tiles issued as the pieces the last group otherwise issues out of
 // range.  It hides the tile prologue as designed (tile top -> loop 2.8 -> 1.4 us) but its K loop runs 1205-1233 cycles per step against
 // 1156-1170 (same instruction count; 253 instead of 234 VGPRs): 128-channel conv 1743-1770 vs 1590-1609 us, C2 conv class 34.9-35.0

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B an environment toggle of libltxhip on the C2 GEMM/conv/attention shapes, interleaved rounds in ONE process.
-usage: ab.py VAR=a,b [gemm|conv|attn ...]"""
+"""A/B a run-time OPTION of libltxhip (include/ltxhip.h, "run-time options"; value "-" = the option's default) on the C2 GEMM / conv /
+attention shapes, interleaved rounds in ONE process.
+usage: ab.py option=a,b [gemm|conv|attn|square ...]      e.g.  ab.py gemm_off=-,asm16 gemm"""
 import json, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "candle-video_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -37,10 +38,10 @@ res = {c[0]: {v: [] for v in vals} for c in cases}
 for rnd in range(3):
     for name, fl, fn in cases:
         for v in vals:
-            os.environ[var] = v
+            ltxhip.set_option(var, None if v == "-" else v)
             ms = timeit(fn, iters=10, warm=2)
             res[name][v].append(fl / ms / 1e9)
-os.environ.pop(var, None)
+ltxhip.set_option(var, None)
 for name in res:
     print(json.dumps({"case": name, var: {v: round(sorted(res[name][v])[1], 1) for v in vals}}))
 plans = {}

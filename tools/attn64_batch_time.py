@@ -8,9 +8,8 @@ for B in (1, 2, 3):
     g = torch.Generator(device="cuda").manual_seed(B)
     q = (torch.randn(B, S, H * D, device="cuda", generator=g) * 0.18).bfloat16(); k = torch.randn(B, S, H * D, device="cuda", generator=g).bfloat16(); v = torch.randn(B, S, H * D, device="cuda", generator=g).bfloat16()
     for tag, env in (("big16", "16"), ("new", None), ("big16b", "16"), ("newb", None)):
-        if env: os.environ["LTX_ATTN_Q64_BIG"] = env
-        else: os.environ.pop("LTX_ATTN_Q64_BIG", None)
+        ltxhip.set_option("attn_q64_big", env)                # None: the option's default (the greedy split)
         ms = min(timeit(lambda: ltxhip.ops.attention_prescaled(q, k, v, H), iters=10, warm=3) for _ in range(3))
         res[f"B{B}_{tag}"] = round(ms * 1000, 1)
-    os.environ.pop("LTX_ATTN_Q64_BIG", None)
+    ltxhip.set_option("attn_q64_big", None)
 print(json.dumps(res))

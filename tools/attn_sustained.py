@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Self-attention A/B under sustained load, on the DiT's own layout (q|k|v column slices of the fused [S, 6144] buffer).
-usage: attn_sustained.py VAR=a,b"""
+usage: attn_sustained.py option=a,b      (a run-time option of include/ltxhip.h; "-" = its default), e.g. attn_q64_big=-,16"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "candle-video_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -18,7 +18,7 @@ res = {(lay, x): [] for lay in ("fused", "separate") for x in vals}
 for rnd in range(5):
     for lay, fn in (("fused", fn_f), ("separate", fn_s)):
         for x in vals:
-            os.environ[var] = x
+            ltxhip.set_option(var, None if x == "-" else x)
             res[(lay, x)].append(timeit(fn, iters=60, warm=3))
 for (lay, x), ms in res.items():
     m = sorted(ms)[len(ms) // 2]

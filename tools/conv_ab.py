@@ -14,9 +14,8 @@ for name, C, T, H, W in [("mid1024", 1024, 13, 16, 24), ("up0_512", 512, 25, 32,
     res[name] = {"ms": round(ms, 3), "TF": round(54 * C * C * T * H * W / ms / 1e9), "plan": ltxhip.ops.gemm_plan(T * H * W, C, C, 1, 27, T, H, W)}
     for force in os.environ.get("CONV_AB_FORCE", "").split(","):          # e.g. CONV_AB_FORCE=128,256: the halo kernel at that tile width
         if not force: continue
-        os.environ["LTX_CONV_HALO"] = force
-        ms = min(timeit(lambda: ltxhip.ops.conv3d(x, w, b), iters=4, warm=2) for _ in range(2))
-        del os.environ["LTX_CONV_HALO"]
+        with ltxhip.options(gemm_plan="halo:" + force):
+            ms = min(timeit(lambda: ltxhip.ops.conv3d(x, w, b), iters=4, warm=2) for _ in range(2))
         res[name]["halo" + force] = round(54 * C * C * T * H * W / ms / 1e9)
     del x
 print(json.dumps(res))

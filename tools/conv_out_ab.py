@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """conv_out (128 -> 48 + unpatchify) at C2's size [97, 128, 192]: the 64-wide halo-staged tile against the per-tap 192 x 64 tile
-(LTX_CONV_OUT_HALO=0), interleaved rounds in one process; the op re-packs the weights per call (both arms pay it)."""
+(gemm_off=halo_out), interleaved rounds in one process; the op re-packs the weights per call (both arms pay it)."""
 import json, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "candle-video_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -12,8 +12,7 @@ t = {"per_tap": [], "halo64": []}
 outs = {}
 for rnd in range(4):
     for arm in (("per_tap", "halo64") if rnd % 2 == 0 else ("halo64", "per_tap")):
-        if arm == "per_tap": os.environ["LTX_CONV_OUT_HALO"] = "0"
-        else: os.environ.pop("LTX_CONV_OUT_HALO", None)
+        ltxhip.set_option("gemm_off", "halo_out" if arm == "per_tap" else None)
         t[arm].append(timeit(lambda: ltxhip.ops.conv_out_unpatchify(x, w, b, postprocess=True), iters=5, warm=2))
         outs[arm] = ltxhip.ops.conv_out_unpatchify(x, w, b, postprocess=True)
 fl = 54 * C * 48 * T * H * W

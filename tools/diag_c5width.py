@@ -55,12 +55,12 @@ w = O.synth_weights(O.dit_weight_shapes(O.DitConfig(**cfgd)), seed=513)
 gg = torch.Generator().manual_seed(514)
 hidden = torch.randn(1, S, 128, generator=gg); enc = torch.randn(1, K, 4096, generator=gg)
 mask = torch.zeros(1, K); mask[:, :45] = 1
-for variant, env in (("default", {}), ("no asm16", {"LTX_GEMM_ASM16": "0"}), ("q128 off", {"LTX_ATTN_Q128": "0"}), ("no tune", {"LTX_GEMM_TUNE": "0"}), ("gemm_big off", {"LTX_GEMM_BIG": "0"})):
-    for k2, v2 in env.items(): os.environ[k2] = v2
+for variant, env in (("default", {}), ("no asm16", {"gemm_off": "asm16"}), ("q128 off", {"attn_off": "q128"}), ("no tune", {"gemm_tune": "0"}), ("gemm_big off", {"gemm_off": "big"})):
+    for k2, v2 in env.items(): ltxhip.set_option(k2, v2)
     outs = {}
     for dt in (torch.float32, torch.bfloat16):
         m = ltxhip.LtxVideoTransformer3DModel(ltxhip.LtxVideoTransformer3DModelConfig(**cfgd), {kk: vv.to(dev) for kk, vv in w.items()}, dt)
         outs[dt] = m.forward(hidden.to(dev), enc.to(dev), torch.tensor([896.0]), mask.to(dev), 3, 22, 31, None, coords.to(dev)).float().cpu()
         del m
-    for k2 in env: os.environ.pop(k2)
+    for k2 in env: ltxhip.set_option(k2, None)
     print("model", variant, "bf16 vs f32 mode rel", round(rel(outs[torch.bfloat16], outs[torch.float32]), 5), flush=True)

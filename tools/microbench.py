@@ -56,22 +56,6 @@ def conv_cases():
         print(json.dumps({"op": "conv3d", "case": name, "ms": round(ms, 4), "TFLOPs": round(54 * C * C * T * H * W / ms / 1e9, 1)}), flush=True)
 
 
-def xcd_sweep():
-    S = 4992
-    for mode in ("0", "1"):
-        os.environ["LTX_XCD_REMAP"] = mode
-        for name, M, N, K in [("qkv", S, 6144, 2048), ("to_out", S, 2048, 2048), ("ff1", S, 8192, 2048), ("ff2", S, 2048, 8192)]:
-            x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
-            ms = timeit(lambda: ltxhip.ops.linear(x, w, b))
-            print(json.dumps({"op": "gemm_xcd", "remap": mode, "case": name, "TFLOPs": round(2 * M * N * K / ms / 1e9, 1)}), flush=True)
-        for name, C, T, H, W in [("up0_512", 512, 25, 32, 48), ("up2_128", 128, 97, 128, 192)]:
-            x = torch.randn(1, T, H, W, C, device=dev).bfloat16()
-            w = (torch.randn(C, C, 3, 3, 3, device=dev) / math.sqrt(27 * C)).bfloat16(); b = torch.randn(C, device=dev).bfloat16()
-            ms = timeit(lambda: ltxhip.ops.conv3d(x, w, b), iters=5, warm=1)
-            print(json.dumps({"op": "conv_xcd", "remap": mode, "case": name, "TFLOPs": round(54 * C * C * T * H * W / ms / 1e9, 1)}), flush=True)
-    os.environ.pop("LTX_XCD_REMAP", None)
-
-
 def norm_cases():
     for name, rows, D in [("dit_rms", 4992, 2048), ("vae_128", 97 * 128 * 192, 128), ("vae_256", 49 * 64 * 96, 256), ("vae_1024", 4992, 1024)]:
         x = torch.randn(rows, D, device=dev).bfloat16(); sc = torch.randn(1, D, device=dev); sh = torch.randn(1, D, device=dev)
@@ -90,17 +74,13 @@ def tile_sweep():
         x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
         res = {}
         for tile in ["256x256", "192x256", "128x256", "256x128", "192x128", "160x128", "128x128"]:
-            if tile == "old":
-                os.environ["LTX_GEMM_BIG"] = "0"
-            else:
-                os.environ["LTX_GEMM_BIG"] = "1"; os.environ["LTX_GEMM_TILE"] = tile
-            ms = timeit(lambda: ltxhip.ops.linear(x, w, b))
+            with ltxhip.options(gemm_plan=tile):             # a gemm_big tile forced wherever the call is eligible for it
+                ms = timeit(lambda: ltxhip.ops.linear(x, w, b))
             res[tile] = round(2 * M * N * K / ms / 1e9, 1)
-        os.environ.pop("LTX_GEMM_TILE", None); os.environ["LTX_GEMM_BIG"] = "1"
         print(json.dumps({"op": "gemm_tile_sweep", "case": name, "TFLOPs": res}), flush=True)
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "conv", "norm"]
     for w in which:
-        {"gemm": gemm_cases, "attn": attn_cases, "conv": conv_cases, "norm": norm_cases, "tiles": tile_sweep, "xcd": xcd_sweep}[w]()
+        {"gemm": gemm_cases, "attn": attn_cases, "conv": conv_cases, "norm": norm_cases, "tiles": tile_sweep}[w]()

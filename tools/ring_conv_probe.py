@@ -1,4 +1,4 @@
-"""Small-plane 3x3x3 convs: every plan a shape may run, timed in one process (tools/ab_round5/r5l_run.sh).
+"""Small-plane 3x3x3 convs: every plan a shape may run, timed in one process (tools/archive/ab_round5/r5l_run.sh).
 usage: python3 tools/ring_conv_probe.py  -> one JSON line per (shape, plan)"""
 import json, math, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "candle-video_amd"))

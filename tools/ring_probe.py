@@ -28,14 +28,14 @@ for M in [int(v) for v in os.environ.get("RING_MS", "384,128").split(",")]:
         def fn():
             w = ws[i[0] % 8]; i[0] += 1
             return ltxhip.ops.linear(x, w, b, epi=epi, resid=resid if epi in (2, 3) else None, gate=gate if epi == 2 else None, rows_per_batch=M)
-        os.environ["LTX_GEMM_RING"] = "0"
+        ltxhip.set_option("gemm_off", "ring")
         i[0] = 0; ref = fn().clone(); us, cnt = run(fn)
         print(json.dumps({"M": M, "case": name, "N": N, "K": K, "arm": "gemm_big (measured plan, ring family off)", "plan": ltxhip.ops.gemm_plan(M, N, K), "us": round(us, 2),
                           "TF": round(2 * M * N * K / us / 1e6), "weight_GBps": round(N * K * 2 / us / 1e3)}), flush=True)
-        del os.environ["LTX_GEMM_RING"]
+        ltxhip.set_option("gemm_off", None)
         for t in TILES:
-            os.environ["LTX_GEMM_RING_TILE"] = t
+            ltxhip.set_option("gemm_plan", "ring:" + t)
             i[0] = 0; got = fn().clone(); us, cnt = run(fn)
-            del os.environ["LTX_GEMM_RING_TILE"]
+            ltxhip.set_option("gemm_plan", None)
             print(json.dumps({"M": M, "case": name, "arm": t, "us": round(us, 2), "TF": round(2 * M * N * K / us / 1e6), "weight_GBps": round(N * K * 2 / us / 1e3),
                               "same_bits": bool(torch.equal(got.view(torch.int16), ref.view(torch.int16)))}), flush=True)
