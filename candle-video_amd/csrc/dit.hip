@@ -31,6 +31,7 @@ struct DitCtx {                      // cached text context (see ltx_dit_forward
 struct DitTimeEntry {
     float t[8] = {0}; int B = 0; hipStream_t stream = nullptr; bool valid = false; uint64_t used = 0;
     DevBuf ada, adaf;                // [L][B][6D] f32, [2][B][D] f32
+    DevBuf cfold; bool cfold_valid = false;      // norm fold: per layer [B][3D] (shift_msa . W_qkv^T + b_qkv) then [B][4D] (shift_mlp . W_ff1^T + b_ff1), f32
 };
 constexpr int kDitTimeEntries = 64;
 
@@ -258,6 +259,26 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     }
     if (presum) LTX_TRY(m->hsq.ensure(M * (D / 128) * sizeof(float)));
     bool hsq_valid = false;                                 // m->hsq holds the partials of the CURRENT contents of h
+    // Norm fold (round 6; GemmArgs::C2 / ::rs_sq, kernels.h): with the partials in hand the norm pass between the layer that writes h
+    // and the layer that reads the normalised rows is gone altogether - norm(h) * (1 + sc) + sh times W^T is
+    // r_m * ((h (.) (1 + sc)) W^T) + (sh W^T + b): out2 / ff2 also store h (.) (1 + sc_next) into m->n, qkv / ff1 read it and finish
+    // with the row's 1 / rms and the per-timestep vector sh W^T + b (cached with the timestep's modulation).  One rounding less than
+    // the pass (bf16 of h (1 + sc) instead of bf16 of the modulated, normalised row); norm_fold=0: the pass (A/B arm).
+    bool nfold = presum && ltx_opt().norm_fold != 0;
+    if (nfold) {
+        GemmArgs gp; gp.A = m->attn.p; gp.W = m->blocks[0].o2.w; gp.C = m->h.p; gp.bias = m->blocks[0].o2.b; gp.resid = m->h.p;
+        gp.M = (int)M; gp.N = D; gp.K = D; gp.lda = D; gp.ldc = D; gp.ldr = D; gp.rows_per_batch = S;
+        gp.rowsq = m->hsq.as<float>(); gp.C2 = m->n.p; gp.scale2 = reinterpret_cast<const float*>(m->hsq.p); gp.scale2_stride = 6 * D;      // (aligned non-null pointers: a fit test)
+        GemmArgs gf = gp; gf.A = m->ff.p; gf.W = m->blocks[0].ff2.w; gf.bias = m->blocks[0].ff2.b; gf.K = 4 * D; gf.lda = 4 * D;
+        gf.gate = reinterpret_cast<const float*>(m->hsq.p); gf.gate_stride = 6 * D;
+        GemmArgs gq; gq.A = m->n.p; gq.W = m->blocks[0].qkv1.w; gq.C = m->qkv.p; gq.M = (int)M; gq.N = 3 * D; gq.K = D; gq.lda = D; gq.ldc = D;
+        gq.c_seg_shift = __builtin_ctz((unsigned)D); gq.c_seg_stride = M * D; gq.rows_per_batch = S;
+        gq.rs_sq = m->hsq.as<float>(); gq.rs_n = D / 128; gq.rs_D = D; gq.rs_eps = c.norm_eps; gq.cvec = m->hsq.as<float>(); gq.cvec_stride = 3 * D;
+        GemmArgs g1 = gq; g1.W = m->blocks[0].ff1.w; g1.C = m->ff.p; g1.N = 4 * D; g1.ldc = 4 * D; g1.c_seg_shift = 0; g1.c_seg_stride = 0; g1.cvec_stride = 4 * D;
+        nfold = ltx_opt().dense_qkv && m->blocks[0].qkv1.out == 3 * D && m->blocks[0].ff1.out == 4 * D &&
+                ltx_gemm_fold_ok(gp, EPI_RESID) && ltx_gemm_fold_ok(gf, EPI_GATE_RESID) && ltx_gemm_fold_ok(gq, EPI_BIAS) && ltx_gemm_fold_ok(g1, EPI_GELU);
+    }
+    bool hs_valid = false;                                  // m->n holds h (.) (1 + scale) of the norm that comes next (written by the layer that wrote h)
     bool hsq_saved = false;                                 // m->orig_hsq holds the partials of m->orig (a layer some rows skip)
     // Few tokens (C1's 384: every linear layer is a latency-bound weight stream): ff2, the deepest one (K = 4 D), runs its K ranges as
     // separate blocks (the shape rule: four ranges from K = 8192 up) and leaves their f32 sums in m->parts; the row norm that follows
@@ -290,7 +311,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (!te) {
         if ((int)m->tcache.size() < kDitTimeEntries) { m->tcache.emplace_back(); te = &m->tcache.back(); }
         else { te = &m->tcache.front(); for (auto& e : m->tcache) if (e.used < te->used) te = &e; }
-        te->valid = false;
+        te->valid = false; te->cfold_valid = false;
         LTX_TRY(te->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(te->adaf.ensure((size_t)2 * B * D * sizeof(float)));
         LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
         LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
@@ -305,6 +326,16 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     te->used = ++m->tclock;
     const float* ada_all = te->ada.as<float>();
     const float* adaf = te->adaf.as<float>();
+    if (nfold && !te->cfold_valid) {                        // once per distinct timestep vector: streams the q|k|v and ff1 weights of every layer once
+        LTX_TRY(te->cfold.ensure((size_t)L * B * 7 * D * sizeof(float)));
+        for (int l = 0; l < L; ++l) {
+            const float* ada = ada_all + (size_t)l * B * 6 * D;
+            float* cq = te->cfold.as<float>() + (size_t)l * B * 7 * D;
+            LTX_TRY(ltx_launch_shift_gemv(m->blocks[l].qkv1.w, m->blocks[l].qkv1.b, ada, 6 * D, B, 3 * D, D, cq, 3 * D, s));
+            LTX_TRY(ltx_launch_shift_gemv(m->blocks[l].ff1.w, m->blocks[l].ff1.b, ada + 3 * D, 6 * D, B, 4 * D, D, cq + (size_t)B * 3 * D, 4 * D, s));
+        }
+        te->cfold_valid = true;
+    }
 
     // Text context: caption projection (:186-190), mask bias (:1059-1070) and, for every layer, the cross-attention
     // K/V projections + k-RMSNorm (:667-672).  None of it depends on the timestep or the latents, so inside a
@@ -371,6 +402,16 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     }
 
     const float attn_scale = 1.0f / std::sqrt((float)hd);
+    auto next_block = [&](int l) {                          // the next block that runs (not in the skip list, not skipped by every row), -1: none
+        for (int n = l + 1; n < L; ++n) {
+            bool skip = false;
+            for (int sb : m->skip_blocks) if (sb == n) skip = true;
+            if (skip) continue;
+            if (skip_layer_mask) { bool all = true; for (int bb = 0; bb < B; ++bb) all &= skip_layer_mask[(size_t)n * B + bb] == 1.f; if (all) continue; }
+            return n;
+        }
+        return -1;
+    };
     for (int l = 0; l < L; ++l) {
         bool skip = false;
         for (int sb : m->skip_blocks) if (sb == l) skip = true;
@@ -395,8 +436,16 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
+        const bool fold1 = nfold && hs_valid && hsq_valid;      // the layer that wrote h left h (.) (1 + scale_msa) in m->n: no pass
+        const float* cfold_l = nfold ? te->cfold.as<float>() + (size_t)l * B * 7 * D : nullptr;
+        if (!fold1) {
         take_pending(rn);
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
+        } else if (ltx_opt().norm_fold >= 2) {              // diagnostic arms: 2 = the fold AND the pass (into a buffer nobody reads) - what the pause between two GEMMs is worth;
+            RowNormArgs dn = rn; dn.y = ltx_opt().norm_fold == 3 ? m->n.p : m->qkv.p;     // 3 (WRONG RESULTS) = the pass writes the rows the folded layer reads (the producers' second output goes elsewhere): who wrote A
+            LTX_TRY(ltx_launch_rownorm(dn, dt, s));
+        }
+        hs_valid = false;
         rn.parts = nullptr; rn.nparts = 0; rn.x_out = nullptr; rn.d_bias = nullptr; rn.d_gate = nullptr;
         // self attention
         // q, k, v leave the fused projection as three DENSE [M, D] matrices (segmented GEMM output) when D is a power
@@ -409,6 +458,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             g.A = m->n.p; g.W = b.qkv1.w; g.C = m->qkv.p; g.bias = b.qkv1.b;
             g.M = (int)M; g.N = b.qkv1.out; g.K = b.qkv1.in; g.lda = D; g.ldc = ldqkv;
             if (dense_qkv) { g.c_seg_shift = __builtin_ctz((unsigned)D); g.c_seg_stride = seg; }
+            if (fold1) { g.bias = nullptr; g.rows_per_batch = S; g.rs_sq = m->hsq.as<float>(); g.rs_n = D / 128; g.rs_D = D; g.rs_eps = c.norm_eps; g.cvec = cfold_l; g.cvec_stride = 3 * D; }
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
         }
         QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = ldqkv; qa.seg_stride = seg; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
@@ -442,19 +492,40 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
         }
         LTX_TRY(ltx_launch_attention(ax, dt, s));
+        if (nfold) {                                           // + h (.) (1 + scale_mlp) into m->n for ff1
+            GemmArgs g; g.A = m->attn.p; g.W = b.o2.w; g.C = m->h.p; g.bias = b.o2.b; g.resid = m->h.p; g.M = (int)M; g.N = b.o2.out; g.K = b.o2.in;
+            g.lda = D; g.ldc = D; g.ldr = D; g.rows_per_batch = S; g.rowsq = m->hsq.as<float>();
+            g.C2 = ltx_opt().norm_fold == 3 ? m->ff.p : m->n.p; g.scale2 = ada + 4 * D; g.scale2_stride = 6 * D;
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_RESID, s));
+            hs_valid = true;
+        } else
         LTX_TRY(ltx_linear(b.o2, m->attn.p, D, m->h.p, D, (int)M, dt, EPI_RESID, s, m->h.p, D, nullptr, 0, 1, presum ? m->hsq.as<float>() : nullptr));
         hsq_valid = presum;
         // MLP (shift_mlp = row 3, scale_mlp = row 4, gate_mlp = row 5)
         rn.shift = ada + 3 * D; rn.scale = ada + 4 * D;
         rn.presum = nullptr; rn.presum_n = 0;
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
+        if (nfold && hs_valid && hsq_valid) {
+            GemmArgs g; g.A = m->n.p; g.W = b.ff1.w; g.C = m->ff.p; g.M = (int)M; g.N = b.ff1.out; g.K = b.ff1.in; g.lda = D; g.ldc = 4 * D; g.rows_per_batch = S;
+            g.rs_sq = m->hsq.as<float>(); g.rs_n = D / 128; g.rs_D = D; g.rs_eps = c.norm_eps; g.cvec = cfold_l + (size_t)B * 3 * D; g.cvec_stride = 4 * D;
+            if (ltx_opt().norm_fold >= 2) { RowNormArgs dn = rn; dn.y = ltx_opt().norm_fold == 3 ? m->n.p : m->ff.p; LTX_TRY(ltx_launch_rownorm(dn, dt, s)); }
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_GELU, s));
+        } else {
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
         LTX_TRY(ltx_linear(b.ff1, m->n.p, D, m->ff.p, 4 * D, (int)M, dt, EPI_GELU, s));
+        }
+        hs_valid = false;
         if (defer_ff2) {
             GemmArgs g; g.A = m->ff.p; g.W = b.ff2.w; g.C = m->h.p; g.M = (int)M; g.N = b.ff2.out; g.K = b.ff2.in; g.lda = 4 * D; g.ldc = D;
             g.defer_parts = m->parts.as<float>();
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
             pending = true; pend_gate = ada + 5 * D; pend_bias = b.ff2.b;
+        } else if (int ln = nfold ? next_block(l) : -1; ln >= 0) {      // + h (.) (1 + scale_msa of the next block that runs) into m->n for its q|k|v projection
+            GemmArgs g; g.A = m->ff.p; g.W = b.ff2.w; g.C = m->h.p; g.bias = b.ff2.b; g.resid = m->h.p; g.M = (int)M; g.N = b.ff2.out; g.K = b.ff2.in;
+            g.lda = 4 * D; g.ldc = D; g.ldr = D; g.gate = ada + 5 * D; g.gate_stride = 6 * D; g.rows_per_batch = S; g.rowsq = m->hsq.as<float>();
+            g.C2 = ltx_opt().norm_fold == 3 ? m->qkv.p : m->n.p; g.scale2 = ada_all + (size_t)ln * B * 6 * D + D; g.scale2_stride = 6 * D;
+            LTX_TRY(ltx_launch_gemm(g, dt, EPI_GATE_RESID, s));
+            hs_valid = true;
         } else
         LTX_TRY(ltx_linear(b.ff2, m->ff.p, 4 * D, m->h.p, D, (int)M, dt, EPI_GATE_RESID, s, m->h.p, D, ada + 5 * D, 6 * D, S, presum ? m->hsq.as<float>() : nullptr));
         hsq_valid = presum;
@@ -467,6 +538,15 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
                 for (int bb = 0; bb < B; ++bb)
                     if (mv.t[bb] == 1.f) HIP_TRY(hipMemcpyAsync((char*)m->hsq.p + bb * rowb, (const char*)m->orig_hsq.p + bb * rowb, rowb, hipMemcpyDeviceToDevice, s));
             } else hsq_valid = false;
+            // m->n was formed from the un-blended rows, for the block after this one; the restored rows need theirs: the producer's
+            // expression on the rows as they stand now (for the rows that kept the block: the bits the epilogue wrote)
+            hs_valid = false;
+            if (nfold && hsq_valid) {
+                if (const int ln = next_block(l); ln >= 0) {
+                    LTX_TRY(ltx_launch_mod_scale(m->h.p, ada_all + (size_t)ln * B * 6 * D + D, 6 * D, m->n.p, B, S, D, dt, s));
+                    hs_valid = true;
+                }
+            }
         }
     }
 

@@ -90,6 +90,16 @@ __global__ void skip_blend_kernel(void* h, const void* orig, TimeVec m, int64_t 
     }
 }
 
+// y = h (.) (1 + scale[b]) in the model dtype: the second output of the norm fold's producers (GemmArgs::C2, gemm_asm.hip - the same
+// expression on the rows as stored, so the same bits), for the one place a GEMM epilogue cannot write it: behind the skip-layer blend
+__global__ void mod_scale_kernel(const void* h, const float* scale, int scale_stride, void* y, int B, int64_t rows_per_batch, int D, int dt) {
+    const int64_t n = (int64_t)B * rows_per_batch * D;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / (rows_per_batch * D)), col = (int)(i % D);
+        std_(y, dt, i, ldd(h, dt, i) * (1.0f + scale[(int64_t)b * scale_stride + col]));
+    }
+}
+
 // ---- guidance + Euler (t2v_pipeline.rs:941-964, 227-243; scheduler.rs:576-581) ----
 __device__ __forceinline__ float cfg_of(const GuidanceArgs& a, int64_t i, float& t) {
     t = ldd(a.text, a.pred_dtype, i);
@@ -253,6 +263,10 @@ int ltx_launch_gather_rows(const void* src, void* dst, const int* idx, const int
 }
 int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s) {
     hipLaunchKernelGGL(skip_blend_kernel, grid_for((int64_t)m.n * rows_per_batch * D), dim3(256), 0, s, h, orig, m, rows_per_batch, D, dtype);
+    LTX_CHECK_LAUNCH(); return LTX_OK;
+}
+int ltx_launch_mod_scale(const void* h, const float* scale, int scale_stride, void* y, int B, int64_t rows_per_batch, int D, int dtype, hipStream_t s) {
+    hipLaunchKernelGGL(mod_scale_kernel, grid_for((int64_t)B * rows_per_batch * D), dim3(256), 0, s, h, scale, scale_stride, y, B, rows_per_batch, D, dtype);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }
 int ltx_launch_guidance_step(const GuidanceArgs& a, hipStream_t s) {

@@ -175,7 +175,9 @@ template <> struct AsmLoop16<320, 256, 2, 2> {             // 320 accumulator re
 __device__ uint32_t g_asm16_trace[1024 * 4 * 16];   // per wave: 8 segment sums, then entry / loop start / loop end / exit (100 MHz clock) and HW_ID
 #endif
 
-template <int BM, int BN, int WGM, int WGN, int EPI, bool RSQ = false, bool PF_R = false>
+// FOLD (EPI_BIAS / EPI_GELU): the consumer side of the norm fold (GemmArgs::rs_sq / cvec, kernels.h) - out = epi(r_m * acc + cvec[b][n]).
+// The producer side (GemmArgs::C2, residual epilogues with RSQ) is a uniform run-time branch of those instantiations.
+template <int BM, int BN, int WGM, int WGN, int EPI, bool RSQ = false, bool PF_R = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, NT = MB * NB, AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 128;
@@ -263,6 +265,26 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         pf_voff[1] = n0 + 4 * cg_pf + 128 < g.N ? row0 + (uint32_t)(8 * cg_pf + 256) : 0x80000000u;
         pf_stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)g.ldr * 2u));
     }
+    // Norm fold, consumer side: the tile rows' partial sums of squares (written by the previous launch, on other XCDs: a trip past the
+    // L2) are requested HERE, in front of the K loop - read right after it they cost the block 3 - 5 us of exposed latency per tile
+    // (kernel trace: qkv 98.5 -> 109.2 us, ff1 133.7 -> 143.9).  One row per thread (rows 256 .. BM - 1: the first threads again);
+    // at most 16 partials per row (D <= 2048), groups past rs_n re-read the last one and are zeroed - no branch around a load.
+    // Rows 256 .. BM - 1 of the 320-row tile: four lanes per row, one group of four partials each (20 registers across the loop
+    // instead of 32, which spilled); the ascending sum then runs through the four lanes in turn.
+    static_assert(!FOLD || BM <= 256 || BM == 320, "norm fold: 64 extra rows = 256 (row, group) units");
+    f32x4 fpt[4], fpx = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) {
+        auto group_of = [&](int row, int q4) {
+            const int m = m0 + row < g.M ? m0 + row : g.M - 1;
+            const bool in = 4 * q4 < g.rs_n;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(g.rs_sq + (int64_t)m * g.rs_n + (in ? 4 * q4 : g.rs_n - 4));
+            return in ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        const int row = tid < BM ? tid : BM - 1;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) fpt[q4] = group_of(row, q4);
+        if constexpr (BM > 256) fpx = group_of(256 + (tid >> 2), tid & 3);
+    }
 #ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
 #else
@@ -297,6 +319,32 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         if (!okA) nA = 0;
         if (!okB) nB = 0;
         float bA[4] = {0.f, 0.f, 0.f, 0.f}, bB[4] = {0.f, 0.f, 0.f, 0.f};
+        static_assert(!FOLD || EPI == EPI_BIAS || EPI == EPI_GELU, "norm fold, consumer side: bias / GELU epilogues");
+        if constexpr (FOLD) {
+            // 1 / rms of the tile's rows from the partials requested in front of the K loop (ascending order, the expression of
+            // rownorm_presum_kernel), one thread per row, into the LDS behind the two stages (the K loop never touches it; the
+            // first barrier below publishes it)
+            float* rl = reinterpret_cast<float*>(asm_smem + 2 * STAGE);
+            if (tid < BM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) { ss += fpt[q4][0]; ss += fpt[q4][1]; ss += fpt[q4][2]; ss += fpt[q4][3]; }
+                rl[tid] = 1.0f / sqrtf(ss * (1.0f / (float)g.rs_D) + g.rs_eps);
+            }
+            if constexpr (BM > 256) {                          // lanes 4 i .. 4 i + 3 hold groups 0 .. 3 of row 256 + tid / 4: the same ascending chain
+                float run = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float before = q4 ? __shfl(run, (lane & ~3) + q4 - 1) : 0.f;
+                    if ((tid & 3) == q4) { run = before; run += fpx[0]; run += fpx[1]; run += fpx[2]; run += fpx[3]; }
+                }
+                if ((tid & 3) == 3) rl[256 + (tid >> 2)] = 1.0f / sqrtf(run * (1.0f / (float)g.rs_D) + g.rs_eps);
+            }
+            const float* cp = g.cvec + (int64_t)(m0 / g.rows_per_batch) * g.cvec_stride;
+            const f32x4 cA4 = *reinterpret_cast<const f32x4*>(cp + nA), cB4 = *reinterpret_cast<const f32x4*>(cp + nB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bA[i] = cA4[i]; bB[i] = cB4[i]; }
+        } else
         if (g.bias) { load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nA, bA); load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nB, bB); }
         // Output and residual tiles through buffer descriptors based at the tile's first row: 32-bit offsets, rows beyond M
         // and column groups beyond N fall out of range (stores dropped, loads return 0) - no branch around a memory operation.
@@ -315,24 +363,73 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         const uint32_t cA = okA ? (uint32_t)(8 * cg) : 0x80000000u, cB = okB ? (uint32_t)(8 * cg + 256) : 0x80000000u;
         const int m_last = m0 + rows_valid - 1;
         const float fA = okA ? 1.f : 0.f, fB = okB ? 1.f : 0.f;
-        bool one_batch = true;
-        f32x4 gA = {}, gB = {};
+        const int m_split = (m0 / g.rows_per_batch + 1) * g.rows_per_batch;      // first row of the tile's second batch element
+        const bool straddle = m_last >= m_split;                                  // (block-uniform)
+        // Gate rows: the tile's first and LAST batch element are loaded here; a tile that straddles one boundary (rows_per_batch >= BM)
+        // chooses per row.  (Round 6: the row loop used to re-load the gate behind an `if (!one_batch)` - never taken at one batch
+        // element, but a load in the loop makes the compiler drain vmcnt, i.e. every output store of the rows before, at each step:
+        // 22 vmcnt(0) per tile in the gate + residual epilogues against 1 - 2 in the others.)  Batch elements shorter than the
+        // tallest tile are not this kernel's (ltx_gemm_asm16_fits).
+        f32x4 gA = {}, gB = {}, gA1 = {}, gB1 = {};
         if constexpr (EPI == EPI_GATE_RESID) {
-            one_batch = m0 / g.rows_per_batch == m_last / g.rows_per_batch;
             const float* gp = g.gate + (int64_t)(m0 / g.rows_per_batch) * g.gate_stride;
+            const float* gp1 = g.gate + (int64_t)(m_last / g.rows_per_batch) * g.gate_stride;
             gA = *reinterpret_cast<const f32x4*>(gp + nA); gB = *reinterpret_cast<const f32x4*>(gp + nB);
+            gA1 = *reinterpret_cast<const f32x4*>(gp1 + nA); gB1 = *reinterpret_cast<const f32x4*>(gp1 + nB);
+        }
+        // Norm fold: the per-batch-row vectors (cvec of the consumer, 1 + scale of the producer) of a tile that straddles a batch
+        // boundary (rows_per_batch >= BM: at most one - ltx_gemm_fold_ok) are BOTH loaded here and chosen per row: a load inside
+        // the row loop, even behind a branch that is never taken, makes the compiler drain vmcnt - the output stores of the
+        // previous rows - before every step (kernel trace: + 9 us per consumer launch, + 4 per producer).
+        float bA1[4] = {0.f, 0.f, 0.f, 0.f}, bB1[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FOLD) {
+            const float* cp1 = g.cvec + (int64_t)(m_last / g.rows_per_batch) * g.cvec_stride;
+            const f32x4 cA4 = *reinterpret_cast<const f32x4*>(cp1 + nA), cB4 = *reinterpret_cast<const f32x4*>(cp1 + nB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bA1[i] = cA4[i]; bB1[i] = cB4[i]; }
+        }
+        // producer side: 1 + scale of the NEXT norm for this thread's columns (a second output of the residual epilogues)
+        const bool fold_out = HAS_R && RSQ && g.C2 != nullptr;
+        float s2A[4] = {1.f, 1.f, 1.f, 1.f}, s2B[4] = {1.f, 1.f, 1.f, 1.f}, s2A1[4] = {1.f, 1.f, 1.f, 1.f}, s2B1[4] = {1.f, 1.f, 1.f, 1.f};
+        __amdgpu_buffer_rsrc_t rc2 = rc;
+        if constexpr (HAS_R && RSQ) {
+            if (fold_out) {
+                const float* sp = g.scale2 + (int64_t)(m0 / g.rows_per_batch) * g.scale2_stride;
+                const float* sp1 = g.scale2 + (int64_t)(m_last / g.rows_per_batch) * g.scale2_stride;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(sp + nA), b4 = *reinterpret_cast<const f32x4*>(sp + nB);
+                const f32x4 a41 = *reinterpret_cast<const f32x4*>(sp1 + nA), b41 = *reinterpret_cast<const f32x4*>(sp1 + nB);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s2A[i] = 1.0f + a4[i]; s2B[i] = 1.0f + b4[i]; s2A1[i] = 1.0f + a41[i]; s2B1[i] = 1.0f + b41[i]; }
+                rc2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(g.C2) + (int64_t)m0 * g.ldc + n0, 0, (int)(((uint32_t)(rows_valid - 1) * (uint32_t)g.ldc + 256u) * 2u), 0x00020000);
+            }
         }
         // value of one 4-column group: the expressions of epilogue() (gemm_common.h), residual already loaded
-        auto finish = [&](const f32x4& acc, const float* bias4, const f32x4& gate_one, const bf16x4& res, int n, int m, float* v) {
+        auto finish = [&](auto str_tag, const f32x4& acc, const float* bias4, const float* bias41, const f32x4& gate_one, const f32x4& gate_two, const bf16x4& res, int n, int m, float* v, float rrow) {
+            constexpr bool STR = decltype(str_tag)::value;
+            if constexpr (FOLD) {
+                if constexpr (!STR) {                               // (uniform: the whole tile in one batch element - no per-element selects)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(rrow, acc[i], bias4[i]);
+                } else {
+                    const bool second = m >= m_split;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(rrow, acc[i], second ? bias41[i] : bias4[i]);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias4[i];
+            }
             if constexpr (EPI == EPI_GELU) {
                 gelu_tanh4(v);
             } else if constexpr (HAS_R) {
                 const float r[4] = {(float)res[0], (float)res[1], (float)res[2], (float)res[3]};
                 if constexpr (EPI == EPI_GATE_RESID) {
                     f32x4 gt = gate_one;
-                    if (!one_batch) gt = *reinterpret_cast<const f32x4*>(g.gate + (int64_t)(m / g.rows_per_batch) * g.gate_stride + n);
+                    if constexpr (STR) {
+                        const bool second = m >= m_split;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gt[i] = second ? gate_two[i] : gate_one[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gt[i], v[i], r[i]);       // ONE rounding, spelled out: every kernel that finishes these rows must agree
                 } else {
@@ -350,6 +447,11 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #ifdef GEMM_ASM_TRACE
         uint32_t t_e0 = 0, t_e1 = 0, t_e2 = 0;
 #endif
+        // The row passes, in two copies: tiles inside one batch element (all of them at one video per call) run without the
+        // per-row choice between the two batch elements' vectors (the compiler turns a branch on the block-uniform flag inside the
+        // row loop into per-element selects: 16 v_cndmask per row on a one-wave-per-SIMD epilogue, 2.4 us per tile).
+        auto run_passes = [&](auto str_tag) {
+        constexpr bool STR = decltype(str_tag)::value;
 #pragma unroll
         for (int p = 0; p < BM / RP; ++p) {
             __syncthreads();                               // K loop (or the previous pass) is done with the LDS image in every wave
@@ -394,12 +496,28 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                     const int trow = p * RP + r0 + 8 * (k0 + j);
                     const int m = m0 + trow < g.M ? m0 + trow : g.M - 1;       // gate row of a straddling tile only
                     float oA[4], oB[4];
-                    finish(vA[j], bA, gA, qA[j], nA, m, oA);
-                    finish(vB[j], bB, gB, qB[j], nB, m, oB);
+                    float rrow = 1.f;
+                    if constexpr (FOLD) rrow = reinterpret_cast<const float*>(asm_smem + 2 * STAGE)[trow];
+                    finish(str_tag, vA[j], bA, bA1, gA, gA1, qA[j], nA, m, oA, rrow);
+                    finish(str_tag, vB[j], bB, bB1, gB, gB1, qB[j], nB, m, oB, rrow);
                     const uint32_t co = (uint32_t)trow * (uint32_t)g.ldc * 2u;
                     const bf16x4 pA = {(bf16_t)oA[0], (bf16_t)oA[1], (bf16_t)oA[2], (bf16_t)oA[3]}, pB = {(bf16_t)oB[0], (bf16_t)oB[1], (bf16_t)oB[2], (bf16_t)oB[3]};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pA), rc, (int)(co + cA), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pB), rc, (int)(co + cB), 0, 0);
+                    if constexpr (HAS_R && RSQ) {
+                        if (fold_out) {                        // h (.) (1 + scale) of the rows as stored: the A operand of the layer behind the next norm
+                            float tA[4] = {s2A[0], s2A[1], s2A[2], s2A[3]}, tB[4] = {s2B[0], s2B[1], s2B[2], s2B[3]};
+                            if constexpr (STR) {
+                                const bool second = m >= m_split;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { tA[i] = second ? s2A1[i] : s2A[i]; tB[i] = second ? s2B1[i] : s2B[i]; }
+                            }
+                            const bf16x4 hA = {(bf16_t)((float)pA[0] * tA[0]), (bf16_t)((float)pA[1] * tA[1]), (bf16_t)((float)pA[2] * tA[2]), (bf16_t)((float)pA[3] * tA[3])};
+                            const bf16x4 hB = {(bf16_t)((float)pB[0] * tB[0]), (bf16_t)((float)pB[1] * tB[1]), (bf16_t)((float)pB[2] * tB[2]), (bf16_t)((float)pB[3] * tB[3])};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hA), rc2, (int)(co + cA), 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hB), rc2, (int)(co + cB), 0, 0);
+                        }
+                    }
                     if constexpr (RSQ) {
                         // GemmArgs::rowsq: the leaves of this thread's two 4-column groups (values as stored) go into the first
                         // dword of its OWN two 16-byte slots of the row, which it has just consumed - nobody else reads them
@@ -444,6 +562,8 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
                 }
             }
         }
+        };
+        if (straddle) run_passes(std::true_type{}); else run_passes(std::false_type{});
 #ifdef GEMM_ASM_TRACE
         if (lane == 0 && blockIdx.x < 1024) { uint32_t* o = g_asm16_trace + (blockIdx.x * 4 + wave) * 16; o[13] = t_e0; o[14] = t_e1; o[15] = t_e2; }
 #endif
@@ -658,7 +778,19 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
     if constexpr (CAN_PF) {
         if (pf_r) kern = g.rowsq ? gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, true, true> : gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, false, true>;
     }
-    LTX_TRY(ltx_set_max_dyn_smem(pf_r ? (wrote_rowsq ? attr_devs_pf_rsq : attr_devs_pf) : (wrote_rowsq ? attr_devs_rsq : attr_devs), reinterpret_cast<const void*>(kern), smem));
+    // norm fold (kernels.h): the consumer side is its own instantiation (+ 2 KiB of LDS for the rows' 1 / rms); the producer side
+    // lives in the RSQ instantiations of the residual epilogues
+    static std::atomic<unsigned long long> attr_devs_fold{0};
+    bool fold_in = false;
+    if constexpr (MF16 && (EPI == EPI_BIAS || EPI == EPI_GELU)) {
+        if (g.rs_sq) {
+            if (g.rowsq || !g.cvec || g.rs_n < 4 || g.rs_n > 16 || g.rs_n % 4 || g.rows_per_batch < 1) LTX_FAIL(LTX_ERR_ARG, "gemm_asm16: norm fold needs cvec, 4 .. 16 row partials in groups of four and no rowsq by-product");
+            kern = gemm_asm16_kernel<BM, BN, WGM, WGN, EPI, false, false, true>; fold_in = true;
+        }
+    } else if (g.rs_sq) LTX_FAIL(LTX_ERR_ARG, "gemm_asm16: norm fold (rs_sq) on an epilogue that does not carry it");
+    if (g.C2 && !(wrote_rowsq && (EPI == EPI_GATE_RESID || EPI == EPI_RESID))) LTX_FAIL(LTX_ERR_ARG, "gemm_asm16: the second output (C2) rides on the residual epilogues with rowsq");
+    const int smem_l = smem + (fold_in ? 2048 : 0);
+    LTX_TRY(ltx_set_max_dyn_smem(fold_in ? attr_devs_fold : pf_r ? (wrote_rowsq ? attr_devs_pf_rsq : attr_devs_pf) : (wrote_rowsq ? attr_devs_rsq : attr_devs), reinterpret_cast<const void*>(kern), smem_l));
     GemmArgs ga = g;
     ga.xcd_remap = ltx_exp("xcd_remap", 1);
     {   // near-square patch of tiles per XCD (gemm_big.hip launch_one): one block per CU
@@ -670,7 +802,7 @@ int launch_asm(const GemmArgs& g, hipStream_t s) {
         ga.group_m = gm < 2 ? 0 : gm;
     }
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(256), smem, s, ga);
+    LTX_LAUNCH_TIMED(kern, dim3((unsigned)tiles), dim3(256), smem_l, s, ga);
     LTX_CHECK_LAUNCH();
     if (wrote_rowsq) ltx_gemm_rowsq_done();
     return LTX_OK;
@@ -703,9 +835,21 @@ bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi) {
     if (g.N % 8 != 0 || g.ldc % 4 != 0 || ((uintptr_t)g.C & 7) || !seg_ok) return false;
     if (g.bias && ((uintptr_t)g.bias & 7)) return false;
     if ((epi == EPI_GATE_RESID || epi == EPI_RESID) && (!g.resid || g.ldr % 4 != 0 || ((uintptr_t)g.resid & 7))) return false;
-    if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 1)) return false;
+    if (epi == EPI_GATE_RESID && (!g.gate || ((uintptr_t)g.gate & 15) || g.gate_stride % 4 != 0 || g.rows_per_batch < 320)) return false;      // (a tile straddles at most one batch boundary)
     if (ltx_gemm_split_factor(g) > 1) return false;       // small outputs keep the split-K tiles of gemm_big
     return g.M > 512 && g.N >= 512;                       // (up to 512 rows: gemm_ring.hip's tiles, never split)
+}
+
+// Norm fold (GemmArgs::C2 / ::rs_sq): what the wide epilogue needs on top of ltx_gemm_asm16_fits
+bool ltx_gemm_fold_ok(const GemmArgs& g, int epi) {
+    if (!ltx_gemm_asm16_fits(g, epi) || (ltx_opt().gemm_off & LTX_FAM_ASM16) || !ltx_opt().gemm_wide_epi) return false;
+    if (g.C2) {
+        if ((epi != EPI_GATE_RESID && epi != EPI_RESID) || !g.rowsq || !g.scale2 || g.scale2_stride % 4 || ((uintptr_t)g.scale2 & 15) || ((uintptr_t)g.C2 & 7) || g.rows_per_batch < 320 || g.c_seg_shift) return false;
+    }
+    if (g.rs_sq) {
+        if ((epi != EPI_BIAS && epi != EPI_GELU) || g.rowsq || !g.cvec || g.cvec_stride % 4 || ((uintptr_t)g.cvec & 15) || g.rs_n < 4 || g.rs_n > 16 || g.rs_n % 4 || ((uintptr_t)g.rs_sq & 15) || g.rows_per_batch < 320) return false;      // (a tile straddles at most one batch boundary)
+    }
+    return true;
 }
 
 // Experiment builds, x_gemm_asm=1: round 1's 32x32x16 loop for every shape it serves (tests, A/B).  The 16x16x32 kernel is a plan

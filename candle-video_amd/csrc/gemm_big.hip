@@ -692,6 +692,7 @@ int tune_plan(const GemmArgs& g_in, int epi, hipStream_t s, int fallback, int* p
     const size_t scratch_bytes = defer ? (size_t)ltx_gemm_split_factor(g) * g.M * g.N * sizeof(float) : (size_t)g.M * g.N * sizeof(bf16_t);
     if (hipMalloc(&scratch, scratch_bytes) != hipSuccess) { (void)hipGetLastError(); return LTX_OK; }
     g.C = scratch; g.ldc = g.N; g.resid = nullptr; g.gate = nullptr; g.c_seg_shift = 0; g.c_seg_stride = 0; g.rowsq = nullptr;
+    g.C2 = nullptr; g.scale2 = nullptr; g.rs_sq = nullptr; g.cvec = nullptr;      // (norm-fold calls share the plain call's plan: same shape, same loop)
     g.defer_parts = defer ? reinterpret_cast<float*>(scratch) : nullptr;
     struct Guard {                                           // events and scratch are released on every return path
         void* scratch; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -857,6 +858,20 @@ int ltx_launch_gemm_big(const GemmArgs& g_in, int epi, hipStream_t s) {
         return ltx_launch_gemm_ring(g, epi, plan - kPlanRing, s);
     }
     const LtxOptions& o = ltx_opt();
+    if (g.C2 || g.rs_sq) {
+        // Norm fold (kernels.h): only gemm_asm16's wide epilogue carries the second output / the row scale (the caller asked
+        // ltx_gemm_fold_ok).  Tile: the shape's measured plan where that is an asm16 tile (or a forced one), else the family's own choice.
+        if (!ltx_gemm_fold_ok(g, epi)) LTX_FAIL(LTX_ERR_ARG, "gemm: norm-fold arguments on a call gemm_asm16 does not serve (ltx_gemm_fold_ok)");
+        const int t = ltx_gemm_asm_pick_tile(g.M, g.N);                  // kAsmTiles order: 256 x 256, 320 x 256, 160 x 256
+        int plan = kPlanAsm16 + (t == 0 ? 0 : (t == 1 ? 2 : 1));
+        if (o.gemm_plan[0]) { const int f = plan_from_name(o.gemm_plan); if (f >= kPlanAsm16 && f < kPlanAsm16 + 3) plan = f; }
+        else {
+            int cached = plan;
+            (void)cached_or_tuned_plan(g, epi, s, &cached);
+            if (cached >= kPlanAsm16 && cached < kPlanAsm16 + 3) plan = cached;
+        }
+        return ltx_launch_gemm_asm16(g, epi, plan - kPlanAsm16, s);
+    }
     const bool split_shape = ltx_gemm_split_factor(g) > 1;
     const int nk = (g.K + 63) / 64 * (g.conv ? g.ntaps : 1);
     // Option gemm_plan (tests, A/B): one plan forced wherever the call is eligible for it - a full plan name, or a family name

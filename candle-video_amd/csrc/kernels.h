@@ -55,6 +55,16 @@ struct GemmArgs {
     // ltx_rowsq_leaf / ltx_launch_rowsq - so the value does not depend on which kernel the plan picked: gemm_asm16's
     // epilogue produces it in place, every other kernel is followed by the stand-alone pass (ltx_launch_gemm).
     float* rowsq = nullptr;
+    // Norm fold (round 6; bf16, gemm_asm16's wide epilogue only - dit.hip asks ltx_gemm_fold_ok).  RMS norm + modulation
+    //   y = h * r_m * (1 + sc) + sh,  r_m = 1 / sqrt(mean(h_m^2) + eps)     (LtxVideoTransformerBlock::forward, ltx_transformer.rs:847-851, 905-909)
+    // followed by a linear layer equals  r_m * ((h (.) (1 + sc)) W^T) + (sh W^T + b): the layer that WRITES h also stores
+    //   C2[m][n] = bf16(float(C[m][n] as stored) * (1 + scale2[b(m)][n]))     (RESID / GATE_RESID; leading dimension ldc)
+    // and the layer that READS the normalised rows takes A = C2 and finishes  out = epi(r_m * acc + cvec[b(m)][n])  with r_m from
+    // the producer's row partials rs_sq[m][0 .. rs_n) (GemmArgs::rowsq of that launch) and cvec = sh W^T + b in f32
+    // (ltx_launch_shift_gemv, cached per timestep): the stand-alone norm pass (a read and a write of [M, D]) disappears.
+    // b(m) = m / rows_per_batch in both.
+    void* C2 = nullptr; const float* scale2 = nullptr; int scale2_stride = 0;
+    const float* rs_sq = nullptr; int rs_n = 0, rs_D = 0; float rs_eps = 0.f; const float* cvec = nullptr; int cvec_stride = 0;
     // Optional second copy of W for gemm_ring.hip (linear layers of at most 512 rows): [ceil(N/32)][ceil(K/64)][32 rows][64] bf16,
     // zero padded - a tile's K-step is then 4-KiB blocks and a block's whole K range one contiguous stream, instead of 128-byte
     // pieces of rows K * 2 bytes apart (ltx_pack_ring_weights; same values; measured neutral: opt-in, LTX_RING_PACK=1)
@@ -88,6 +98,9 @@ bool ltx_gemm_defer_ok(const GemmArgs& g, int epi);   // gemm_ring.hip: the call
 // gemm_asm.hip: one-wave-per-SIMD kernels with a generated asm K loop; eligibility is a function of the shape only
 bool ltx_gemm_asm_eligible(const GemmArgs& g, int dtype, int epi);
 int ltx_launch_gemm_asm(const GemmArgs& g, int epi, hipStream_t s);
+bool ltx_gemm_fold_ok(const GemmArgs& g, int epi);      // gemm_asm.hip: the call (with GemmArgs::C2 or ::rs_sq set) is one the wide epilogue serves
+// cvec[b][n] = sum_k shift[b * shift_stride + k] * W[n][k] + bias[n]   (f32 accumulation in ascending k; W, bias bf16; rownorm.hip)
+int ltx_launch_shift_gemv(const void* W, const void* bias, const float* shift, int shift_stride, int B, int N, int K, float* cvec, int cvec_stride, hipStream_t s);
 bool ltx_gemm_asm16_fits(const GemmArgs& g, int epi);                       // the 16x16x32 one-wave-per-SIMD kernel (plan family asm16:*)
 int ltx_launch_gemm_asm16(const GemmArgs& g, int epi, int tile, hipStream_t s);
 bool ltx_gemm_asm16_conv_fits(const GemmArgs& g, int epi);                  // the same loop in conv mode (3x3x3, tile 256 x 256; plan "asm16c:256x256")
@@ -220,6 +233,7 @@ int ltx_launch_key_compact(const float* bias, int B, int K, int* idx, int* count
 int ltx_launch_gather_rows(const void* src, void* dst, const int* idx, const int* count, int nl, int B, int K, int row_bytes, hipStream_t s);
 // h = h*(1-m_b) + orig*m_b
 int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s);
+int ltx_launch_mod_scale(const void* h, const float* scale, int scale_stride, void* y, int B, int64_t rows_per_batch, int D, int dtype, hipStream_t s);   // y = h (.) (1 + scale[b])
 
 struct GuidanceArgs {
     const void* text = nullptr; const void* uncond = nullptr; const void* pert = nullptr;  // model dtype (pred_dtype)

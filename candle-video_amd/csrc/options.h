@@ -29,6 +29,7 @@ struct LtxOptions {
     int norm_presum = 1;          // 0: row-reducing RMS norms; 2: the map whatever the shape
     int norm_lean = 1;            // 0: the general presum kernel (same bits as the lean one)
     int xattn_compact = 1;        // 0: cross attention multiplies every text key
+    int norm_fold = 1;            // 0: the DiT's RMS norms between GEMMs as their own (presum) pass; 1: folded into the producer's / consumer's epilogues (dit.hip)
     int guidance_batch = 1;       // 0: the guidance branches of a step (uncond / text / perturbed) as separate forwards, the reference's call order
     int dense_qkv = 1;            // 0: q | k | v as column slices of one [M, 3D] matrix
     int vae_fuse_norm = 1;        // 0: the resnet's second norm as its own pass; 2: fused on grids below one round of the chip too (tests)

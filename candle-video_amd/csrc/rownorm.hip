@@ -1037,6 +1037,52 @@ int ltx_launch_rowsq(const void* x, int dtype, int64_t rows, int N, int ld, floa
     return LTX_OK;
 }
 
+// cvec[b][n] = sum_k shift[b][k] * W[n][k] + bias[n] (norm fold, kernels.h): one wave per output column, lanes over 16-byte
+// chunks of the weight row, f32 throughout, a fixed order of additions (per lane ascending k, then the lanes' sums by halving).
+// Reads W once: a step's 2 x num_layers launches stream the q|k|v and ff1 weights at the HBM rate - once per distinct timestep.
+namespace {
+__global__ __launch_bounds__(256) void shift_gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, const float* __restrict__ shift, int shift_stride,
+                                                          int B, int N, int K, float* __restrict__ out, int out_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wr = W + (int64_t)n * K;
+    for (int c = lane; c < K / 8; c += 64) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wr + c * 8);
+        float wf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wf[i] = (float)w[i];
+        for (int b = 0; b < B; ++b) {
+            const float* sp = shift + (int64_t)b * shift_stride + c * 8;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            float a = acc[b];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a = __builtin_fmaf(wf[i], s0[i], a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a = __builtin_fmaf(wf[4 + i], s1[i], a);
+            acc[b] = a;
+        }
+    }
+    const float bn = bias ? (float)bias[n] : 0.f;
+    for (int b = 0; b < B; ++b) {
+        float a = acc[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0) out[(int64_t)b * out_stride + n] = a + bn;
+    }
+}
+}  // namespace
+
+int ltx_launch_shift_gemv(const void* W, const void* bias, const float* shift, int shift_stride, int B, int N, int K, float* cvec, int cvec_stride, hipStream_t s) {
+    if (!W || !shift || !cvec || B < 1 || B > 8 || N < 1 || K < 8 || K % 8 || shift_stride % 4 || ((uintptr_t)W & 15) || ((uintptr_t)shift & 15))
+        LTX_FAIL(LTX_ERR_ARG, "shift_gemv: bf16 weights [N, K] with K % 8 == 0, f32 shift rows 16-byte aligned, 1..8 batch rows");
+    hipLaunchKernelGGL(shift_gemv_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(W), reinterpret_cast<const bf16_t*>(bias),
+                       shift, shift_stride, B, N, K, cvec, cvec_stride);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
+
 int ltx_launch_rope_table(const RopeTableArgs& a, hipStream_t s) {
     if (a.D % 2 != 0 || a.D < 6) LTX_FAIL(LTX_ERR_ARG, "rope: dim must be even and >= 6");
     const int64_t total = (int64_t)a.B * a.F * a.H * a.W * (a.D / 2);
