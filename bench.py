@@ -60,6 +60,12 @@ DISTILLED_SIGMAS = [1.0, 0.9937, 0.9875, 0.9812, 0.9750, 0.9094, 0.7250]      # 
 # 8 minutes of 16 threads - too long for the default bench run, which times a bounded sample and labels its value an ESTIMATE).
 FULL_C2_RUN = {"seconds": 501.07, "frames_per_sec": 97 / 501.07, "cores": 16, "machine": "a GPU box of the pool (AMD EPYC 9575F 64-Core, 256 logical CPUs), not necessarily the box of this run",
                "record": "profiles/r5_oracle_c2_on_gpu_box.json", "earlier": "622.57 s on the 8-core build container (profiles/r3_oracle_cpu_runs.json)"}
+# Round 6: the bounded sample and the full run measured in ONE process on one GPU box (tools/cpu_baseline_calibrate.py): the full C2 run
+# took 31.35 x the full C1 run of the same process (556.2 s against 17.74 s); the bounded-sample estimate of that run was 598.6 s
+# (-7 % .. +34 % against full runs over the boxes seen: its 1- and 3-layer timings are noisy).  `value` for the headline workload is
+# therefore THIS run's measured C1 time x that ratio - an estimate, and labelled one (`value_is`) - with the sample beside it.
+C2_OVER_C1_SECONDS = 556.1911268234253 / 17.744389533996582
+CPU_CALIBRATION_RECORD = "profiles/r6_cpu_baseline_calibration.json"
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -183,8 +189,14 @@ def cpu_baseline(cfg, fl_job, calibrate=True):
     t_crop = time.time() - t0
     t_vae = t_crop * vae_flops(F, H, W) / vae_flops(cf, chh, cww)
     total = 7 * t_fwd + t_vae
-    return {"value": cfg["num_frames"] / total, "unit": "frames/sec", "cores": ncores, "kind": "port", "port_of": "torch-CPU (oneDNN / MKL) op-for-op restatement of the reference's CPU path (oracle/ltx_oracle.py)",
+    total_cal = t_c1 * C2_OVER_C1_SECONDS if calibrate else total
+    return {"value": cfg["num_frames"] / total_cal, "unit": "frames/sec", "value_is": "estimate" if calibrate else "raw bounded-sample estimate",
+            "value_from": (f"this run's MEASURED full C1 oracle run ({t_c1:.1f} s) x {C2_OVER_C1_SECONDS:.2f}, the C2 / C1 time ratio of two full oracle runs measured in one "
+                           f"process on a GPU box ({CPU_CALIBRATION_RECORD}) = {total_cal:.0f} s per video; the bounded sample of C2 itself gives {total:.0f} s") if calibrate else "bounded sample",
+            "bounded_sample_value": cfg["num_frames"] / total,
+            "cores": ncores, "kind": "port", "port_of": "torch-CPU (oneDNN / MKL) op-for-op restatement of the reference's CPU path (oracle/ltx_oracle.py)",
             "machine": host_machine(), "c1_measured": c1, "full_c2_run": FULL_C2_RUN,
+            "full_c2_run_r6": {"seconds": 556.19, "frames_per_sec": 97 / 556.19, "cores": 16, "same_process_c1_seconds": 17.74, "record": CPU_CALIBRATION_RECORD},
             "sample": f"ESTIMATE for this workload from a bounded sample of it ({t_n[1] + t_n[3] + t_crop:.1f} s of CPU work): oracle f32 DiT forwards with 1 and 3 of 28 "
                       f"layers at S={S} ({t_n[1]:.2f} s, {t_n[3]:.2f} s -> {t_fixed:.2f} s + 28 x {t_layer:.2f} s per forward, x7 steps) + VAE decode of a {cf}x{chh}x{cww} "
                       f"latent crop ({t_crop:.2f} s, scaled by conv FLOPs to {F}x{H}x{W}) = {total:.0f} s per video; MEASURED beside it: C1 in full, {t_c1:.1f} s "

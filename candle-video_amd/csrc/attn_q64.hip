@@ -751,7 +751,6 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnArgs a, int 
     else attn_q64_block<1>(a, smem, b, head, nbig * 256 + qb * 128, 0, a.Sk, nullptr);
 }
 
-#ifdef LTX_EXPERIMENTS     // the persistent form (measured 3 % behind the block grid, lab notes): experiment builds only (x_attn_q64_persist=1)
 // ---- persistent form: one workgroup per CU walks a static list of items ---------------------------------------------
 // The one-block-per-(head, 256 queries) grid above runs 2.44 rounds of work in 2 + 0.70 rounds at S = 4992 (the last
 // round as 128-query blocks at 70 % of a big block's time each).  Here the host cuts the work evenly: every CU gets
@@ -855,7 +854,147 @@ __global__ __launch_bounds__(256, 1) void attn_q64_persist_kernel(const AttnArgs
     }
 }
 
-#endif  // LTX_EXPERIMENTS
+
+// ---- stream form (round 6): the persistent list above with the seams between items hidden -------------------------------------
+// A workgroup's items run as one continuous K/V/Q stream: the last four loop iterations of an item request the NEXT item's first
+// four key tiles into the ring slots they free (where the block grid requests out-of-range zeros), its Q^T goes by LDS-DMA into a
+// per-wave staging area laid out like a K tile (so its fragments are K fragment reads) when the loop ends, and the epilogue runs under
+// their flight: a block start costs the S^T(0) chain and the row maxima instead of a cold 96-KiB burst that all 256 CUs of a
+// lockstep grid issue at once (5.5 us per block).  The tail of the grid (S = 4992: 2.44 rounds) is cut into key-range
+// parts of 256-query blocks, merged by the last arriver (attn_q64_merge): every CU gets 2.44 blocks' worth of tiles.
+// One generated statement per item (q64_stream_qb2 / q64_stream_part_qb2); what crosses from one to the next is LDS contents and
+// outstanding vector-memory operations only - nothing the compiler sees.  Every scalar of an item is host-built (Q64SItem::w).
+struct Q64SItem { uint32_t w[16]; int kind, b, head, q_first, k_row0, Sk, slab0, part, nparts, cnt, pad[6]; };     // kind: 2 whole block, 3 part, 1 128-query block (QB = 1, cold)
+constexpr int QS_OFF = NSLOT * TILE_BYTES + 1024;          // Q^T staging: 8 KiB per wave, behind the ring and its flag words
+
+__global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs a, const Q64SItem* __restrict__ items, const int* __restrict__ first,
+                                                                  float* slabs, unsigned* cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[QS_OFF + 4 * 8192];
+    volatile unsigned* flagw = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, lr = lane >> 3, pc = lane & 7;
+    const int i0 = first[blockIdx.x], i1 = first[blockIdx.x + 1];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // whole-tensor descriptors: every item offset (batch, head, first row) rides in the scalar offset of the loads / stores
+    auto desc = [&](const void* p, uint32_t bytes) {
+        const uint64_t u = (uint64_t)(uintptr_t)p;
+        return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) & 0xffffu,
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+    };
+    const u32x4 rk = desc(a.k, (uint32_t)a.B * (uint32_t)a.Sk * (uint32_t)a.ldk * 2u), rv = desc(a.v, (uint32_t)a.B * (uint32_t)a.Sk * (uint32_t)a.ldv * 2u);
+    const u32x4 rq = desc(a.q, (uint32_t)a.B * (uint32_t)a.Sq * (uint32_t)a.ldq * 2u), ro_full = desc(a.o, (uint32_t)a.B * (uint32_t)a.Sq * (uint32_t)a.ldo * 2u);
+    const uint32_t kstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldk * 2u));
+    const uint32_t vstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)BKV * (uint32_t)a.ldv * 2u));
+    const uint32_t qstep8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)a.ldq * 2u));
+    const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
+    const uint32_t ldsq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)QS_OFF + (uint32_t)wave * 8192u));
+    bool force_cold = false;                               // block-uniform: the item before this one ran the exact pass (the ring was re-used)
+    for (int i = i0; i < i1; ++i) {
+        const Q64SItem* itp = items + i;
+        if (itp->kind == 1) {                               // 128-query block: the self-contained QB = 1 form (last in a list: nothing was requested ahead)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            attn_q64_block<1>(a, smem, itp->b, itp->head, itp->q_first, 0, a.Sk, nullptr);
+            force_cold = true;
+            continue;
+        }
+        // lane vectors (re-derived per item: as loop invariants they would be spilled across the statement, and a spill's reload
+        // drains vmcnt - the requests in flight for the next item)
+        u32x16 lanes; u32x4 qbase, ones_u;
+        {
+            const int rr_ = __builtin_amdgcn_readfirstlane(0) + r;      // (opaque zero: keeps the arithmetic inside the loop)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lanes[ks] = smem_base + rr_ * KROW + kswz8(rr_, 2 * ks + h) * 16;
+                qbase[ks] = smem_base + QS_OFF + wave * 8192 + rr_ * KROW + kswz8(rr_, 2 * ks + h) * 16;
+            }
+            const int trq = (lane & 15) >> 2, trp = lane & 3, trdh = (lane >> 4) & 1;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int row = 4 * h + trq, cv = d * 4 + trdh * 2 + (trp >> 1);
+                lanes[4 + d] = smem_base + row * VROW + vswz8(row, cv) * 16 + (trp & 1) * 8;
+            }
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const int row = (wave * PW + j) * 8 + lr;
+                lanes[6 + j] = (uint32_t)row * (uint32_t)a.ldk * 2u + (uint32_t)kswz8(row, pc) * 16u;
+                lanes[8 + j] = (uint32_t)row * (uint32_t)a.ldv * 2u + (uint32_t)vswz8(row, pc) * 16u;
+            }
+            // Q^T pieces: piece j = rows 8 j .. 8 j + 7 of the wave's 64 queries; the K image's swizzle on the SOURCE chunk (even / odd j differ in bit 2)
+            const uint32_t qrow = (uint32_t)(wave * 64 + lr) * (uint32_t)a.ldq * 2u;
+            lanes[10] = qrow + (uint32_t)(pc ^ (lr >> 1)) * 16u;
+            lanes[11] = qrow + (uint32_t)(pc ^ (lr >> 1) ^ 4) * 16u;
+            lanes[14] = (lane & 16) ? 1u : 0u;
+            lanes[15] = 0u;
+            const bf16_t v1 = (bf16_t)(((lane & 1) == ((lane >> 4) & 1)) ? 1.0f : 0.0f);
+            union { bf16x8 v; uint32_t u[4]; } c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c.v[e] = v1;
+            ones_u = (u32x4){c.u[0], c.u[1], c.u[2], c.u[3]};
+        }
+        u32x16 item;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) item[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)itp->w[e]);
+        if (force_cold) { item[11] = 1u; force_cold = false; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) item[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)item[e]);
+        const bool part = itp->kind == 3;
+        f32x8 la;
+        if (part) {
+            float* slab = slabs + (int64_t)(itp->slab0 + itp->part) * SLAB_F;
+            const uint64_t sp = (uint64_t)(uintptr_t)(slab + wave * SLAB_WAVE_F);
+            const u32x4 ro_slab = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32)) & 0xffffu,
+                                   (uint32_t)(SLAB_WAVE_F * 4), 0x00020000u};
+            lanes[12] = (uint32_t)lane * 16u; lanes[13] = 0u;
+            q64_stream_part_qb2(la, ones_u, lanes, qbase, item, rk, rv, rq, ro_slab, kstep, vstep, ldsw, ldsq, qstep8);
+        } else {
+            lanes[12] = (uint32_t)(wave * 64 + r) * (uint32_t)a.ldo * 2u + 16u * h;
+            lanes[13] = (uint32_t)(wave * 64 + 32 + r) * (uint32_t)a.ldo * 2u + 16u * h;
+            q64_stream_qb2(la, ones_u, lanes, qbase, item, rk, rv, rq, ro_full, kstep, vstep, ldsw, ldsq, qstep8);
+        }
+        const float l0 = (lane & 16) ? la[1] : la[0], l1 = (lane & 16) ? la[5] : la[4];
+        const bool bad = !(l0 < 0x1p100f) || !(l1 < 0x1p100f);
+        // block-uniform OR through one LDS word, with bare barriers: __syncthreads() carries a fence that would drain vmcnt
+        if (tid == 0) *flagw = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (__any(bad) && lane == 0) *flagw = 1u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool any_bad = __builtin_amdgcn_readfirstlane((int)*flagw) != 0;      // (block-uniform, and known to be: the item record is SGPR data)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // (the word is rewritten by the next item)
+        if (!Q64_NO_FALLBACK && any_bad) {                 // overflow of the fixed max: the self-contained form with its exact second pass
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            float* slab = part ? slabs + (int64_t)(itp->slab0 + itp->part) * SLAB_F : nullptr;
+            attn_q64_block<2>(a, smem, itp->b, itp->head, itp->q_first, itp->k_row0, itp->Sk, slab);
+            force_cold = true;
+        }
+        if (part) {
+            // publish: every storing wave drains its sc1 stores, the workgroup meets, ONE lane draws the ticket (attn_q64_persist_kernel)
+            volatile unsigned* last_flag = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF + 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(cnt + itp->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned last = ticket == (unsigned)itp->nparts - 1u;
+                if (last) __hip_atomic_store(cnt + itp->cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *last_flag = last;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool is_last = __builtin_amdgcn_readfirstlane((int)*last_flag) != 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (is_last) {
+                Q64Item mi; mi.b = itp->b; mi.head = itp->head; mi.q_first = itp->q_first; mi.kind = 2; mi.k_row0 = 0; mi.Sk = a.Sk; mi.slab0 = itp->slab0; mi.part = itp->part; mi.nparts = itp->nparts; mi.cnt = itp->cnt;
+                attn_q64_merge(a, mi, slabs);
+            }
+        }
+    }
+}
+
 }  // namespace
 #if Q64_TRACE
 extern "C" int ltx_dbg_q64_trace(unsigned long long* host, int n) {
@@ -863,7 +1002,6 @@ extern "C" int ltx_dbg_q64_trace(unsigned long long* host, int n) {
 }
 #endif
 
-#ifdef LTX_EXPERIMENTS
 // ---- host side of the persistent form: the static item lists ----------------------------------------------------------
 namespace {
 struct Q64Plan { Q64Item* items = nullptr; int* first = nullptr; int grid = 0, nslab = 0, ncnt = 0; };
@@ -879,8 +1017,10 @@ constexpr int Q64_PART_OVH = 8;          // what a part costs beyond its tiles, 
 // Cuts the blocks of the (batch, head) pairs `bh` over `ncu` workgroups.  Every workgroup's list: its parts first (the
 // merges then happen early, off the tail of the launch), then its whole blocks.
 void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int Sk, int ncu, std::vector<std::vector<Q64Item>>& lists,
-                        int& nslab, int& ncnt) {
-    const int nt = Sk / 64;
+                        int& nslab, int& ncnt, int unit = 1, int small_pct = Q64_SMALL_PCT, int part_ovh = Q64_PART_OVH) {
+    // unit: key tiles per scheduling step (the stream form cuts at even tiles: 2); costs are in steps
+    const int nt = Sk / (64 * unit);
+    const int min_part = Q64_MIN_PART / unit > 1 ? Q64_MIN_PART / unit : 1, ovh = part_ovh / unit;
     struct Blk { int b, head, q_first; };
     std::vector<Blk> bigs, smalls;
     const int nfull = Sq / 256, rest = Sq - nfull * 256;
@@ -890,7 +1030,7 @@ void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int 
         for (int i = 0; i < nfull + (rest > 128 ? 1 : 0); ++i) bigs.push_back({p.first, p.second, i * 256});
         if (rest > 0 && rest <= 128) smalls.push_back({p.first, p.second, nfull * 256});
     }
-    const int64_t big_cost = (int64_t)nt * 100, small_cost = (int64_t)nt * Q64_SMALL_PCT;
+    const int64_t big_cost = (int64_t)nt * 100, small_cost = (int64_t)nt * small_pct;
     const int64_t total = big_cost * (int64_t)bigs.size() + small_cost * (int64_t)smalls.size();
     const int64_t target = (total + ncu - 1) / ncu;
     std::vector<int64_t> load(ncu, 0);
@@ -919,8 +1059,8 @@ void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int 
     auto cover = [&](int64_t T, bool commit) {
         std::vector<std::pair<int, int>> caps;             // (cap tiles, cu), ascending
         for (int c = 0; c < ncu; ++c) {
-            int64_t cap = (T - load[c]) / 100 - Q64_PART_OVH;
-            if (cap >= nt) cap = nt; else if (cap < Q64_MIN_PART) continue;
+            int64_t cap = (T - load[c]) / 100 - ovh;
+            if (cap >= nt) cap = nt; else if (cap < min_part) continue;
             caps.push_back({(int)cap, c});
         }
         std::sort(caps.begin(), caps.end());
@@ -959,7 +1099,7 @@ void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int 
         return true;
     };
     if (ntape > 0) {
-        int64_t lo = target, hi = target + (int64_t)(2 * nt + Q64_PART_OVH) * 100;
+        int64_t lo = target, hi = target + (int64_t)(2 * nt + ovh) * 100;
         while (!cover(hi, false)) hi += (int64_t)nt * 100;                    // always ends: with cap = nt every block is one workgroup's
         while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (cover(mid, false)) hi = mid; else lo = mid + 1; }
         (void)cover(hi, true);
@@ -971,12 +1111,13 @@ void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int 
         const int slab0 = np > 1 ? nslab : 0, cn = np > 1 ? ncnt : 0;
         if (np > 1) { nslab += np; ++ncnt; }
         for (int p = 0; p < np; ++p)
-            lists[cuts[k][p].cu].push_back({bk.b, bk.head, bk.q_first, 2, cuts[k][p].t0 * 64, (cuts[k][p].t1 - cuts[k][p].t0) * 64, slab0, p, np, cn});
+            lists[cuts[k][p].cu].push_back({bk.b, bk.head, bk.q_first, 2, cuts[k][p].t0 * 64 * unit, (cuts[k][p].t1 - cuts[k][p].t0) * 64 * unit, slab0, p, np, cn});
     }
     for (int c = 0; c < ncu; ++c) for (const auto& w : whole[c]) lists[c].push_back(w);
 }
 }  // namespace
 
+#ifdef LTX_EXPERIMENTS
 // tuning / test aid: the schedule as text ("cu: kind head q_first k_row0 Sk part/nparts | ...")
 extern "C" int ltx_dbg_q64_schedule(int B, int heads, int Sq, int Sk, int n_cu, int xcd, char* out, int cap) {
     std::vector<std::vector<Q64Item>> all(n_cu);
@@ -1000,7 +1141,6 @@ extern "C" int ltx_dbg_q64_schedule(int B, int heads, int Sq, int Sk, int n_cu, 
     memcpy(out, t.c_str(), t.size() + 1);
     return 0;
 }
-
 #endif  // LTX_EXPERIMENTS
 
 static int q64_n_cu() {
@@ -1021,7 +1161,6 @@ bool ltx_attention_q64_fits(const AttnArgs& a) {
     return (double)a.Sk * a.ldk * 2.0 < lim && (double)a.Sk * a.ldv * 2.0 < lim && (double)a.Sq * a.ldq * 2.0 < lim && (double)a.Sq * a.ldo * 2.0 < lim;
 }
 
-#ifdef LTX_EXPERIMENTS
 static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
     int dev = 0; (void)hipGetDevice(&dev);
     const int xcd = (a.xcd_heads && n_cu % 8 == 0) ? 1 : 0;
@@ -1068,7 +1207,96 @@ static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
     return LTX_OK;
 }
 
-#endif  // LTX_EXPERIMENTS
+// ---- host side of the stream form: the persistent lists + everything the generated statement reads from an item record -------
+namespace {
+struct Q64SPlan { Q64SItem* items = nullptr; int* first = nullptr; int grid = 0, nslab = 0, ncnt = 0; };
+std::map<std::tuple<int, int, int, int, int, int, int, int, int, int>, Q64SPlan> g_q64s_plans;     // (device, B, heads, Sq, Sk, xcd order, ldq, ldk, ldv, ldo)
+constexpr int Q64S_SMALL_PCT = 62;       // a 128-query block against a 256-query one, cold start included (measured 0.59 + its prologue)
+constexpr int Q64S_PART_OVH = 6;         // key tiles a part costs beyond its own: the S^T(0) chain, the slab publish, its share of the merge
+}  // namespace
+
+bool ltx_attention_q64_stream_ok(const AttnArgs& a, int n_cu) {
+    if (!ltx_opt().attn_q64_stream || ltx_opt().attn_q64_big >= 0) return false;
+    if (a.Sk % 128 != 0 || a.Sq % 128 != 0 || a.Sk < 64 * 2 * Q64_MIN_PART || a.B * a.heads * ((a.Sq + 255) / 256) <= n_cu) return false;
+    const double lim = 2147483648.0 - 65536.0;               // whole-tensor descriptors, 32-bit scalar offsets
+    return (double)a.B * a.Sk * a.ldk * 2.0 < lim && (double)a.B * a.Sk * a.ldv * 2.0 < lim && (double)a.B * a.Sq * a.ldq * 2.0 < lim && (double)a.B * a.Sq * a.ldo * 2.0 < lim;
+}
+
+static int launch_q64_stream(const AttnArgs& a, int n_cu, hipStream_t s) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    const int xcd = (a.xcd_heads && n_cu % 8 == 0) ? 1 : 0;
+    Q64SPlan plan; Q64Ws ws;
+    {
+        std::lock_guard<std::mutex> lock(g_q64_mu);
+        const auto key = std::make_tuple(dev, a.B, a.heads, a.Sq, a.Sk, xcd, a.ldq, a.ldk, a.ldv, a.ldo);
+        auto it = g_q64s_plans.find(key);
+        if (it == g_q64s_plans.end()) {
+            std::vector<std::vector<Q64Item>> all(n_cu);
+            int nslab = 0, ncnt = 0;
+            const int G = xcd ? 8 : 1;
+            for (int x = 0; x < G; ++x) {
+                std::vector<std::pair<int, int>> bh;
+                for (int b = 0; b < a.B; ++b) for (int h = 0; h < a.heads; ++h) if (!xcd || (h & 7) == x) bh.push_back({b, h});
+                std::vector<std::vector<Q64Item>> lists;
+                q64_schedule_group(bh, a.Sq, a.Sk, n_cu / G, lists, nslab, ncnt, 2, Q64S_SMALL_PCT, Q64S_PART_OVH);
+                for (int c = 0; c < n_cu / G; ++c) all[c * G + x] = lists[c];      // blocks b and b + 8 share an XCD
+            }
+            std::vector<Q64SItem> flat; std::vector<int> first(n_cu + 1, 0);
+            for (int c = 0; c < n_cu; ++c) {
+                first[c] = (int)flat.size();
+                // order inside a list: parts (their merges then happen early), whole 256-query blocks, the 128-query block last (it runs cold)
+                std::vector<Q64Item> ord;
+                for (const auto& q : all[c]) if (q.kind == 2 && q.nparts > 1) ord.push_back(q);
+                for (const auto& q : all[c]) if (q.kind == 2 && q.nparts == 1) ord.push_back(q);
+                for (const auto& q : all[c]) if (q.kind == 1) ord.push_back(q);
+                uint32_t rot = 0;
+                for (size_t i = 0; i < ord.size(); ++i) {
+                    const Q64Item& q = ord[i];
+                    Q64SItem o; memset(&o, 0, sizeof(o));
+                    o.kind = q.kind == 1 ? 1 : (q.nparts > 1 ? 3 : 2);
+                    o.b = q.b; o.head = q.head; o.q_first = q.q_first; o.k_row0 = q.k_row0; o.Sk = q.Sk; o.slab0 = q.slab0; o.part = q.part; o.nparts = q.nparts; o.cnt = q.cnt;
+                    if (o.kind != 1) {
+                        const uint32_t nt = (uint32_t)q.Sk / 64u;
+                        if (nt < 6 || (nt & 1) || (q.k_row0 % 128) != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "attn_q64 stream: a schedule with an odd or too short key range");
+                        auto koff = [&](const Q64Item& t, int ld) { return (uint32_t)((((int64_t)t.b * a.Sk + t.k_row0) * ld + t.head * 64) * 2); };
+                        auto qoff = [&](const Q64Item& t, int ld) { return (uint32_t)((((int64_t)t.b * a.Sq + t.q_first) * ld + t.head * 64) * 2); };
+                        o.w[0] = koff(q, a.ldk); o.w[1] = koff(q, a.ldv); o.w[2] = qoff(q, a.ldq); o.w[3] = qoff(q, a.ldo);
+                        const bool has_next = i + 1 < ord.size() && ord[i + 1].kind != 1;
+                        o.w[4] = has_next ? koff(ord[i + 1], a.ldk) : 0x80000000u;
+                        o.w[5] = has_next ? koff(ord[i + 1], a.ldv) : 0x80000000u;
+                        o.w[6] = has_next ? qoff(ord[i + 1], a.ldq) : 0x80000000u;
+                        o.w[7] = nt - 4u; o.w[8] = rot; o.w[9] = (rot + nt) & 3u; o.w[10] = rot * 16384u;
+                        o.w[11] = i == 0 ? 1u : 0u;
+                        o.w[12] = (i > 0 && ord[i - 1].nparts > 1) ? 17u : 8u;
+                        rot = (rot + nt) & 3u;
+                    }
+                    flat.push_back(o);
+                }
+            }
+            first[n_cu] = (int)flat.size();
+            Q64SPlan np; np.grid = n_cu; np.nslab = nslab; np.ncnt = ncnt;
+            HIP_TRY(hipMalloc(&np.items, flat.size() * sizeof(Q64SItem) + 16));
+            HIP_TRY(hipMalloc(&np.first, first.size() * sizeof(int)));
+            HIP_TRY(hipMemcpy(np.items, flat.data(), flat.size() * sizeof(Q64SItem), hipMemcpyHostToDevice));      // once per shape (ltx_warmup)
+            HIP_TRY(hipMemcpy(np.first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+            it = g_q64s_plans.emplace(key, np).first;
+        }
+        plan = it->second;
+        Q64Ws& w = g_q64_ws[std::make_pair(dev, s)];
+        const size_t need_f = (size_t)(plan.nslab > 0 ? plan.nslab : 1) * SLAB_F, need_c = (size_t)(plan.ncnt > 0 ? plan.ncnt : 1);
+        if (w.slab_f < need_f) { if (w.slabs) (void)hipFree(w.slabs); w.slabs = nullptr; HIP_TRY(hipMalloc(&w.slabs, need_f * sizeof(float))); w.slab_f = need_f; }
+        if (w.ncnt < need_c) {
+            const size_t n = need_c < 1024 ? 1024 : need_c;
+            if (w.cnt) (void)hipFree(w.cnt);
+            w.cnt = nullptr; HIP_TRY(hipMalloc(&w.cnt, n * sizeof(unsigned))); w.ncnt = n;
+            HIP_TRY(hipMemsetAsync(w.cnt, 0, n * sizeof(unsigned), s));      // once: every merger hands its counter back at zero
+        }
+        ws = w;
+    }
+    LTX_LAUNCH_TIMED(attn_q64_stream_kernel, dim3((unsigned)plan.grid), dim3(256), 0, s, a, plan.items, plan.first, ws.slabs, ws.cnt);
+    LTX_CHECK_LAUNCH();
+    return LTX_OK;
+}
 
 // Split of a head's queries into big (256) and small (128) blocks: as many big blocks as fill whole rounds of the
 // chip's CUs (one block per CU), the rest as small blocks that run in about half a big block's time, so the last
@@ -1076,6 +1304,7 @@ static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
     const int n_cu = q64_n_cu();
     const int heads_total = a.heads * a.B;
+    if (ltx_attention_q64_stream_ok(a, n_cu)) return launch_q64_stream(a, n_cu, s);      // option attn_q64_stream=0: the block grid below
     {
         // persistent form (LTX_ATTN_Q64_PERSIST=1; key counts in whole tiles, more work than one round of blocks).  Measured
         // on MI355X at S = 4992, 32 heads: 183 us against 178 us for the block grid below - a 128-query block costs 0.59 of a

@@ -37,11 +37,14 @@ VBASE = 64 * KROW
 DEFAULTS = dict(align=1, phase=0, abl="", cvt_lag=1, v_early=1, stamp=0, split_wait=0, v_gaps="", k_gaps="", dma_gaps="", row_gaps="", v_gaps1="", k_gaps1="", dma_gaps1="", row_gaps1="")
 
 
-def gen(QB, opt=None, full=False, part=False):
+def gen(QB, opt=None, full=False, part=False, stream=False):
     o_ = dict(DEFAULTS); o_.update(opt or {})
     abl = set(x for x in str(o_["abl"]).split("+") if x)
     lag = int(o_["cvt_lag"])
     L = []
+    # stream flavour (round 6): every scalar lives in a NAMED SGPR - s[64:79] the item record (host-built, attn_q64.hip Q64StreamItem),
+    # s[80:87] scratch - so that the statement stays under the 30-operand limit of inline asm
+    KOFF, VOFF, CNT = ("s80", "s81", "s82") if stream else ("%[koff]", "%[voff]", "%[cnt]")
     def emit(ins):
         op = ins.split()[0]
         if "nodma" in abl and (op.startswith("buffer_load") or ins.startswith("s_add_u32 m0")): return
@@ -157,8 +160,8 @@ def gen(QB, opt=None, full=False, part=False):
                 if dg != gp: continue
                 imm = slot * TILE + (VBASE if p >= 2 else 0) + (p & 1) * 1024
                 pre.append(f"s_add_u32 m0, %[ldsw], {imm}")   # M0 written >= 2 instructions ahead of the load
-                if p < 2: fill.append(f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], %[koff] offen lds")
-                else: fill.append(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], %[voff] offen lds")
+                if p < 2: fill.append(f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], {KOFF} offen lds")
+                else: fill.append(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], {VOFF} offen lds")
             for ri, rg in enumerate(r_gaps):                  # row-sum MFMA ri: query block ri / 4, operand (kb, s) = ri % 4
                 if rg != gp: continue
                 rq, ro = ri // 4, ri % 4
@@ -167,8 +170,8 @@ def gen(QB, opt=None, full=False, part=False):
             emit(main)
             for ins in pre: emit(ins)
             exp_slice(sb, pb, i, fill)
-        emit("s_add_u32 %[koff], %[koff], %[kstep]")
-        emit("s_add_u32 %[voff], %[voff], %[vstep]")
+        emit(f"s_add_u32 {KOFF}, {KOFF}, %[kstep]")
+        emit(f"s_add_u32 {VOFF}, {VOFF}, %[vstep]")
         if pending[0]:                                        # cvt_lag: the body's last pair (two SALU since its exps)
             emit("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % pending[0]); pending[0] = None
         emit("s_waitcnt lgkmcnt(0)")
@@ -243,6 +246,109 @@ def gen(QB, opt=None, full=False, part=False):
             emit(f"v_cvt_pk_bf16_f32 v{P(0, 0, 0, i >> 2) + (i & 3)}, v{t0}, v{t1}")
         tmp[0] = 0
 
+    def prologue_stream():
+        """stream flavour (QB = 2): one item of a persistent workgroup's list.  Item record s[64:79]:
+          s64 K offset of the item's first key tile   s65 V offset   s66 Q offset of the item's first query row   s67 O offset (or slab: unused)
+          s68 next item's K offset   s69 its V offset   s70 its Q offset   (0x80000000 = none: out of range, zeros, no traffic)
+          s71 key tiles - 4   s72 ring slot of tile 0 (0 | 2)   s73 ring slot of the tile after the last (0 | 2)   s74 s72 * 16384
+          s75 cold (1: nothing of this item was requested yet)   s76 vector-memory stores the previous item's epilogue issued (8 | 17)
+          s[76:79] part flavour: words 1 .. 3 are unused here (the slab descriptor is an operand)
+        A WARM item finds Q^T in the wave's 8-KiB staging area (K-tile image: the fragment reads are K reads at another base) and its
+        first four tiles requested - by the previous item's last four loop iterations, into the ring slots those freed - so the block
+        start costs the S^T(0) chain, not a cold 96-KiB burst (5.5 us per block)."""
+        assert QB == 2
+        emit("s_mov_b32 s80, s64"); emit("s_mov_b32 s81, s65")
+        emit("s_cmp_eq_u32 s75, 0")
+        emit("s_cbranch_scc1 5f")
+        # ---- cold: Q^T pieces (8 per wave: 8 rows x 128 B each) and the first four tiles, as the full flavour issues them
+        emit("s_mov_b32 s83, s66")
+        for j in range(8):
+            emit(f"s_add_u32 m0, %[ldsq], {j * 1024}")
+            emit("s_nop 0")
+            emit(f"buffer_load_dwordx4 v{218 + (j & 1)}, %[rq], s83 offen lds")
+            emit("s_add_u32 s83, s83, %[qstep8]")
+        for tl in range(4):
+            emit(f"s_add_u32 s84, s72, {tl}"); emit("s_and_b32 s84, s84, 3"); emit("s_lshl_b32 s84, s84, 14"); emit("s_add_u32 s84, s84, %[ldsw]")
+            for p in range(4):
+                imm = (VBASE if p >= 2 else 0) + (p & 1) * 1024
+                emit(f"s_add_u32 m0, s84, {imm}")
+                emit("s_nop 0")
+                if p < 2: emit(f"buffer_load_dwordx4 v{214 + (p & 1)}, %[rk], s80 offen lds")
+                else: emit(f"buffer_load_dwordx4 v{216 + (p & 1)}, %[rv], s81 offen lds")
+            emit("s_add_u32 s80, s80, %[kstep]"); emit("s_add_u32 s81, s81, %[vstep]")
+        for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
+        for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
+        emit("s_waitcnt vmcnt(8)")                          # Q^T and tiles 0, 1 landed; 2, 3 stay in flight
+        emit("s_branch 6f")
+        # ---- warm: everything was requested by the previous item; its epilogue's stores are the only younger operations
+        emit("5:")
+        emit("s_lshl_b32 s83, %[kstep], 2"); emit("s_add_u32 s80, s80, s83")
+        emit("s_lshl_b32 s83, %[vstep], 2"); emit("s_add_u32 s81, s81, s83")
+        for i in range(32 * QB): emit(f"v_accvgpr_write_b32 a{i}, 0")
+        for i in range(4 * QB): emit(f"v_mov_b32_e32 v{192 + i}, 0")
+        emit("s_cmp_eq_u32 s76, 8")
+        emit("s_cbranch_scc1 7f")
+        emit("s_waitcnt vmcnt(17)")
+        emit("s_branch 6f")
+        emit("7:")
+        emit("s_waitcnt vmcnt(8)")
+        emit("6:")
+        emit("s_barrier")
+        # Q^T fragments from the staging area, K(0) fragments from ring slot s72
+        for qb in range(QB):
+            for ks in range(4):
+                emit(f"ds_read_b128 {ar(Q(qb, ks), 4)}, v{224 + ks} offset:{qb * 32 * KROW}")
+        for ks in range(4): emit(f"v_add_u32_e32 v{200 + ks}, s74, v{208 + ks}")
+        for i in range(8):
+            emit(f"ds_read_b128 {ar(KF(i), 4)}, v{200 + (i & 3)} offset:{(i >> 2) * 32 * KROW}")
+        emit("s_waitcnt lgkmcnt(0)")
+        for qb in range(QB):
+            for i in range(8):
+                kb, ks = i >> 2, i & 3
+                d = vr(S(0, qb, kb), 16)
+                emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF(i), 4)}, {ar(Q(qb, ks), 4)}, {'0' if ks == 0 else d}")
+        for i in range(8):                                   # K(1) fragments: slot s72 + 1 (s72 is 0 or 2: no wrap)
+            emit(f"ds_read_b128 {ar(KF(i), 4)}, v{200 + (i & 3)} offset:{TILE + (i >> 2) * 32 * KROW}")
+        for qb in range(QB):
+            s0 = S(0, qb, 0); m = 204 + qb                   # (v200 .. v203 hold the read bases until the reads above have issued)
+            emit(f"v_max3_f32 v{m}, v{s0}, v{s0 + 1}, v{s0 + 2}")
+            for i in range(3, 31, 2): emit(f"v_max3_f32 v{m}, v{m}, v{s0 + i}, v{s0 + i + 1}")
+            emit(f"v_max_f32_e32 v{m}, v{m}, v{s0 + 31}")
+            emit(f"v_mov_b32_e32 v{206 + qb}, v{m}")
+        emit("s_nop 1")
+        for qb in range(QB): emit(f"v_permlane32_swap_b32_e32 v{204 + qb}, v{206 + qb}")
+        for qb in range(QB): emit(f"v_max_f32_e32 v{204 + qb}, v{204 + qb}, v{206 + qb}")
+        for qb in range(QB):
+            for i in range(16): emit(f"v_xor_b32_e32 v{MINIT(qb) + i}, 0x80000000, v{204 + qb}")
+            for i in range(32): emit(f"v_sub_f32_e32 v{S(0, qb, 0) + i}, v{S(0, qb, 0) + i}, v{204 + qb}")
+        emit("s_waitcnt lgkmcnt(0)")
+        for i in range(8):                                   # first exp slice: (tile 0, q0, k0)
+            t0, t1 = temps()
+            emit(f"v_exp_f32_e32 v{t0}, v{S(0, 0, 0) + 2 * i}")
+            emit(f"v_exp_f32_e32 v{t1}, v{S(0, 0, 0) + 2 * i + 1}")
+            emit("s_nop 0")
+            emit(f"v_cvt_pk_bf16_f32 v{P(0, 0, 0, i >> 2) + (i & 3)}, v{t0}, v{t1}")
+        tmp[0] = 0
+        # loop control: phase A = the item's tiles but the last four (the loads issued are its own), phase B = the last four
+        # (the loads issued are the NEXT item's first four tiles, into the slots these iterations free)
+        emit("s_mov_b32 s82, s71")
+        emit("s_mov_b32 s85, 0")                             # phase
+        emit("s_mov_b32 s86, s72")                           # entry body
+        emit("8:")
+        emit("s_cmp_eq_u32 s86, 0")
+        emit("s_cbranch_scc1 1f")
+        emit("s_branch 3f")
+
+    def next_q_stream():
+        """stream flavour: the next item's Q^T into the staging area (this item's fragments left it in the prologue), issued where the
+        loop ends: the epilogue and the next prologue's zeroing run under its flight"""
+        emit("s_mov_b32 s83, s70")
+        for j in range(8):
+            emit(f"s_add_u32 m0, %[ldsq], {j * 1024}")
+            emit("s_nop 0")
+            emit(f"buffer_load_dwordx4 v{218 + (j & 1)}, %[rq], s83 offen lds")
+            emit("s_add_u32 s83, s83, %[qstep8]")
+
     def epilogue():
         """full flavour: O^T / l -> bf16 rows, 16-byte stores (lanes l, l^32 exchange column groups, attention.hip store_o_wide)"""
         emit("v_cmp_ne_u32_e32 vcc, 0, v222")
@@ -260,7 +366,7 @@ def gen(QB, opt=None, full=False, part=False):
                     emit("s_nop 1")
                     emit(f"v_permlane32_swap_b32_e32 v{base + 8}, v{base + 10}")
                     emit(f"v_permlane32_swap_b32_e32 v{base + 9}, v{base + 11}")
-                    emit(f"buffer_store_dwordx4 {vr(base + 8, 4)}, v{220 + qb}, %[ro], 0 offen offset:{d * 64 + 32 * k}")
+                    emit(f"buffer_store_dwordx4 {vr(base + 8, 4)}, v{220 + qb}, %[ro], {'s67' if stream else '0'} offen offset:{d * 64 + 32 * k}")
 
     def epilogue_part():
         """part flavour (a key range of a split block, attn_q64.hip): the un-normalised O^T, the row sums and -m leave
@@ -274,14 +380,16 @@ def gen(QB, opt=None, full=False, part=False):
         ng = 8 * QB
         for g in range(ng + 1):
             if g % 4 == 0:
-                emit(f"s_mov_b32 %[koff], {(g // 4) * 4096}")
+                emit(f"s_mov_b32 {KOFF}, {(g // 4) * 4096}")
                 emit("s_nop 0")
             src = ar(4 * g, 4) if g < ng else vr(200, 4)
             off = f" offset:{(g % 4) * 1024}" if g % 4 else ""
-            emit(f"buffer_store_dwordx4 {src}, v220, %[ro], %[koff] offen{off} sc1")
+            emit(f"buffer_store_dwordx4 {src}, v220, %[ro], {KOFF} offen{off} sc1")
 
     emit("s_nop 15")                                        # operands set up by compiler-scheduled VALU / accvgpr writes
-    if full:
+    if stream:
+        prologue_stream()
+    elif full:
         stamp("sp0", "sq0")
         prologue()
     stamp("st0", "sr0")
@@ -294,17 +402,28 @@ def gen(QB, opt=None, full=False, part=False):
             emit(".p2align 6" if it == 0 else ".p2align 3")
             if int(o_["phase"]): emit("s_nop 0")
         if it == 0: emit("1:")
+        if it == 2 and stream: emit("3:")
         body(it, it & 1)
-        emit("s_add_i32 %[cnt], %[cnt], -1")
-        emit("s_cmp_eq_u32 %[cnt], 0")
+        emit(f"s_add_i32 {CNT}, {CNT}, -1")
+        emit(f"s_cmp_eq_u32 {CNT}, 0")
         if it < 3: emit("s_cbranch_scc1 2f")
         else: emit("s_cbranch_scc0 1b")
     emit("2:")
     stamp("st1", "sr1")
-    emit("s_waitcnt vmcnt(0)")
+    if stream:
+        emit("s_cmp_eq_u32 s85, 1")
+        emit("s_cbranch_scc1 9f")
+        emit("s_mov_b32 s85, 1")
+        emit("s_mov_b32 s80, s68"); emit("s_mov_b32 s81, s69")
+        emit("s_mov_b32 s82, 4"); emit("s_mov_b32 s86, s73")
+        emit("s_branch 8b")
+        emit("9:")
+        next_q_stream()                                     # (no drain: the next item's tiles and Q^T stay in flight across the epilogue)
+    else:
+        emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")
     emit("s_nop 15")
-    if full:
+    if full or stream:
         if part: epilogue_part()
         else: epilogue()
         stamp("sp1", "sq1")
@@ -366,6 +485,25 @@ __device__ __forceinline__ void q64_{"part" if part else "full"}_qb{QB}({ltype}&
 """
 
 
+def c_function_stream(opt=None, part=False):
+    """one item of a persistent workgroup (QB = 2): item record in s[64:79], lane vectors in v[208:227] (see prologue_stream)"""
+    lines = gen(2, opt, full=False, part=part, stream=True)
+    text = "".join(f'        "{ins}\\n\\t"\n' for ins in lines)
+    used_v = [i for i in range(0, 192)] + [i for i in range(200, 208)]
+    clob = [f'"v{i}"' for i in used_v] + [f'"a{i}"' for i in range(0, 160)] + [f'"s{i}"' for i in range(80, 88)] + ['"vcc"', '"scc"', '"memory"']
+    name = "q64_stream_part_qb2" if part else "q64_stream_qb2"
+    return f"""// GENERATED by tools/gen_attn_q64_asm.py - do not edit.  {len(lines)} instructions, QB = 2, stream flavour: warm / cold prologue + two-phase loop + next item's Q^T request + {"slab-publishing epilogue (key-range part of a split block)" if part else "epilogue"}.
+__device__ __forceinline__ void {name}(f32x8& lacc, const u32x4& ones, const u32x16& lanes, const u32x4& qbase, const u32x16& item,
+        const u32x4& rk, const u32x4& rv, const u32x4& rq, const u32x4& ro, uint32_t kstep, uint32_t vstep, uint32_t ldsw, uint32_t ldsq, uint32_t qstep8) {{
+    asm volatile(
+{text}        : "={{v[192:199]}}"(lacc)
+        : "{{a[160:163]}}"(ones), "{{v[208:223]}}"(lanes), "{{v[224:227]}}"(qbase), "{{s[64:79]}}"(item),
+          [rk] "s"(rk), [rv] "s"(rv), [rq] "s"(rq), [ro] "s"(ro), [kstep] "s"(kstep), [vstep] "s"(vstep), [ldsw] "s"(ldsw), [ldsq] "s"(ldsq), [qstep8] "s"(qstep8)
+        : {", ".join(clob)});
+}}
+"""
+
+
 def main():
     """usage: gen_attn_q64_asm.py [--out FILE] [key=value ...]   (keys: see DEFAULTS; the shipped file uses the defaults)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -387,6 +525,10 @@ def main():
         f.write(c_function_full(1, opt))
         f.write("\n")
         f.write(c_function_full(2, opt, part=True))
+        f.write("\n")
+        f.write(c_function_stream(opt))
+        f.write("\n")
+        f.write(c_function_stream(opt, part=True))
     print("wrote", out, opt)
 
 
