@@ -811,6 +811,9 @@ __device__ __forceinline__ void attn_q64_merge(const AttnArgs& a, const Q64Item&
 #endif
 #if Q64_TRACE
 __device__ unsigned long long q64_trace[512 * 8 * 4];   // [workgroup][item][start, block done, published, merged] in 10 ns ticks
+#ifndef Q64_TR_MASK
+#define Q64_TR_MASK 15
+#endif
 #define Q64_TR(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && i - i0 < 8) q64_trace[(blockIdx.x * 8 + (i - i0)) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define Q64_TR(slot) do { } while (0)
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
     volatile unsigned* flagw = reinterpret_cast<volatile unsigned*>(smem + FLAG_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, lr = lane >> 3, pc = lane & 7;
-    const int i0 = first[blockIdx.x], i1 = first[blockIdx.x + 1];
+    const int i0 = __builtin_amdgcn_readfirstlane(first[blockIdx.x]), i1 = __builtin_amdgcn_readfirstlane(first[blockIdx.x + 1]);
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // whole-tensor descriptors: every item offset (batch, head, first row) rides in the scalar offset of the loads / stores
     auto desc = [&](const void* p, uint32_t bytes) {
@@ -888,14 +891,31 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
     const uint32_t qstep8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)a.ldq * 2u));
     const uint32_t ldsw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * (PW * 1024)));
     const uint32_t ldsq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)QS_OFF + (uint32_t)wave * 8192u));
+    int n_item = -1;
+    auto tr = [&](int slot) {                               // diagnostic builds (-DQ64_TRACE=1): 10-ns stamps per item
+#if Q64_TRACE
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (((Q64_TR_MASK >> slot) & 1) && tid == 0 && blockIdx.x < 512 && n_item < 8) q64_trace[(blockIdx.x * 8 + n_item) * 4 + slot] = t;
+#else
+        (void)slot;
+#endif
+    };
     bool force_cold = false;                               // block-uniform: the item before this one ran the exact pass (the ring was re-used)
     for (int i = i0; i < i1; ++i) {
-        const Q64SItem* itp = items + i;
-        if (itp->kind == 1) {                               // 128-query block: the self-contained QB = 1 form (last in a list: nothing was requested ahead)
+        const Q64SItem* itp = items + __builtin_amdgcn_readfirstlane(i);
+        const int kind = __builtin_amdgcn_readfirstlane(itp->kind);
+        n_item = __builtin_amdgcn_readfirstlane(n_item + 1);
+        tr(0);
+#if Q64_TRACE
+        if (((Q64_TR_MASK >> 4) & 1) && tid == 0 && blockIdx.x < 512 && n_item < 8)        // what the item is: kind, key tiles, part / parts
+            q64_trace[(blockIdx.x * 8 + n_item) * 4 + 3] = ((unsigned long long)kind << 48) | ((unsigned long long)(itp->Sk / 64) << 32) | ((unsigned long long)itp->part << 16) | (unsigned long long)itp->nparts;
+#endif
+        if (kind == 1) {                               // 128-query block: the self-contained QB = 1 form (last in a list: nothing was requested ahead)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             attn_q64_block<1>(a, smem, itp->b, itp->head, itp->q_first, 0, a.Sk, nullptr);
             force_cold = true;
+            tr(1);
             continue;
         }
         // lane vectors (re-derived per item: as loop invariants they would be spilled across the statement, and a spill's reload
@@ -938,10 +958,11 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
         if (force_cold) { item[11] = 1u; force_cold = false; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) item[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)item[e]);
-        const bool part = itp->kind == 3;
+        const bool part = kind == 3;
+        const int slab_i = __builtin_amdgcn_readfirstlane(itp->slab0 + itp->part);
         f32x8 la;
         if (part) {
-            float* slab = slabs + (int64_t)(itp->slab0 + itp->part) * SLAB_F;
+            float* slab = slabs + (int64_t)slab_i * SLAB_F;
             const uint64_t sp = (uint64_t)(uintptr_t)(slab + wave * SLAB_WAVE_F);
             const u32x4 ro_slab = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32)) & 0xffffu,
                                    (uint32_t)(SLAB_WAVE_F * 4), 0x00020000u};
@@ -952,6 +973,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
             lanes[13] = (uint32_t)(wave * 64 + 32 + r) * (uint32_t)a.ldo * 2u + 16u * h;
             q64_stream_qb2(la, ones_u, lanes, qbase, item, rk, rv, rq, ro_full, kstep, vstep, ldsw, ldsq, qstep8);
         }
+        tr(1);
         const float l0 = (lane & 16) ? la[1] : la[0], l1 = (lane & 16) ? la[5] : la[4];
         const bool bad = !(l0 < 0x1p100f) || !(l1 < 0x1p100f);
         // block-uniform OR through one LDS word, with bare barriers: __syncthreads() carries a fence that would drain vmcnt
@@ -967,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
         if (!Q64_NO_FALLBACK && any_bad) {                 // overflow of the fixed max: the self-contained form with its exact second pass
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            float* slab = part ? slabs + (int64_t)(itp->slab0 + itp->part) * SLAB_F : nullptr;
+            float* slab = part ? slabs + (int64_t)slab_i * SLAB_F : nullptr;
             attn_q64_block<2>(a, smem, itp->b, itp->head, itp->q_first, itp->k_row0, itp->Sk, slab);
             force_cold = true;
         }
@@ -987,9 +1009,14 @@ __global__ __launch_bounds__(256, 1) void attn_q64_stream_kernel(const AttnArgs 
             const bool is_last = __builtin_amdgcn_readfirstlane((int)*last_flag) != 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            tr(2);
             if (is_last) {
                 Q64Item mi; mi.b = itp->b; mi.head = itp->head; mi.q_first = itp->q_first; mi.kind = 2; mi.k_row0 = 0; mi.Sk = a.Sk; mi.slab0 = itp->slab0; mi.part = itp->part; mi.nparts = itp->nparts; mi.cnt = itp->cnt;
                 attn_q64_merge(a, mi, slabs);
+#if Q64_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                tr(3);
             }
         }
     }
@@ -1017,8 +1044,9 @@ constexpr int Q64_PART_OVH = 8;          // what a part costs beyond its tiles, 
 // Cuts the blocks of the (batch, head) pairs `bh` over `ncu` workgroups.  Every workgroup's list: its parts first (the
 // merges then happen early, off the tail of the launch), then its whole blocks.
 void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int Sk, int ncu, std::vector<std::vector<Q64Item>>& lists,
-                        int& nslab, int& ncnt, int unit = 1, int small_pct = Q64_SMALL_PCT, int part_ovh = Q64_PART_OVH) {
-    // unit: key tiles per scheduling step (the stream form cuts at even tiles: 2); costs are in steps
+                        int& nslab, int& ncnt, int unit = 1, int small_pct = Q64_SMALL_PCT, int part_ovh = Q64_PART_OVH, int part_step_pct = 100) {
+    // unit: key tiles per scheduling step (the stream form cuts at even tiles: 2); costs are in steps (a whole block's step = 100).
+    // A part of s steps costs s * part_step_pct + ovh * 100 (the stream form: measured, tools/attn_stream_trace.py)
     const int nt = Sk / (64 * unit);
     const int min_part = Q64_MIN_PART / unit > 1 ? Q64_MIN_PART / unit : 1, ovh = part_ovh / unit;
     struct Blk { int b, head, q_first; };
@@ -1059,7 +1087,7 @@ void q64_schedule_group(const std::vector<std::pair<int, int>>& bh, int Sq, int 
     auto cover = [&](int64_t T, bool commit) {
         std::vector<std::pair<int, int>> caps;             // (cap tiles, cu), ascending
         for (int c = 0; c < ncu; ++c) {
-            int64_t cap = (T - load[c]) / 100 - ovh;
+            int64_t cap = (T - load[c] - (int64_t)ovh * 100) / part_step_pct;
             if (cap >= nt) cap = nt; else if (cap < min_part) continue;
             caps.push_back({(int)cap, c});
         }
@@ -1211,8 +1239,86 @@ static int launch_q64_persist(const AttnArgs& a, int n_cu, hipStream_t s) {
 namespace {
 struct Q64SPlan { Q64SItem* items = nullptr; int* first = nullptr; int grid = 0, nslab = 0, ncnt = 0; };
 std::map<std::tuple<int, int, int, int, int, int, int, int, int, int>, Q64SPlan> g_q64s_plans;     // (device, B, heads, Sq, Sk, xcd order, ldq, ldk, ldv, ldo)
-constexpr int Q64S_SMALL_PCT = 62;       // a 128-query block against a 256-query one, cold start included (measured 0.59 + its prologue)
-constexpr int Q64S_PART_OVH = 6;         // key tiles a part costs beyond its own: the S^T(0) chain, the slab publish, its share of the merge
+}  // namespace
+
+namespace {
+// Stream schedule of the (batch, head) pairs `bh` over `ncu` workgroups (one XCD's share).  Whole 256-query blocks are dealt while they
+// fit under the finish time; the rest lie on a TAPE of key tiles (block after block) that is cut once per workgroup - a workgroup's
+// stretch may cross ONE block boundary, it then runs two parts - so every workgroup ends at the same time up to a two-tile step (the
+// one-part-per-workgroup rule of the persistent form left a 26-us spread: profiles/r6_attn_stream_trace.json).  Times in microseconds
+// from in-kernel stamps (tools/attn_stream_trace.py).  Lists: parts (tape order), whole blocks, the 128-query block.
+void q64_stream_schedule(const std::vector<std::pair<int, int>>& bh, int Sq, int Sk, int ncu, std::vector<std::vector<Q64Item>>& lists, int& nslab, int& ncnt) {
+    const int nt = Sk / 64;                                  // even (ltx_attention_q64_stream_ok)
+    const double whole_us = 0.806 * nt + 2.6, small_us = 0.617 * nt, part_tile_us = 0.68, part1_us = 17.0, part2_us = 10.0;
+    const int min_part = 8;
+    struct Blk { int b, head, q_first; };
+    std::vector<Blk> bigs, smalls;
+    const int nfull = Sq / 256, rest = Sq - nfull * 256;
+    for (const auto& p : bh) {
+        for (int i = 0; i < nfull; ++i) bigs.push_back({p.first, p.second, i * 256});
+        if (rest > 0) smalls.push_back({p.first, p.second, nfull * 256});          // rest == 128 (stream_ok)
+    }
+    lists.assign(ncu, {});
+    std::vector<int> nsmall(ncu, 0);
+    for (size_t i = 0; i < smalls.size(); ++i) ++nsmall[ncu - 1 - (int)(i % ncu)];
+    const double total_us = whole_us * bigs.size() + small_us * smalls.size();
+    // whole blocks per workgroup: as many as leave at least a minimal part's room under the even share
+    const double share = total_us / ncu;
+    std::vector<int> nwhole(ncu, 0);
+    size_t used = 0;
+    for (bool any = true; any;) {
+        any = false;
+        for (int c = 0; c < ncu && used < bigs.size(); ++c)
+            if (nsmall[c] * small_us + (nwhole[c] + 1) * whole_us <= share) { ++nwhole[c]; ++used; any = true; }
+    }
+    const int ntape = (int)(bigs.size() - used);
+    const int64_t tape_tiles = (int64_t)ntape * nt;
+    struct Seg { int cu, blk, t0, t1; };
+    std::vector<Seg> segs;
+    auto cut = [&](double T, bool commit) {
+        int64_t pos = 0;                                       // tape position in tiles
+        if (commit) segs.clear();
+        for (int c = 0; c < ncu && pos < tape_tiles; ++c) {
+            double room = T - nsmall[c] * small_us - nwhole[c] * whole_us - part1_us;
+            int cap = (int)(room / part_tile_us); cap &= ~1;
+            if (cap < min_part) continue;
+            const int in_blk = (int)(pos % nt), left = nt - in_blk;         // tiles left of the block the tape stands in
+            int take1 = cap < left ? cap : left;
+            if (left - take1 > 0 && left - take1 < min_part) take1 = left;  // never leave a sliver of a block: this workgroup runs a little over
+            if (commit) segs.push_back({c, (int)(pos / nt), in_blk, in_blk + take1});
+            pos += take1;
+            int cap2 = ((int)((room - take1 * part_tile_us - part2_us) / part_tile_us)) & ~1;
+            if (take1 == left && cap2 >= min_part && pos < tape_tiles) {    // room for a stretch of the next block
+                int take2 = cap2 < nt ? cap2 : nt;
+                if (nt - take2 > 0 && nt - take2 < min_part) take2 = nt - min_part;
+                if (take2 >= min_part) { if (commit) segs.push_back({c, (int)(pos / nt), 0, take2}); pos += take2; }
+            }
+        }
+        return pos >= tape_tiles;
+    };
+    if (ntape > 0) {
+        double lo = share, hi = share + 2.0 * whole_us;
+        while (!cut(hi, false)) hi += whole_us;
+        for (int it = 0; it < 40; ++it) { const double mid = 0.5 * (lo + hi); if (cut(mid, false)) hi = mid; else lo = mid; }
+        (void)cut(hi, true);
+    }
+    // parts of a tape block: slab / counter indices
+    std::vector<int> nparts(ntape, 0), slab0(ntape, 0), cnt0(ntape, 0);
+    for (const auto& sg : segs) ++nparts[sg.blk];
+    for (int k = 0; k < ntape; ++k) if (nparts[k] > 1) { slab0[k] = nslab; nslab += nparts[k]; cnt0[k] = ncnt++; }
+    std::vector<int> seen(ntape, 0);
+    for (const auto& sg : segs) {
+        const Blk& bk = bigs[used + sg.blk];
+        lists[sg.cu].push_back({bk.b, bk.head, bk.q_first, 2, sg.t0 * 64, (sg.t1 - sg.t0) * 64, slab0[sg.blk], seen[sg.blk]++, nparts[sg.blk], cnt0[sg.blk]});
+    }
+    size_t nb = 0;
+    for (int round = 0; nb < used; ++round)
+        for (int c = 0; c < ncu && nb < used; ++c)
+            if (round < nwhole[c]) { lists[c].push_back({bigs[nb].b, bigs[nb].head, bigs[nb].q_first, 2, 0, Sk, 0, 0, 1, 0}); ++nb; }
+    size_t ns = 0;
+    for (int c = ncu - 1; c >= 0 && ns < smalls.size(); --c)
+        for (int j = 0; j < nsmall[c]; ++j, ++ns) lists[c].push_back({smalls[ns].b, smalls[ns].head, smalls[ns].q_first, 1, 0, Sk, 0, 0, 1, 0});
+}
 }  // namespace
 
 bool ltx_attention_q64_stream_ok(const AttnArgs& a, int n_cu) {
@@ -1238,7 +1344,7 @@ static int launch_q64_stream(const AttnArgs& a, int n_cu, hipStream_t s) {
                 std::vector<std::pair<int, int>> bh;
                 for (int b = 0; b < a.B; ++b) for (int h = 0; h < a.heads; ++h) if (!xcd || (h & 7) == x) bh.push_back({b, h});
                 std::vector<std::vector<Q64Item>> lists;
-                q64_schedule_group(bh, a.Sq, a.Sk, n_cu / G, lists, nslab, ncnt, 2, Q64S_SMALL_PCT, Q64S_PART_OVH);
+                q64_stream_schedule(bh, a.Sq, a.Sk, n_cu / G, lists, nslab, ncnt);
                 for (int c = 0; c < n_cu / G; ++c) all[c * G + x] = lists[c];      // blocks b and b + 8 share an XCD
             }
             std::vector<Q64SItem> flat; std::vector<int> first(n_cu + 1, 0);
@@ -1257,7 +1363,7 @@ static int launch_q64_stream(const AttnArgs& a, int n_cu, hipStream_t s) {
                     o.b = q.b; o.head = q.head; o.q_first = q.q_first; o.k_row0 = q.k_row0; o.Sk = q.Sk; o.slab0 = q.slab0; o.part = q.part; o.nparts = q.nparts; o.cnt = q.cnt;
                     if (o.kind != 1) {
                         const uint32_t nt = (uint32_t)q.Sk / 64u;
-                        if (nt < 6 || (nt & 1) || (q.k_row0 % 128) != 0) LTX_FAIL(LTX_ERR_UNSUPPORTED, "attn_q64 stream: a schedule with an odd or too short key range");
+                        if (nt < 6 || (nt & 1) || (q.k_row0 % 128) != 0 || q.nparts > 8) return -2;      // (not a schedule the stream statement runs: the block grid serves)
                         auto koff = [&](const Q64Item& t, int ld) { return (uint32_t)((((int64_t)t.b * a.Sk + t.k_row0) * ld + t.head * 64) * 2); };
                         auto qoff = [&](const Q64Item& t, int ld) { return (uint32_t)((((int64_t)t.b * a.Sq + t.q_first) * ld + t.head * 64) * 2); };
                         o.w[0] = koff(q, a.ldk); o.w[1] = koff(q, a.ldv); o.w[2] = qoff(q, a.ldq); o.w[3] = qoff(q, a.ldo);
@@ -1304,7 +1410,10 @@ static int launch_q64_stream(const AttnArgs& a, int n_cu, hipStream_t s) {
 int ltx_launch_attention_q64(const AttnArgs& a, hipStream_t s) {
     const int n_cu = q64_n_cu();
     const int heads_total = a.heads * a.B;
-    if (ltx_attention_q64_stream_ok(a, n_cu)) return launch_q64_stream(a, n_cu, s);      // option attn_q64_stream=0: the block grid below
+    if (ltx_attention_q64_stream_ok(a, n_cu)) {                  // option attn_q64_stream=0: the block grid below
+        const int rc = launch_q64_stream(a, n_cu, s);
+        if (rc != -2) return rc;
+    }
     {
         // persistent form (LTX_ATTN_Q64_PERSIST=1; key counts in whole tiles, more work than one round of blocks).  Measured
         // on MI355X at S = 4992, 32 heads: 183 us against 178 us for the block grid below - a 128-query block costs 0.59 of a

@@ -29,7 +29,7 @@ struct LtxOptions {
     int norm_presum = 1;          // 0: row-reducing RMS norms; 2: the map whatever the shape
     int norm_lean = 1;            // 0: the general presum kernel (same bits as the lean one)
     int xattn_compact = 1;        // 0: cross attention multiplies every text key
-    int attn_q64_stream = 1;      // 0: head_dim-64 self-attention as a grid of independent blocks (round 2-5); 1: persistent workgroups streaming their item lists (attn_q64.hip)
+    int attn_q64_stream = 0;      // 1: head_dim-64 self-attention as persistent workgroups streaming host-built item lists (attn_q64.hip; round 6: built, tested, 4 - 6 % behind the block grid)
     int norm_fold = 1;            // 0: the DiT's RMS norms between GEMMs as their own (presum) pass; 1: folded into the producer's / consumer's epilogues (dit.hip)
     int guidance_batch = 1;       // 0: the guidance branches of a step (uncond / text / perturbed) as separate forwards, the reference's call order
     int dense_qkv = 1;            // 0: q | k | v as column slices of one [M, 3D] matrix

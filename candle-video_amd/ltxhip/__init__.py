@@ -1180,9 +1180,12 @@ class ops:
     def attention_prescaled(q, k, v, heads):
         """bf16, head_dim 64: q already multiplied by scale*log2(e); softmax in base 2 (DiT self-attention fast path)."""
         B, Sq, D = q.shape
-        o = torch.empty_like(q)
-        _check(lib.ltx_op_attention_prescaled(_ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), B, Sq, k.shape[1],
-                                              heads, D // heads, D, D, D, D, _stream()))
+        def rows(t):          # a [B, S, D] view whose rows are dense and whose batches are S rows apart keeps its row stride (column slices of a fused buffer)
+            return t if t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0 else t.contiguous()
+        q, k, v = rows(q), rows(k), rows(v)
+        o = torch.empty(B, Sq, D, dtype=q.dtype, device=q.device)
+        _check(lib.ltx_op_attention_prescaled(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, Sq, k.shape[1],
+                                              heads, D // heads, q.stride(1), k.stride(1), v.stride(1), D, _stream()))
         return o
 
     @staticmethod

@@ -281,6 +281,9 @@ int ltx_plan_load(const char* path);
  *   gemm_wide_epi=0        fragment-wise 8-byte epilogue stores instead of the LDS-transposed 16-byte ones
  *   gemm_trace=1           print every bf16 GEMM shape left to the 128 x 128 register-staged kernel
  *   attn_q64_big=N         self-attention (head_dim 64): N 256-query blocks per head, the rest in 128-query blocks
+ *   attn_q64_stream=1      self-attention (head_dim 64) as persistent workgroups that stream host-built item lists (key-range parts of
+ *                          the last round's blocks merged in the launch: those rows round differently, <= 3e-3 rel-L2 from the block
+ *                          grid; measured 4 - 6 % slower, kept as a tested option)
  *   norm_lean=0            the general RMS-norm map kernel instead of the DiT-specialised one
  *   vae_tile_batch=N       at most N leaves per decoder call of the tiled decode (-1: one)
  *   prof_kernel_events=0   stream-level event brackets in the ltx_prof_* timing

@@ -12,8 +12,13 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 4992
 heads = 32
 q, k, v = [torch.randn(1, S, heads * 64, device="cuda").bfloat16() for _ in range(3)]
 qp = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
-for _ in range(20): ltxhip.ops.attention_prescaled(qp, k, v, heads)
+for _ in range(400): ltxhip.ops.attention_prescaled(qp, k, v, heads)       # (clocks settled: the stamps of the LAST launch are read)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100): ltxhip.ops.attention_prescaled(qp, k, v, heads)
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"us_per_launch_events": round(e0.elapsed_time(e1) * 10, 1)}))
 lib = ctypes.CDLL(os.path.join(PKG, "libltxhip.so"))
 n = 256 * 8 * 4
 buf = (ctypes.c_ulonglong * n)()
