@@ -15,6 +15,7 @@
 #include <deque>
 #include "model_util.h"
 #include "options.h"
+#include "../../include/ltxhip_frames.h"
 
 extern "C" int ltx_pcg32_randn(uint64_t seed, uint64_t inc, size_t n, float* out_host);   // host/pipeline.hip (utils/deterministic_rng.rs)
 
@@ -40,7 +41,7 @@ struct ltx_vae {
     float *mean = nullptr, *std_ = nullptr, *vtab = nullptr;
     int mid_ch = 0, last_ch = 0;
     std::vector<void*> owned;
-    DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats, predec;
+    DevBuf zin, X, Y, N, C, tproj, e1, te, mod, tiles[2], tile_lat, stats, predec, rgbtmp;
     std::deque<DevBuf> tilebufs;   // deque: growing it must not move DevBufs that Tile.buf points at
     // CombinedTimestepEmbedder outputs (+ scale_shift_table) per (table, timestep vector, stream): functions of the weights and the
     // timestep alone (a pipeline decodes every video at the same decode_timestep), 5 launches per resnet when recomputed
@@ -583,7 +584,13 @@ int decode_cl(ltx_vae* v, const void* z, int B, int F, int H, int W, const TimeV
     const int oT = (F - 1) * tr + 1, oH = H * r, oW = W * r;
     const bool framewise = tl && tl->use_framewise_decoding && F > tl->tile_sample_min_num_frames / tr;
     const bool spatial = tl && tl->use_tiling && (W > tl->tile_sample_min_width / r || H > tl->tile_sample_min_height / r);
-    if (!framewise && !spatial) return decoder_forward(v, z, B, F, H, W, tv, post, out, s);     // vae.rs:2065
+    if (!framewise && !spatial) return decoder_forward(v, z, B, F, H, W, tv, post, out, s);     // vae.rs:2065 (post == 2: RGB8 from conv_out's epilogue)
+    // RGB8 output of a TILED decode: the blends run on f32 tiles - decode into a scratch video, convert with the frame kernel (same bits)
+    if (post == 2) {
+        LTX_TRY(v->rgbtmp.ensure((size_t)BC * oT * oH * oW * sizeof(float)));
+        LTX_TRY(decode_cl(v, z, B, F, H, W, tv, tl, 1, v->rgbtmp.as<float>(), s));
+        return ltx_video_to_rgb8(v->rgbtmp.as<float>(), B, oT, oH, oW, reinterpret_cast<uint8_t*>(out), (ltx_stream)s);
+    }
     size_t pool_used = 0;
     if (!framewise) {
         LTX_TRY(tiled_decode(v, z, B, F, H, W, tv, *tl, out, v->tilebufs, pool_used, s));
@@ -700,7 +707,7 @@ extern "C" int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtyp
         const size_t in_b = (size_t)v->cfg.latent_channels * F * H * W * (io_dtype == LTX_BF16 ? 2 : 4), out_b = out_elems_per_sample(v, F, H, W);
         for (int b0 = 0; b0 < B; b0 += 8)
             LTX_TRY(ltx_vae_decode(v, (const char*)latents + b0 * in_b, io_dtype, timestep ? timestep + b0 : nullptr, B - b0 < 8 ? B - b0 : 8, F, H, W, tiling,
-                                   postprocess, out + b0 * out_b, stream));
+                                   postprocess, postprocess == 2 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(out) + b0 * out_b) : out + b0 * out_b, stream));
         return LTX_OK;
     }
     HIP_TRY(hipSetDevice(v->device));
@@ -722,7 +729,8 @@ extern "C" int ltx_vae_decode_tokens(ltx_vae* v, const float* tokens, const floa
         const size_t in_e = (size_t)v->cfg.latent_channels * F * H * W, out_b = out_elems_per_sample(v, F, H, W);
         for (int b0 = 0; b0 < B; b0 += 8)
             LTX_TRY(ltx_vae_decode_tokens(v, tokens + b0 * in_e, noise ? noise + b0 * in_e : nullptr, noise ? noise_scale + b0 : nullptr, timestep ? timestep + b0 : nullptr,
-                                          B - b0 < 8 ? B - b0 : 8, F, H, W, tiling, postprocess, out + b0 * out_b, stream));
+                                          B - b0 < 8 ? B - b0 : 8, F, H, W, tiling, postprocess,
+                                          postprocess == 2 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(out) + b0 * out_b) : out + b0 * out_b, stream));
         return LTX_OK;
     }
     HIP_TRY(hipSetDevice(v->device));

@@ -557,7 +557,8 @@ class AutoencoderKLLtxVideo:
                        self.tile_sample_min_width, self.tile_sample_min_num_frames, self.tile_sample_stride_height,
                        self.tile_sample_stride_width, self.tile_sample_stride_num_frames)
 
-    def decode(self, latents: torch.Tensor, timestep=None, postprocess: bool = False) -> torch.Tensor:
+    def decode(self, latents: torch.Tensor, timestep=None, postprocess: bool = False, rgb8: bool = False) -> torch.Tensor:
+        """rgb8=True: the post-processed video as u8 frames [B, frames, H, W, 3] (main.rs:653-675) from the decoder's last epilogue"""
         io = latents.dtype if latents.dtype in (torch.float32, torch.bfloat16) else torch.float32
         z = _dev(latents, io)
         if z.dim() != 5 or z.shape[1] != self.config.latent_channels:
@@ -570,9 +571,12 @@ class AutoencoderKLLtxVideo:
                 raise LtxError(f"timestep must have {B} entries")
             t = _floats(tv)
         r, tr = self.config.spatial_compression_ratio, self.config.temporal_compression_ratio
-        out = torch.empty(B, self.config.out_channels, (F - 1) * tr + 1, H * r, W * r, dtype=torch.float32, device=z.device)
+        if rgb8:
+            out = torch.empty(B, (F - 1) * tr + 1, H * r, W * r, self.config.out_channels, dtype=torch.uint8, device=z.device)
+        else:
+            out = torch.empty(B, self.config.out_channels, (F - 1) * tr + 1, H * r, W * r, dtype=torch.float32, device=z.device)
         tl = self._tiling()
-        _check(lib.ltx_vae_decode(self._h, _ptr(z), _dt(io), t, B, F, H, W, C.byref(tl) if tl else None, int(postprocess),
+        _check(lib.ltx_vae_decode(self._h, _ptr(z), _dt(io), t, B, F, H, W, C.byref(tl) if tl else None, 2 if rgb8 else int(postprocess),
                                   _ptr(out), _stream()))
         return out
 
@@ -746,6 +750,7 @@ class PipelineCall:
     decode_noise_scale: float = 0.025
     output_latent: bool = False
     postprocess: bool = True
+    output_rgb8: bool = False                   # the video as u8 frames [B, frames, H, W, 3] (ltx_pipeline_params::postprocess = 2; main.rs:653-675)
     shift_terminal: Optional[float] = 0.1
     stochastic_sampling: bool = False           # SchedulerConfig::stochastic_sampling (0.9.6-distilled preset)
 
@@ -802,7 +807,7 @@ class LtxPipeline:
             p.skip_block_list = C.cast(sb, C.POINTER(C.c_int))
             p.n_skip_blocks = len(args.skip_block_list)
         p.decode_timestep, p.decode_noise_scale = args.decode_timestep, args.decode_noise_scale
-        p.output_latent, p.postprocess = int(args.output_latent), int(args.postprocess)
+        p.output_latent, p.postprocess = int(args.output_latent), (2 if args.output_rgb8 else int(args.postprocess))
         p.shift_terminal = args.shift_terminal if args.shift_terminal is not None else 0.0
         p.use_shift_terminal = int(args.shift_terminal is not None)
         if args.stochastic_sampling:
@@ -832,7 +837,10 @@ class LtxPipeline:
             if self.vae is None:
                 raise LtxError("decode requested but the pipeline has no VAE")
             # the decoder's own output shape (vae.rs:2101-2136): (F-1)*tr+1 frames, which is num_frames only for tr*k+1
-            video = torch.empty(B, 3, (F - 1) * tr + 1, H * sr, W * sr, dtype=torch.float32, device=lat.device)
+            if args.output_rgb8:
+                video = torch.empty(B, (F - 1) * tr + 1, H * sr, W * sr, 3, dtype=torch.uint8, device=lat.device)
+            else:
+                video = torch.empty(B, 3, (F - 1) * tr + 1, H * sr, W * sr, dtype=torch.float32, device=lat.device)
         _check(lib.ltx_pipeline_call(self.transformer._h, self.vae._h if self.vae is not None else None, C.byref(p),
                                      _ptr(lat), _ptr(pe), _ptr(pm), _ptr(ne), _ptr(nm), _ptr(dn), B, K,
                                      _ptr(video), _stream()))

@@ -144,8 +144,11 @@ const float* ltx_vae_latents_mean(const ltx_vae* v);   /* device f32 [latent_cha
 const float* ltx_vae_latents_std(const ltx_vae* v);
 /* VaeLtxVideo::decode (t2v_pipeline.rs:102; vae.rs:2101-2136, 2459-2462).
  *   latents  [B,C,F,H,W] io_dtype;  timestep HOST f32 [B] or NULL;  tiling NULL = direct decode
- *   out      [B,3,8F-7,32H,32W] f32, approx [-1,1]  (or [0,255] when postprocess != 0:
- *            LtxVideoProcessor::postprocess_video, t2v_pipeline.rs:146-155) */
+ *   out      [B,3,8F-7,32H,32W] f32, approx [-1,1]  (or [0,255] when postprocess == 1:
+ *            LtxVideoProcessor::postprocess_video, t2v_pipeline.rs:146-155);
+ *            postprocess == 2: `out` is a u8 buffer [B,8F-7,32H,32W,3] - the RGB8 frames the reference's CLI converts the
+ *            post-processed tensor to (main.rs:653-675), written by conv_out's epilogue: the bytes of ltx_video_to_rgb8 on the
+ *            postprocess == 1 result, a quarter of the bytes stored and no conversion pass */
 int ltx_vae_decode(ltx_vae* v, const void* latents, ltx_dtype io_dtype, const float* timestep,
                    int B, int F, int H, int W, const ltx_tiling* tiling, int postprocess,
                    float* out, ltx_stream stream);
@@ -214,7 +217,7 @@ typedef struct {
     int n_skip_blocks;
     float decode_timestep, decode_noise_scale;
     int output_latent;              /* OutputType::Latent: stop before decode */
-    int postprocess;                /* apply postprocess_video */
+    int postprocess;                /* 1: apply postprocess_video; 2: that + RGB8 frames: out_video is then u8 [B,frames,height,width,3] (ltx_vae_decode) */
     const ltx_tiling* tiling;       /* NULL = untiled */
     float shift_terminal; int use_shift_terminal;   /* scheduler config (configs.rs:101-121) */
     int stochastic_sampling;        /* scheduler config (configs.rs:16; main.rs:550): stochastic step instead of Euler */
