@@ -442,20 +442,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            // The bias of this lane's FN column groups, loaded ONCE and together (round 6: the load used to sit inside the fm / fn loops
+            // - FM x FN dependent global loads per thread, each waited for with vmcnt(0) before its add: 35 drains per tile, about
+            // 3 us of a 46-us tile on a kernel whose epilogue nothing overlaps).  Same values, same adds: same bits.
+            float bias4[FN][4];
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bias4[fn][i] = 0.f;
+            }
+            if (g.bias) {
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + n0 + wn * WN + fn * 16 + 4 * fq, bias4[fn]);
+            }
             __syncthreads();
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
                 const int row = (wm * FM + fm) * 16 + frow;
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) {
-                    const int col = wn * WN + fn * 16 + 4 * fq, nb = n0 + col;
+                    const int col = wn * WN + fn * 16 + 4 * fq;
                     unsigned char* slot = halo_smem + row * (CPR * 16) + (((col >> 3) ^ (row & XM)) << 4) + ((col >> 2) & 1) * 8;
                     float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
-                    if (g.bias) {
-                        float bb[4];
-                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nb, bb);
+                    {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += bb[i];
+                        for (int i = 0; i < 4; ++i) v[i] += bias4[fn][i];
                     }
                     if constexpr (EPI == EPI_RESID) {
                         float r[4];
@@ -518,6 +529,76 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             return;
         }
     }
+    // Fragment-wise epilogues (depth-to-space, unpatchify, narrow bias / residual outputs).  Round 6: every load of the tile - the bias
+    // of the lane's FN column groups, the depth-to-space residual's gathers - is issued FIRST and waited for once; inside the fm / fn
+    // loops each fragment's load waited vmcnt(0), which on gfx950 also waits for the STORE of the fragment before it: FM x FN
+    // store -> load round trips in a row on an epilogue nothing overlaps.  Same values added in the same order: same bits.
+    if constexpr (EPI == EPI_D2S || EPI == EPI_UNPATCH || EPI == EPI_BIAS) {
+        float bias4[FN][4];
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias4[fn][i] = 0.f;
+        }
+        if (g.bias) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                int nb = n0 + wn * WN + fn * 16 + 4 * fq; nb = nb < g.N ? nb : g.N - 4;
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nb, bias4[fn]);
+            }
+        }
+        const bool d2s_res = EPI == EPI_D2S && g.resid != nullptr;
+        GemmArgs gs = g; gs.bias = nullptr; gs.resid = nullptr;      // epilogue() then only places and stores
+        // rows in chunks of FC: a chunk's residual gathers are all in flight together (one wait per chunk - it also waits for the
+        // stores of the chunk before, the only serialisation left), FC sized so that nothing is spilled (8 x 4 fragments: 2 rows)
+        constexpr int FC = FM * FN > 16 ? 2 : FM;
+#pragma unroll
+        for (int f0 = 0; f0 < FM; f0 += FC) {
+            bf16_t raw[FC][FN][4];
+            if constexpr (EPI == EPI_D2S) {
+                if (d2s_res) {                              // (uniform; inside: no condition in front of a load - rows / columns outside the tensor read clamped addresses and are never stored)
+                    const int nsub = g.d2s_sp ? 4 : 8;
+#pragma unroll
+                    for (int fc = 0; fc < FC; ++fc) {
+                        int y = y0 + wm * FM + f0 + fc, x = x0 + frow;
+                        y = y < g.H ? y : g.H - 1; x = x < g.Wd ? x : g.Wd - 1;
+                        const int m = ((b * g.T + t) * g.H + y) * g.Wd + x;
+                        const bf16_t* xr = reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m * g.Cin;
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn) {
+                            int nb = n0 + wn * WN + fn * 16 + 4 * fq; nb = nb < g.N ? nb : g.N - 4;
+                            const int sidx = nb / g.Cf, co = nb - sidx * g.Cf;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) raw[fc][fn][i] = xr[((co + i) % g.Cr) * nsub + sidx];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int fc = 0; fc < FC; ++fc) {
+                const int fm = f0 + fc;
+                const int y = y0 + wm * FM + fm, x = x0 + frow;
+                if (y >= g.H || x >= g.Wd) continue;
+                const int m = ((b * g.T + t) * g.H + y) * g.Wd + x;
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    const int nb = n0 + wn * WN + fn * 16 + 4 * fq;
+                    if (nb >= g.N) continue;                // N % 4 == 0: a 4-column group is inside or outside as a whole
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[fm][fn][i] + bias4[fn][i];
+                    if constexpr (EPI == EPI_D2S) {
+                        if (d2s_res) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += to_f32(raw[fc][fn][i]);
+                        }
+                    }
+                    epilogue<bf16_t, EPI>(gs, m, nb, v);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int y = y0 + wm * FM + fm, x = x0 + frow;
@@ -530,6 +611,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
             float v[4] = {acc[fm][fn][0], acc[fm][fn][1], acc[fm][fn][2], acc[fm][fn][3]};
             epilogue<bf16_t, EPI>(g, m, nb, v);
         }
+    }
     }
 }
 

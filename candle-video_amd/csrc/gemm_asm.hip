@@ -661,24 +661,68 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_conv_kernel(const GemmArgs 
         ad[nb] = smem_base + (uint32_t)(rr * 1024 + ((chunk ^ rr) << 4));
     }
     float* slab = sf > 1 ? g.sk_ws + ((int64_t)tile * sf + part) * (BM * BN) : nullptr;
+    // Round 6: no load inside the row loops.  The bias of the thread's two column groups is loaded once; the depth-to-space
+    // residual's gathers of four rows are issued together.  (A load per row waited vmcnt(0), i.e. also for the row before's stores:
+    // 64 store -> load round trips per thread and tile.)  epilogue() is handed a GemmArgs without bias / residual: it places and stores.
+    float bA4[4] = {0.f, 0.f, 0.f, 0.f}, bB4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nAc = nA < g.N ? nA : g.N - 4, nBc = nB < g.N ? nB : g.N - 4;       // (clamped: no condition in front of a load)
+    if (g.bias) { load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nAc, bA4); load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nBc, bB4); }
+    GemmArgs gs = g; gs.bias = nullptr; if (EPI == EPI_D2S) gs.resid = nullptr;
+    const bool d2s_res = EPI == EPI_D2S && g.resid != nullptr;
 #pragma unroll
     for (int p = 0; p < BM / RP; ++p) {
         __syncthreads();
         AsmLoop16<256, 256, 2, 2>::store(p, wm, c, ad);
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < RP / 8; ++k) {
-            const int row = r0 + 8 * k, trow = p * RP + row, m = m0 + trow;
-            const unsigned char* rowp = asm_smem + row * 1024;
-            f32x4 vA = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
-            f32x4 vB = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
+        constexpr int UQ = 4;
+#pragma unroll 1
+        for (int k0 = 0; k0 < RP / 8; k0 += UQ) {
+            f32x4 vA[UQ], vB[UQ];
+            bf16_t xa[UQ][4], xb[UQ][4];
+#pragma unroll
+            for (int j = 0; j < UQ; ++j) {
+                const int row = r0 + 8 * (k0 + j);
+                const unsigned char* rowp = asm_smem + row * 1024;
+                vA[j] = *reinterpret_cast<const f32x4*>(rowp + ((cg ^ (row & 15)) << 4));
+                vB[j] = *reinterpret_cast<const f32x4*>(rowp + (((cg + 32) ^ (row & 15)) << 4));
+            }
             if (sf > 1) {
-                *reinterpret_cast<f32x4*>(slab + trow * BN + 4 * cg) = vA;
-                *reinterpret_cast<f32x4*>(slab + trow * BN + 128 + 4 * cg) = vB;
-            } else if (m < g.M) {
-                float a4[4] = {vA[0], vA[1], vA[2], vA[3]}, b4[4] = {vB[0], vB[1], vB[2], vB[3]};
-                if (nA < g.N) epilogue<bf16_t, EPI>(g, m, nA, a4);
-                if (nB < g.N) epilogue<bf16_t, EPI>(g, m, nB, b4);
+#pragma unroll
+                for (int j = 0; j < UQ; ++j) {
+                    const int trow = p * RP + r0 + 8 * (k0 + j);
+                    *reinterpret_cast<f32x4*>(slab + trow * BN + 4 * cg) = vA[j];
+                    *reinterpret_cast<f32x4*>(slab + trow * BN + 128 + 4 * cg) = vB[j];
+                }
+                continue;
+            }
+            if constexpr (EPI == EPI_D2S) {
+                if (d2s_res) {
+                    const int nsub = g.d2s_sp ? 4 : 8;
+                    const int sA = nAc / g.Cf, coA = nAc - sA * g.Cf, sB = nBc / g.Cf, coB = nBc - sB * g.Cf;
+#pragma unroll
+                    for (int j = 0; j < UQ; ++j) {
+                        int m = m0 + p * RP + r0 + 8 * (k0 + j); if (m > g.M - 1) m = g.M - 1;
+                        const bf16_t* xr = reinterpret_cast<const bf16_t*>(g.resid) + (int64_t)m * g.Cin;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { xa[j][i] = xr[((coA + i) % g.Cr) * nsub + sA]; xb[j][i] = xr[((coB + i) % g.Cr) * nsub + sB]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UQ; ++j) {
+                const int m = m0 + p * RP + r0 + 8 * (k0 + j);
+                if (m >= g.M) continue;
+                float a4[4], b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a4[i] = vA[j][i] + bA4[i]; b4[i] = vB[j][i] + bB4[i]; }
+                if constexpr (EPI == EPI_D2S) {
+                    if (d2s_res) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { a4[i] += to_f32(xa[j][i]); b4[i] += to_f32(xb[j][i]); }
+                    }
+                }
+                if (nA < g.N) epilogue<bf16_t, EPI>(gs, m, nA, a4);
+                if (nB < g.N) epilogue<bf16_t, EPI>(gs, m, nB, b4);
             }
         }
     }
@@ -734,15 +778,15 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_conv_kernel(const GemmArgs 
                 if constexpr (EPI == EPI_D2S) {
                     if (nA < g.N) epilogue<bf16_t, EPI>(g, m, nA, a4);
                     if (nB < g.N) epilogue<bf16_t, EPI>(g, m, nB, b4);
-                } else {                                          // epilogue()'s expressions for bias / residual, residual already here
+                } else {                                          // epilogue()'s expressions for bias / residual, residual already here, bias loaded once above
                     bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc;
                     if (nA < g.N) {
-                        if (g.bias) { float bb[4]; load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nA, bb); for (int i = 0; i < 4; ++i) a4[i] += bb[i]; }
+                        for (int i = 0; i < 4; ++i) a4[i] += bA4[i];
                         if constexpr (EPI == EPI_RESID) for (int i = 0; i < 4; ++i) a4[i] += (float)qA[j][i];
                         store4<bf16_t>(crow + nA, a4);
                     }
                     if (nB < g.N) {
-                        if (g.bias) { float bb[4]; load4<bf16_t>(reinterpret_cast<const bf16_t*>(g.bias) + nB, bb); for (int i = 0; i < 4; ++i) b4[i] += bb[i]; }
+                        for (int i = 0; i < 4; ++i) b4[i] += bB4[i];
                         if constexpr (EPI == EPI_RESID) for (int i = 0; i < 4; ++i) b4[i] += (float)qB[j][i];
                         store4<bf16_t>(crow + nB, b4);
                     }
