@@ -32,6 +32,7 @@ struct DitTimeEntry {
     float t[8] = {0}; int B = 0; hipStream_t stream = nullptr; bool valid = false; uint64_t used = 0;
     DevBuf ada, adaf;                // [L][B][6D] f32, [2][B][D] f32
     DevBuf cfold; bool cfold_valid = false;      // norm fold: per layer [B][3D] (shift_msa . W_qkv^T + b_qkv) then [B][4D] (shift_mlp . W_ff1^T + b_ff1), f32
+    DevBuf wfold; bool wfold_valid = false;      // norm fold through the weights (norm_fold=2): per layer W_qkv (.) (1 + scale_msa) [3D, D] then W_ff1 (.) (1 + scale_mlp) [4D, D], model dtype
 };
 constexpr int kDitTimeEntries = 64;
 
@@ -50,6 +51,7 @@ struct ltx_dit {
     std::deque<DitCtx> ctxs;         // deque: entries must not move while `ctx` points at one
     bool ctx_mode = false;
     std::deque<DitTimeEntry> tcache; uint64_t tclock = 0;
+    bool wfold_off = false;          // norm_fold=2 gave up on this handle: more distinct timesteps in flight than scaled-weight copies (a schedule that would re-scale every step)
     // RoPE tables of the caching scope (ltx_dit_context_cache: the caller keeps coords / geometry constant inside it): what cosb / sinb hold
     struct { bool valid = false; const float* coords = nullptr; float rs[3] = {0, 0, 0}; bool has_rs = false; int B = 0, S = 0, F = 0, H = 0, W = 0; hipStream_t stream = nullptr; } rope_key;
     std::vector<void*> owned;        // every hipMalloc'd weight pointer
@@ -62,7 +64,7 @@ struct ltx_dit {
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); e.kvc.release(); e.biasc.release(); e.kidx.release(); e.kcount.release(); }
         ctxs.clear();
-        for (auto& e : tcache) { e.ada.release(); e.adaf.release(); }
+        for (auto& e : tcache) { e.ada.release(); e.adaf.release(); e.cfold.release(); e.wfold.release(); }
         tcache.clear();
     }
 };
@@ -311,7 +313,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (!te) {
         if ((int)m->tcache.size() < kDitTimeEntries) { m->tcache.emplace_back(); te = &m->tcache.back(); }
         else { te = &m->tcache.front(); for (auto& e : m->tcache) if (e.used < te->used) te = &e; }
-        te->valid = false; te->cfold_valid = false;
+        te->valid = false; te->cfold_valid = false; te->wfold_valid = false;
         LTX_TRY(te->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(te->adaf.ensure((size_t)2 * B * D * sizeof(float)));
         LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
         LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
@@ -335,6 +337,37 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             LTX_TRY(ltx_launch_shift_gemv(m->blocks[l].ff1.w, m->blocks[l].ff1.b, ada + 3 * D, 6 * D, B, 4 * D, D, cq + (size_t)B * 3 * D, 4 * D, s));
         }
         te->cfold_valid = true;
+    }
+    // norm_fold=2: the (1 + scale) factor rides on the CONSUMER's weights instead of on a second output of the producer:
+    // (h (.) (1 + sc)) W^T = h (W (.) (1 + sc))^T.  One scaled copy of the q|k|v and ff1 weights per distinct timestep (1.6 GB at 2B:
+    // read + written once, then cached like the modulation they are made from - a distilled schedule has 7), all batch rows at one
+    // timestep (what LtxPipeline::call passes, t2v_pipeline.rs:868); otherwise, or when the schedule has more distinct timesteps
+    // than copies (norm_fold_copies; the 40-step presets), the second-output form serves.  bf16 rounding moves from h (1 + sc) to W (1 + sc).
+    bool wf = nfold && ltx_opt().norm_fold == 2 && !m->wfold_off;
+    for (int i = 1; i < B; ++i) wf = wf && tv.t[i] == tv.t[0];
+    if (wf && !te->wfold_valid) {
+        const int cap = ltx_opt().norm_fold_copies > 0 ? ltx_opt().norm_fold_copies : 1;
+        int live = 0; DitTimeEntry* victim = nullptr;
+        for (auto& e : m->tcache) if (e.wfold_valid) { ++live; if (!victim || e.used < victim->used) victim = &e; }
+        if (live >= cap) {
+            if (m->tclock - victim->used < (uint64_t)4 * cap) {      // its owner ran a moment ago: the schedule cycles through more timesteps than copies
+                m->wfold_off = true; wf = false;
+                HIP_TRY(hipStreamSynchronize(s));               // (earlier forwards on this stream may still read the copies)
+                for (auto& e : m->tcache) { e.wfold.release(); e.wfold_valid = false; }
+            }
+            else { victim->wfold.release(); victim->wfold_valid = false; }
+        }
+        if (wf) {
+            const size_t per_layer = (size_t)7 * D * D * esz;
+            LTX_TRY(te->wfold.ensure((size_t)L * per_layer));
+            for (int l = 0; l < L; ++l) {
+                const float* ada = ada_all + (size_t)l * B * 6 * D;
+                char* wl = (char*)te->wfold.p + (size_t)l * per_layer;
+                LTX_TRY(ltx_launch_scale_cols(m->blocks[l].qkv1.w, ada + D, wl, 3 * D, D, dt, s));
+                LTX_TRY(ltx_launch_scale_cols(m->blocks[l].ff1.w, ada + 4 * D, wl + (size_t)3 * D * D * esz, 4 * D, D, dt, s));
+            }
+            te->wfold_valid = true;
+        }
     }
 
     // Text context: caption projection (:186-190), mask bias (:1059-1070) and, for every layer, the cross-attention
@@ -436,14 +469,12 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         RowNormArgs rn; rn.x = m->h.p; rn.y = m->n.p; rn.rows = M; rn.D = D; rn.ldx = D; rn.ldy = D;
         rn.kind = 0; rn.eps = c.norm_eps; rn.shift = ada; rn.scale = ada + D; rn.rows_per_batch = S; rn.mod_stride = 6 * D;
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
-        const bool fold1 = nfold && hs_valid && hsq_valid;      // the layer that wrote h left h (.) (1 + scale_msa) in m->n: no pass
+        const bool fold1 = nfold && hsq_valid && (wf || hs_valid);      // the layer that wrote h left its row partials and h (.) (1 + scale_msa) in m->n (or the factor is in the weights): no pass
         const float* cfold_l = nfold ? te->cfold.as<float>() + (size_t)l * B * 7 * D : nullptr;
+        const char* wfold_l = wf ? (const char*)te->wfold.p + (size_t)l * 7 * D * D * esz : nullptr;
         if (!fold1) {
         take_pending(rn);
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
-        } else if (ltx_opt().norm_fold >= 2) {              // diagnostic arms: 2 = the fold AND the pass (into a buffer nobody reads) - what the pause between two GEMMs is worth;
-            RowNormArgs dn = rn; dn.y = ltx_opt().norm_fold == 3 ? m->n.p : m->qkv.p;     // 3 (WRONG RESULTS) = the pass writes the rows the folded layer reads (the producers' second output goes elsewhere): who wrote A
-            LTX_TRY(ltx_launch_rownorm(dn, dt, s));
         }
         hs_valid = false;
         rn.parts = nullptr; rn.nparts = 0; rn.x_out = nullptr; rn.d_bias = nullptr; rn.d_gate = nullptr;
@@ -458,7 +489,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             g.A = m->n.p; g.W = b.qkv1.w; g.C = m->qkv.p; g.bias = b.qkv1.b;
             g.M = (int)M; g.N = b.qkv1.out; g.K = b.qkv1.in; g.lda = D; g.ldc = ldqkv;
             if (dense_qkv) { g.c_seg_shift = __builtin_ctz((unsigned)D); g.c_seg_stride = seg; }
-            if (fold1) { g.bias = nullptr; g.rows_per_batch = S; g.rs_sq = m->hsq.as<float>(); g.rs_n = D / 128; g.rs_D = D; g.rs_eps = c.norm_eps; g.cvec = cfold_l; g.cvec_stride = 3 * D; }
+            if (fold1) {
+                g.bias = nullptr; g.rows_per_batch = S; g.rs_sq = m->hsq.as<float>(); g.rs_n = D / 128; g.rs_D = D; g.rs_eps = c.norm_eps; g.cvec = cfold_l; g.cvec_stride = 3 * D;
+                if (wf) { g.A = m->h.p; g.W = wfold_l; }
+            }
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
         }
         QkNormRopeArgs qa; qa.x = m->qkv.p; qa.rows = M; qa.D = D; qa.ld = ldqkv; qa.seg_stride = seg; qa.nseg = 2; qa.w0 = b.nq1; qa.w1 = b.nk1;
@@ -492,10 +526,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             LTX_TRY(ltx_launch_qknorm_rope(q2, dt, s));
         }
         LTX_TRY(ltx_launch_attention(ax, dt, s));
-        if (nfold) {                                           // + h (.) (1 + scale_mlp) into m->n for ff1
+        if (nfold && !wf) {                                    // + h (.) (1 + scale_mlp) into m->n for ff1
             GemmArgs g; g.A = m->attn.p; g.W = b.o2.w; g.C = m->h.p; g.bias = b.o2.b; g.resid = m->h.p; g.M = (int)M; g.N = b.o2.out; g.K = b.o2.in;
             g.lda = D; g.ldc = D; g.ldr = D; g.rows_per_batch = S; g.rowsq = m->hsq.as<float>();
-            g.C2 = ltx_opt().norm_fold == 3 ? m->ff.p : m->n.p; g.scale2 = ada + 4 * D; g.scale2_stride = 6 * D;
+            g.C2 = m->n.p; g.scale2 = ada + 4 * D; g.scale2_stride = 6 * D;
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_RESID, s));
             hs_valid = true;
         } else
@@ -505,10 +539,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         rn.shift = ada + 3 * D; rn.scale = ada + 4 * D;
         rn.presum = nullptr; rn.presum_n = 0;
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
-        if (nfold && hs_valid && hsq_valid) {
+        if (nfold && hsq_valid && (wf || hs_valid)) {
             GemmArgs g; g.A = m->n.p; g.W = b.ff1.w; g.C = m->ff.p; g.M = (int)M; g.N = b.ff1.out; g.K = b.ff1.in; g.lda = D; g.ldc = 4 * D; g.rows_per_batch = S;
             g.rs_sq = m->hsq.as<float>(); g.rs_n = D / 128; g.rs_D = D; g.rs_eps = c.norm_eps; g.cvec = cfold_l + (size_t)B * 3 * D; g.cvec_stride = 4 * D;
-            if (ltx_opt().norm_fold >= 2) { RowNormArgs dn = rn; dn.y = ltx_opt().norm_fold == 3 ? m->n.p : m->ff.p; LTX_TRY(ltx_launch_rownorm(dn, dt, s)); }
+            if (wf) { g.A = m->h.p; g.W = wfold_l + (size_t)3 * D * D * esz; }
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_GELU, s));
         } else {
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
@@ -520,10 +554,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             g.defer_parts = m->parts.as<float>();
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_BIAS, s));
             pending = true; pend_gate = ada + 5 * D; pend_bias = b.ff2.b;
-        } else if (int ln = nfold ? next_block(l) : -1; ln >= 0) {      // + h (.) (1 + scale_msa of the next block that runs) into m->n for its q|k|v projection
+        } else if (int ln = (nfold && !wf) ? next_block(l) : -1; ln >= 0) {      // + h (.) (1 + scale_msa of the next block that runs) into m->n for its q|k|v projection
             GemmArgs g; g.A = m->ff.p; g.W = b.ff2.w; g.C = m->h.p; g.bias = b.ff2.b; g.resid = m->h.p; g.M = (int)M; g.N = b.ff2.out; g.K = b.ff2.in;
             g.lda = 4 * D; g.ldc = D; g.ldr = D; g.gate = ada + 5 * D; g.gate_stride = 6 * D; g.rows_per_batch = S; g.rowsq = m->hsq.as<float>();
-            g.C2 = ltx_opt().norm_fold == 3 ? m->qkv.p : m->n.p; g.scale2 = ada_all + (size_t)ln * B * 6 * D + D; g.scale2_stride = 6 * D;
+            g.C2 = m->n.p; g.scale2 = ada_all + (size_t)ln * B * 6 * D + D; g.scale2_stride = 6 * D;
             LTX_TRY(ltx_launch_gemm(g, dt, EPI_GATE_RESID, s));
             hs_valid = true;
         } else
@@ -541,7 +575,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
             // m->n was formed from the un-blended rows, for the block after this one; the restored rows need theirs: the producer's
             // expression on the rows as they stand now (for the rows that kept the block: the bits the epilogue wrote)
             hs_valid = false;
-            if (nfold && hsq_valid) {
+            if (nfold && !wf && hsq_valid) {
                 if (const int ln = next_block(l); ln >= 0) {
                     LTX_TRY(ltx_launch_mod_scale(m->h.p, ada_all + (size_t)ln * B * 6 * D + D, 6 * D, m->n.p, B, S, D, dt, s));
                     hs_valid = true;

@@ -100,6 +100,12 @@ __global__ void mod_scale_kernel(const void* h, const float* scale, int scale_st
     }
 }
 
+// W'[n][k] = W[n][k] * (1 + scale[k]) in the model dtype (norm fold through the consumer's weights: dit.hip, DitTimeEntry::wfold)
+__global__ void scale_cols_kernel(const void* W, const float* scale, void* out, int64_t N, int K, int dt) {
+    const int64_t n = N * K;
+    GRID_STRIDE(i, n) std_(out, dt, i, ldd(W, dt, i) * (1.0f + scale[(int)(i % K)]));
+}
+
 // ---- guidance + Euler (t2v_pipeline.rs:941-964, 227-243; scheduler.rs:576-581) ----
 __device__ __forceinline__ float cfg_of(const GuidanceArgs& a, int64_t i, float& t) {
     t = ldd(a.text, a.pred_dtype, i);
@@ -267,6 +273,10 @@ int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t r
 }
 int ltx_launch_mod_scale(const void* h, const float* scale, int scale_stride, void* y, int B, int64_t rows_per_batch, int D, int dtype, hipStream_t s) {
     hipLaunchKernelGGL(mod_scale_kernel, grid_for((int64_t)B * rows_per_batch * D), dim3(256), 0, s, h, scale, scale_stride, y, B, rows_per_batch, D, dtype);
+    LTX_CHECK_LAUNCH(); return LTX_OK;
+}
+int ltx_launch_scale_cols(const void* W, const float* scale, void* out, int64_t N, int K, int dtype, hipStream_t s) {
+    hipLaunchKernelGGL(scale_cols_kernel, grid_for(N * K), dim3(256), 0, s, W, scale, out, N, K, dtype);
     LTX_CHECK_LAUNCH(); return LTX_OK;
 }
 int ltx_launch_guidance_step(const GuidanceArgs& a, hipStream_t s) {

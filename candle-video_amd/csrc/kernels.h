@@ -233,6 +233,7 @@ int ltx_launch_key_compact(const float* bias, int B, int K, int* idx, int* count
 int ltx_launch_gather_rows(const void* src, void* dst, const int* idx, const int* count, int nl, int B, int K, int row_bytes, hipStream_t s);
 // h = h*(1-m_b) + orig*m_b
 int ltx_launch_skip_blend(void* h, const void* orig, const TimeVec& m, int64_t rows_per_batch, int D, int dtype, hipStream_t s);
+int ltx_launch_scale_cols(const void* W, const float* scale, void* out, int64_t N, int K, int dtype, hipStream_t s);      // out[n][k] = W[n][k] * (1 + scale[k])
 int ltx_launch_mod_scale(const void* h, const float* scale, int scale_stride, void* y, int B, int64_t rows_per_batch, int D, int dtype, hipStream_t s);   // y = h (.) (1 + scale[b])
 
 struct GuidanceArgs {

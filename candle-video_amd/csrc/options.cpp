@@ -40,7 +40,7 @@ const IntField kInts[] = {
     {"gemm_tune", &LtxOptions::gemm_tune}, {"gemm_wide_epi", &LtxOptions::gemm_wide_epi}, {"gemm_trace", &LtxOptions::gemm_trace},
     {"attn_q64_big", &LtxOptions::attn_q64_big}, {"vae_tile_batch", &LtxOptions::vae_tile_batch}, {"prof_kernel_events", &LtxOptions::prof_kernel_events}, {"ff2_defer", &LtxOptions::ff2_defer},
     {"gemm_splitk", &LtxOptions::gemm_splitk}, {"q2_fold", &LtxOptions::q2_fold}, {"norm_presum", &LtxOptions::norm_presum}, {"norm_lean", &LtxOptions::norm_lean},
-    {"xattn_compact", &LtxOptions::xattn_compact}, {"dense_qkv", &LtxOptions::dense_qkv}, {"vae_fuse_norm", &LtxOptions::vae_fuse_norm}, {"t5_attn_mfma", &LtxOptions::t5_attn_mfma}, {"guidance_batch", &LtxOptions::guidance_batch}, {"norm_fold", &LtxOptions::norm_fold}, {"attn_q64_stream", &LtxOptions::attn_q64_stream},
+    {"xattn_compact", &LtxOptions::xattn_compact}, {"dense_qkv", &LtxOptions::dense_qkv}, {"vae_fuse_norm", &LtxOptions::vae_fuse_norm}, {"t5_attn_mfma", &LtxOptions::t5_attn_mfma}, {"guidance_batch", &LtxOptions::guidance_batch}, {"norm_fold", &LtxOptions::norm_fold}, {"norm_fold_copies", &LtxOptions::norm_fold_copies}, {"attn_q64_stream", &LtxOptions::attn_q64_stream},
 };
 
 // value == nullptr: the option's default

@@ -30,7 +30,8 @@ struct LtxOptions {
     int norm_lean = 1;            // 0: the general presum kernel (same bits as the lean one)
     int xattn_compact = 1;        // 0: cross attention multiplies every text key
     int attn_q64_stream = 0;      // 1: head_dim-64 self-attention as persistent workgroups streaming host-built item lists (attn_q64.hip; round 6: built, tested, 4 - 6 % behind the block grid)
-    int norm_fold = 1;            // 0: the DiT's RMS norms between GEMMs as their own (presum) pass; 1: folded into the producer's / consumer's epilogues (dit.hip)
+    int norm_fold = 2;            // 0: the DiT's RMS norms between GEMMs as their own (presum) pass; 1: folded into the producer's / consumer's epilogues (dit.hip); 2: the (1 + scale) factor in per-timestep copies of the consumer's weights
+    int norm_fold_copies = 10;    // norm_fold=2: scaled-weight copies kept per DiT handle (one per distinct timestep; 1.6 GB each at 2B: a distilled schedule's 7 + the warm-up's)
     int guidance_batch = 1;       // 0: the guidance branches of a step (uncond / text / perturbed) as separate forwards, the reference's call order
     int dense_qkv = 1;            // 0: q | k | v as column slices of one [M, 3D] matrix
     int vae_fuse_norm = 1;        // 0: the resnet's second norm as its own pass; 2: fused on grids below one round of the chip too (tests)

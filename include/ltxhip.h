@@ -297,8 +297,11 @@ int ltx_plan_load(const char* path);
  *   gemm_splitk=0          small outputs keep one K range (another f32 summation order)
  *   q2_fold=0 | 2          cross-attention q-norm as its own pass | folded whatever the shape
  *   norm_presum=0 | 2      row-reducing RMS norms | sums of squares from the producing GEMM whatever the shape
- *   norm_fold=0            the DiT's RMS norm + modulation between two GEMMs as its own pass (default 1: folded into the epilogues of
- *                          the layer that writes the rows and the layer that reads them, where norm_presum applies)
+ *   norm_fold=0 | 1        the DiT's RMS norm + modulation between two GEMMs as its own pass | folded into the epilogues of the layer
+ *                          that writes the rows (a second output h (1 + scale)) and of the layer that reads them (row 1 / rms, per-timestep
+ *                          vector).  Default 2: the (1 + scale) factor in a per-timestep COPY of the reading layer's weights instead of
+ *                          the second output (1.6 GB per distinct timestep at 2B, cached like the modulation; rows at different
+ *                          timesteps, or a schedule with more distinct timesteps than norm_fold_copies (10), use form 1)
  *   xattn_compact=0        cross attention multiplies every text key (differs from the default only for non-prefix masks)
  *   dense_qkv=0            q | k | v as column slices of one [M, 3D] matrix (same bits; another memory layout)
  *   vae_fuse_norm=0        the resnet's second norm as its own pass (1, default: fused where the conv's grid is about one round of

@@ -53,8 +53,8 @@ def test_fold_matches_the_pass_and_the_oracle(hip, B, F, H, W, skip):
     want = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, F, H, W, None, coords, slm)
     model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**CFGD), {k: v.to(DEV) for k, v in w.items()}, torch.bfloat16)
     args = (hidden.to(DEV), enc.to(DEV), t, mask.to(DEV), F, H, W, None, coords.to(DEV), slm)
-    y1, n1 = run(hip, model, args)
-    y1b, _ = run(hip, model, args)
+    y1, n1 = run(hip, model, args, norm_fold="1")
+    y1b, _ = run(hip, model, args, norm_fold="1")
     y0, n0 = run(hip, model, args, norm_fold="0")
     assert torch.isfinite(y1).all() and torch.equal(y1, y1b)    # repeatable bit for bit
     e1, e0, d = rel_l2(y1, want), rel_l2(y0, want), rel_l2(y1, y0)
@@ -65,6 +65,51 @@ def test_fold_matches_the_pass_and_the_oracle(hip, B, F, H, W, skip):
     # per block two norms; with the fold only the first block's norm1 (nothing produced its rows) and the final LayerNorm remain
     # (+ none behind the blend: the restored rows' h (.) (1 + sc) is a map, not a norm)
     assert n0 == 2 * 3 + 1 and n1 == 2, (n1, n0)
+    # norm_fold=2: the factor in per-timestep copies of the consumer's weights.  Rows at different timesteps (B = 2, 3 here) cannot
+    # share a copy: the second-output form serves them - the bits of norm_fold=1
+    y2, n2 = run(hip, model, args, norm_fold="2")
+    if B == 1:
+        e2 = rel_l2(y2, want)
+        print({"weights_form_vs_oracle": round(e2, 5), "vs_second_output_form": round(rel_l2(y2, y1), 5)})
+        assert n2 == 2 and e2 <= 1.1 * e0 + 1e-4 and rel_l2(y2, y1) <= 1e-2
+        assert torch.equal(y2, run(hip, model, args, norm_fold="2")[0])
+    else:
+        assert torch.equal(y2, y1)
+
+
+def test_weights_form_with_rows_at_one_timestep_and_a_cycling_schedule(hip):
+    """norm_fold=2 on a guidance batch (three rows, ONE timestep, a row that skips a block) against the oracle; then more distinct
+    timesteps than scaled-weight copies in a cycle: the handle gives the form up (it would re-scale 1.6 GB per step) and returns the
+    second-output form's bits from then on."""
+    cfg = O.DitConfig(**CFGD)
+    w = O.synth_weights(O.dit_weight_shapes(cfg), seed=71)
+    B, F, H, W, K = 3, 4, 16, 26, 128
+    S = F * H * W
+    g = torch.Generator().manual_seed(74)
+    hidden = torch.randn(B, S, 128, generator=g); enc = torch.randn(B, K, 4096, generator=g)
+    mask = torch.zeros(B, K); mask[:, :40] = 1
+    coords = O.build_video_coords(B, F, H, W)
+    slm = torch.zeros(3, B); slm[1, 2] = 1.0
+    t = torch.tensor([896.0] * B)
+    wr = {k: v.bfloat16().float() for k, v in w.items()}
+    want = O.dit_forward(wr, cfg, hidden.bfloat16().float(), enc.bfloat16().float(), t, mask, F, H, W, None, coords, slm)
+    model = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**CFGD), {k: v.to(DEV) for k, v in w.items()}, torch.bfloat16)
+    args = lambda tt: (hidden.to(DEV), enc.to(DEV), tt, mask.to(DEV), F, H, W, None, coords.to(DEV), slm)
+    y2, n2 = run(hip, model, args(t), norm_fold="2")
+    y0, _ = run(hip, model, args(t), norm_fold="0")
+    e2, e0 = rel_l2(y2, want), rel_l2(y0, want)
+    print({"weights_form_guidance_batch_vs_oracle": round(e2, 5), "pass": round(e0, 5)})
+    assert n2 == 2 and e2 <= 1.1 * e0 + 1e-4
+    # five timesteps cycling through two copies
+    with hip.options(norm_fold="2", norm_fold_copies="2"):
+        outs = {}
+        for rnd in range(3):
+            for tv in (896.0, 640.0, 384.0, 256.0, 128.0):
+                outs[(rnd, tv)] = model.forward(*args(torch.tensor([tv] * B))).float().cpu()
+    with hip.options(norm_fold="1"):
+        ref = model.forward(*args(torch.tensor([128.0] * B))).float().cpu()
+    assert torch.equal(outs[(2, 128.0)], ref)                  # given up by then: the second-output form
+    assert torch.equal(outs[(1, 128.0)], outs[(2, 128.0)])
 
 
 def test_guidance_rows_in_one_forward_keep_the_bits_of_separate_forwards(hip):
