@@ -32,8 +32,10 @@ struct DitTimeEntry {
     float t[8] = {0}; int B = 0; hipStream_t stream = nullptr; bool valid = false; uint64_t used = 0;
     DevBuf ada, adaf;                // [L][B][6D] f32, [2][B][D] f32
     DevBuf cfold; bool cfold_valid = false;      // norm fold: per layer [B][3D] (shift_msa . W_qkv^T + b_qkv) then [B][4D] (shift_mlp . W_ff1^T + b_ff1), f32
-    DevBuf wfold; bool wfold_valid = false;      // norm fold through the weights (norm_fold=2): per layer W_qkv (.) (1 + scale_msa) [3D, D] then W_ff1 (.) (1 + scale_mlp) [4D, D], model dtype
 };
+// norm fold through the weights (norm_fold=2): per layer W_qkv (.) (1 + scale_msa) [3D, D] then W_ff1 (.) (1 + scale_mlp) [4D, D], model dtype.
+// Keyed by the TIMESTEP alone (the modulation of a row depends on nothing else): forwards of any batch size at that timestep share the copy.
+struct DitWfold { float t = 0.f; hipStream_t stream = nullptr; bool valid = false; uint64_t used = 0; DevBuf w; };
 constexpr int kDitTimeEntries = 64;
 
 struct ltx_dit {
@@ -51,6 +53,7 @@ struct ltx_dit {
     std::deque<DitCtx> ctxs;         // deque: entries must not move while `ctx` points at one
     bool ctx_mode = false;
     std::deque<DitTimeEntry> tcache; uint64_t tclock = 0;
+    std::deque<DitWfold> wcache;
     bool wfold_off = false;          // norm_fold=2 gave up on this handle: more distinct timesteps in flight than scaled-weight copies (a schedule that would re-scale every step)
     // RoPE tables of the caching scope (ltx_dit_context_cache: the caller keeps coords / geometry constant inside it): what cosb / sinb hold
     struct { bool valid = false; const float* coords = nullptr; float rs[3] = {0, 0, 0}; bool has_rs = false; int B = 0, S = 0, F = 0, H = 0, W = 0; hipStream_t stream = nullptr; } rope_key;
@@ -64,7 +67,9 @@ struct ltx_dit {
         for (DevBuf* b : bs) b->release();
         for (auto& e : ctxs) { e.kv.release(); e.bias.release(); e.kvc.release(); e.biasc.release(); e.kidx.release(); e.kcount.release(); }
         ctxs.clear();
-        for (auto& e : tcache) { e.ada.release(); e.adaf.release(); e.cfold.release(); e.wfold.release(); }
+        for (auto& e : tcache) { e.ada.release(); e.adaf.release(); e.cfold.release(); }
+        for (auto& e : wcache) e.w.release();
+        wcache.clear();
         tcache.clear();
     }
 };
@@ -313,7 +318,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     if (!te) {
         if ((int)m->tcache.size() < kDitTimeEntries) { m->tcache.emplace_back(); te = &m->tcache.back(); }
         else { te = &m->tcache.front(); for (auto& e : m->tcache) if (e.used < te->used) te = &e; }
-        te->valid = false; te->cfold_valid = false; te->wfold_valid = false;
+        te->valid = false; te->cfold_valid = false;
         LTX_TRY(te->ada.ensure((size_t)L * B * 6 * D * sizeof(float))); LTX_TRY(te->adaf.ensure((size_t)2 * B * D * sizeof(float)));
         LTX_TRY(ltx_launch_sinusoid(m->tproj.p, dt, tv, m->inv_freq, 128, /*round_t=*/dt == LTX_DT_BF16, 1.0f, s));
         LTX_TRY(ltx_linear(m->te1, m->tproj.p, 256, m->e1.p, D, B, dt, EPI_BIAS, s));
@@ -345,29 +350,35 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
     // than copies (norm_fold_copies; the 40-step presets), the second-output form serves.  bf16 rounding moves from h (1 + sc) to W (1 + sc).
     bool wf = nfold && ltx_opt().norm_fold == 2 && !m->wfold_off;
     for (int i = 1; i < B; ++i) wf = wf && tv.t[i] == tv.t[0];
-    if (wf && !te->wfold_valid) {
-        const int cap = ltx_opt().norm_fold_copies > 0 ? ltx_opt().norm_fold_copies : 1;
-        int live = 0; DitTimeEntry* victim = nullptr;
-        for (auto& e : m->tcache) if (e.wfold_valid) { ++live; if (!victim || e.used < victim->used) victim = &e; }
-        if (live >= cap) {
-            if (m->tclock - victim->used < (uint64_t)4 * cap) {      // its owner ran a moment ago: the schedule cycles through more timesteps than copies
-                m->wfold_off = true; wf = false;
-                HIP_TRY(hipStreamSynchronize(s));               // (earlier forwards on this stream may still read the copies)
-                for (auto& e : m->tcache) { e.wfold.release(); e.wfold_valid = false; }
+    DitWfold* we = nullptr;
+    if (wf) {
+        for (auto& e : m->wcache) if (e.valid && e.t == tv.t[0] && e.stream == s) we = &e;
+        if (!we) {
+            const int cap = ltx_opt().norm_fold_copies > 0 ? ltx_opt().norm_fold_copies : 1;
+            int live = 0; DitWfold* victim = nullptr;
+            for (auto& e : m->wcache) if (e.valid) { ++live; if (!victim || e.used < victim->used) victim = &e; }
+            if (live >= cap) {
+                if (m->tclock - victim->used < (uint64_t)4 * cap) {      // its timestep ran a moment ago: the schedule cycles through more timesteps than copies
+                    m->wfold_off = true; wf = false;
+                    HIP_TRY(hipStreamSynchronize(s));               // (earlier forwards on this stream may still read the copies)
+                    for (auto& e : m->wcache) { e.w.release(); e.valid = false; }
+                } else { victim->valid = false; we = victim; }          // its buffer is re-used (same size)
             }
-            else { victim->wfold.release(); victim->wfold_valid = false; }
-        }
-        if (wf) {
-            const size_t per_layer = (size_t)7 * D * D * esz;
-            LTX_TRY(te->wfold.ensure((size_t)L * per_layer));
-            for (int l = 0; l < L; ++l) {
-                const float* ada = ada_all + (size_t)l * B * 6 * D;
-                char* wl = (char*)te->wfold.p + (size_t)l * per_layer;
-                LTX_TRY(ltx_launch_scale_cols(m->blocks[l].qkv1.w, ada + D, wl, 3 * D, D, dt, s));
-                LTX_TRY(ltx_launch_scale_cols(m->blocks[l].ff1.w, ada + 4 * D, wl + (size_t)3 * D * D * esz, 4 * D, D, dt, s));
+            if (wf) {
+                if (!we) { for (auto& e : m->wcache) if (!e.valid) { we = &e; break; } }
+                if (!we) { m->wcache.emplace_back(); we = &m->wcache.back(); }
+                const size_t per_layer = (size_t)7 * D * D * esz;
+                LTX_TRY(we->w.ensure((size_t)L * per_layer));
+                for (int l = 0; l < L; ++l) {
+                    const float* ada = ada_all + (size_t)l * B * 6 * D;
+                    char* wl = (char*)we->w.p + (size_t)l * per_layer;
+                    LTX_TRY(ltx_launch_scale_cols(m->blocks[l].qkv1.w, ada + D, wl, 3 * D, D, dt, s));
+                    LTX_TRY(ltx_launch_scale_cols(m->blocks[l].ff1.w, ada + 4 * D, wl + (size_t)3 * D * D * esz, 4 * D, D, dt, s));
+                }
+                we->t = tv.t[0]; we->stream = s; we->valid = true;
             }
-            te->wfold_valid = true;
         }
+        if (wf) we->used = m->tclock;
     }
 
     // Text context: caption projection (:186-190), mask bias (:1059-1070) and, for every layer, the cross-attention
@@ -471,7 +482,7 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
         if (presum && hsq_valid) { rn.presum = m->hsq.as<float>(); rn.presum_n = D / 128; }
         const bool fold1 = nfold && hsq_valid && (wf || hs_valid);      // the layer that wrote h left its row partials and h (.) (1 + scale_msa) in m->n (or the factor is in the weights): no pass
         const float* cfold_l = nfold ? te->cfold.as<float>() + (size_t)l * B * 7 * D : nullptr;
-        const char* wfold_l = wf ? (const char*)te->wfold.p + (size_t)l * 7 * D * D * esz : nullptr;
+        const char* wfold_l = wf ? (const char*)we->w.p + (size_t)l * 7 * D * D * esz : nullptr;
         if (!fold1) {
         take_pending(rn);
         LTX_TRY(ltx_launch_rownorm(rn, dt, s));
