@@ -368,14 +368,18 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
                 if (!we) { for (auto& e : m->wcache) if (!e.valid) { we = &e; break; } }
                 if (!we) { m->wcache.emplace_back(); we = &m->wcache.back(); }
                 const size_t per_layer = (size_t)7 * D * D * esz;
-                LTX_TRY(we->w.ensure((size_t)L * per_layer));
+                if (we->w.ensure((size_t)L * per_layer) != LTX_OK) {      // no room for another copy: the second-output form from here on (speed only)
+                    (void)hipGetLastError();
+                    m->wfold_off = true; wf = false; we = nullptr;
+                }
+                if (wf)
                 for (int l = 0; l < L; ++l) {
                     const float* ada = ada_all + (size_t)l * B * 6 * D;
                     char* wl = (char*)we->w.p + (size_t)l * per_layer;
                     LTX_TRY(ltx_launch_scale_cols(m->blocks[l].qkv1.w, ada + D, wl, 3 * D, D, dt, s));
                     LTX_TRY(ltx_launch_scale_cols(m->blocks[l].ff1.w, ada + 4 * D, wl + (size_t)3 * D * D * esz, 4 * D, D, dt, s));
                 }
-                we->t = tv.t[0]; we->stream = s; we->valid = true;
+                if (wf) { we->t = tv.t[0]; we->stream = s; we->valid = true; }
             }
         }
         if (wf) we->used = m->tclock;
