@@ -362,7 +362,10 @@ static int dit_forward_b8(ltx_dit* m, const void* hidden, const void* enc, const
                     m->wfold_off = true; wf = false;
                     HIP_TRY(hipStreamSynchronize(s));               // (earlier forwards on this stream may still read the copies)
                     for (auto& e : m->wcache) { e.w.release(); e.valid = false; }
-                } else { victim->valid = false; we = victim; }          // its buffer is re-used (same size)
+                } else {                                                // its buffer is re-used (same size)
+                    if (victim->stream != s) HIP_TRY(hipStreamSynchronize(victim->stream));      // (forwards on ITS stream may still read it)
+                    victim->valid = false; we = victim;
+                }
             }
             if (wf) {
                 if (!we) { for (auto& e : m->wcache) if (!e.valid) { we = &e; break; } }

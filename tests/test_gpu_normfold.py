@@ -110,6 +110,14 @@ def test_weights_form_with_rows_at_one_timestep_and_a_cycling_schedule(hip):
         ref = model.forward(*args(torch.tensor([128.0] * B))).float().cpu()
     assert torch.equal(outs[(2, 128.0)], ref)                  # given up by then: the second-output form
     assert torch.equal(outs[(1, 128.0)], outs[(2, 128.0)])
+    # a long-unused copy is evicted and its buffer re-used (no thrash: each timestep runs nine forwards before the next one arrives)
+    model2 = hip.LtxVideoTransformer3DModel(hip.LtxVideoTransformer3DModelConfig(**CFGD), {k: v.to(DEV) for k, v in w.items()}, torch.bfloat16)
+    with hip.options(norm_fold="2", norm_fold_copies="2"):
+        seq = {}
+        for tv in (896.0, 640.0, 384.0, 896.0):
+            for _ in range(9):
+                seq[tv] = model2.forward(*args(torch.tensor([tv] * B))).float().cpu()
+    assert torch.equal(seq[896.0], y2)                          # still the scaled-weight form, rebuilt after its eviction: same bits
 
 
 def test_guidance_rows_in_one_forward_keep_the_bits_of_separate_forwards(hip):
