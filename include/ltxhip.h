@@ -301,7 +301,8 @@ int ltx_plan_load(const char* path);
  *                          that writes the rows (a second output h (1 + scale)) and of the layer that reads them (row 1 / rms, per-timestep
  *                          vector).  Default 2: the (1 + scale) factor in a per-timestep COPY of the reading layer's weights instead of
  *                          the second output (1.6 GB per distinct timestep at 2B, cached like the modulation; rows at different
- *                          timesteps, or a schedule with more distinct timesteps than norm_fold_copies (10), use form 1)
+ *                          timesteps, or a schedule with more distinct timesteps than norm_fold_copies (10), use form 1; a handle that
+ *                          met such a schedule, or could not allocate a copy, frees its copies and stays on form 1)
  *   xattn_compact=0        cross attention multiplies every text key (differs from the default only for non-prefix masks)
  *   dense_qkv=0            q | k | v as column slices of one [M, 3D] matrix (same bits; another memory layout)
  *   vae_fuse_norm=0        the resnet's second norm as its own pass (1, default: fused where the conv's grid is about one round of
