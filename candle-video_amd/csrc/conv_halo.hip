@@ -108,6 +108,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
     // (round 5, measured and left out: frames fastest inside a run - one patch position in 32 consecutive frames at a time, so that
     // a frame's patch is fetched once for the three output frames that read it - moved 8 % fewer bytes past the L2s and not a
     // microsecond: profiles/r5a_conv_tile_order_ab.json)
+#ifdef HALO_SAME_TILE    // timing experiment (wrong results; tools/conv_trace.py build hot -DHALO_SAME_TILE): every block stages ONE tile's operands, so
+    bid = bid % ntn;    // its prologue, halo prefetches and residual rows are served by the L2s (docs/lab_notes.md R6.8)
+#endif
     const int nt = bid % ntn; int rr = bid / ntn;
     const int px = rr % pwn; rr /= pwn;
     const int py = rr % phn; const int bt = rr / phn;

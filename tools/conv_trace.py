@@ -9,16 +9,18 @@ PKG = os.path.join(ROOT, "candle-video_amd"); VAR = os.path.join(ROOT, "tools", 
 
 
 def build():
+    """build [NAME -D...]: extra defines make a second traced library (tools/variants/libltxhip_halotrace_NAME.so; LTXHIP_LIB selects it for `run`)"""
     os.makedirs(VAR, exist_ok=True)
     bdir = os.path.join(PKG, "build", "var"); os.makedirs(bdir, exist_ok=True)
-    obj = os.path.join(bdir, "conv_halo_trace.o")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DHALO_TRACE=1", "-x", "hip", "-c",
+    tag = "_" + sys.argv[2] if len(sys.argv) > 2 else ""
+    obj = os.path.join(bdir, f"conv_halo_trace{tag}.o")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DHALO_TRACE=1"] + sys.argv[3:] + ["-x", "hip", "-c",
                     os.path.join(PKG, "csrc", "conv_halo.hip"), "-o", obj], check=True)
     objs = []
     for sub in ("csrc", "host"):
         d = os.path.join(PKG, "build", sub)
         objs += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".o") and not f.startswith("conv_halo")]
-    out = os.path.join(VAR, "libltxhip_halotrace.so")
+    out = os.path.join(VAR, f"libltxhip_halotrace{tag}.so")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [obj, "-lz", "-ldl"], check=True)
     print("built", out)
 
