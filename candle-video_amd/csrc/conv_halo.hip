@@ -384,12 +384,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
                 if ((HALO_ABL & 2) && f > 0) { wf[f].u = wf[0].u + (u32x4){(uint32_t)f, 0u, 0u, 0u}; continue; }
                 wf[f].u = *reinterpret_cast<const u32x4*>(Bs + swz_h(wn * WN + f * 16 + frow, kb * 4 + fq));
             }
-            af[0].u = *reinterpret_cast<const u32x4*>(As + rowbase[0] + colpart[iw][kb] + ih * HW * ROWB);
+            // (the six column terms are recomputed where they are used: kept in registers across the nine steps they were spilled -
+            // 256 registers at two waves per SIMD - and reloaded from scratch in front of their step's first fragment read)
+            int fr_ = frow; asm volatile("" : "+v"(fr_));
+            const int cp = BN == 256 ? iw * ROWB + (((kb * 4 + fq) ^ (((fr_ + iw) >> 1) & 7)) << 4) : colpart[iw][kb];
+            af[0].u = *reinterpret_cast<const u32x4*>(As + rowbase[0] + cp + ih * HW * ROWB);
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
                 if ((HALO_ABL & 1) && fm + 1 < FM) af[fm + 1].u = af[0].u + (u32x4){(uint32_t)fm, 0u, 0u, 0u};
                 else
-                if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + rowbase[fm + 1] + colpart[iw][kb] + ih * HW * ROWB);
+                if (fm + 1 < FM) af[fm + 1].u = *reinterpret_cast<const u32x4*>(As + rowbase[fm + 1] + cp + ih * HW * ROWB);
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = Mma<bf16_t>::run(wf[fn], af[fm], acc[fm][fn]);
             }
