@@ -201,6 +201,21 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         nt = w / rows; mt = gm0 + (w - nt * rows);
     } else { mt = bid / ntn; nt = bid - mt * ntn; }
     const int m0 = mt * BM, n0 = nt * BN;
+    // (norm fold: the tile rows' partial sums of squares are requested first thing - see in front of the K loop)
+    static_assert(!FOLD || BM <= 256 || BM == 320, "norm fold: 64 extra rows = 256 (row, group) units");
+    f32x4 fpt[4], fpx = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) {
+        auto group_of = [&](int row, int q4) {
+            const int m = m0 + row < g.M ? m0 + row : g.M - 1;
+            const bool in = 4 * q4 < g.rs_n;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(g.rs_sq + (int64_t)m * g.rs_n + (in ? 4 * q4 : g.rs_n - 4));
+            return in ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        const int row = tid < BM ? tid : BM - 1;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) fpt[q4] = group_of(row, q4);
+        if constexpr (BM > 256) fpx = group_of(256 + (tid >> 2), tid & 3);
+    }
     const int lr = lane >> 3, pc = lane & 7;
     u32x16 dma0; u32x2 dma1 = {0x80000000u, 0x80000000u};    // source offsets of the wave's AI + BI (<= 18) pieces of a K-step
 #pragma unroll
@@ -265,25 +280,35 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         pf_voff[1] = n0 + 4 * cg_pf + 128 < g.N ? row0 + (uint32_t)(8 * cg_pf + 256) : 0x80000000u;
         pf_stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)g.ldr * 2u));
     }
-    // Norm fold, consumer side: the tile rows' partial sums of squares (written by the previous launch, on other XCDs: a trip past the
-    // L2) are requested HERE, in front of the K loop - read right after it they cost the block 3 - 5 us of exposed latency per tile
-    // (kernel trace: qkv 98.5 -> 109.2 us, ff1 133.7 -> 143.9).  One row per thread (rows 256 .. BM - 1: the first threads again);
-    // at most 16 partials per row (D <= 2048), groups past rs_n re-read the last one and are zeroed - no branch around a load.
-    // Rows 256 .. BM - 1 of the 320-row tile: four lanes per row, one group of four partials each (20 registers across the loop
-    // instead of 32, which spilled); the ascending sum then runs through the four lanes in turn.
-    static_assert(!FOLD || BM <= 256 || BM == 320, "norm fold: 64 extra rows = 256 (row, group) units");
-    f32x4 fpt[4], fpx = {0.f, 0.f, 0.f, 0.f};
+    // Norm fold, consumer side: the tile rows' partial sums of squares were written by the previous launch on other XCDs (a trip past
+    // the L2).  Read after the K loop they cost the block 3 - 5 us of exposed latency per tile (kernel trace: qkv 98.5 -> 109.2 us,
+    // ff1 133.7 -> 143.9); requested in front of the loop and summed behind it they held 20 registers across it - three more than the
+    // 320-row tile has, spilled and reloaded at the top of the epilogue.  Now: requested first thing in the kernel (above), summed
+    // HERE - their latency ran under the set-up - and the rows' 1 / rms parked in the LDS behind the two stages, which the K loop
+    // never touches (the epilogue's first barrier publishes it): nothing of the fold lives across the loop.  One row per thread, at
+    // most 16 partials per row (D <= 2048), groups past rs_n re-read the last one and are zeroed - no branch around a load; rows
+    // 256 .. BM - 1 of the 320-row tile: four lanes per row, one group of four partials each, the ascending sum (the expression of
+    // rownorm_presum_kernel) then runs through the four lanes in turn.
     if constexpr (FOLD) {
-        auto group_of = [&](int row, int q4) {
-            const int m = m0 + row < g.M ? m0 + row : g.M - 1;
-            const bool in = 4 * q4 < g.rs_n;
-            const f32x4 u = *reinterpret_cast<const f32x4*>(g.rs_sq + (int64_t)m * g.rs_n + (in ? 4 * q4 : g.rs_n - 4));
-            return in ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
-        };
-        const int row = tid < BM ? tid : BM - 1;
+        // (the compiler otherwise sums right behind the loads and waits for them in front of the set-up)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(fpt[0]), "+v"(fpt[1]), "+v"(fpt[2]), "+v"(fpt[3]), "+v"(fpx), "+v"(dma0), "+v"(dma1), "+v"(rbase));   // (the set-up's results: it stays in front)
+        float* rl = reinterpret_cast<float*>(asm_smem + 2 * STAGE);
+        if (tid < BM) {
+            float ss = 0.f;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) fpt[q4] = group_of(row, q4);
-        if constexpr (BM > 256) fpx = group_of(256 + (tid >> 2), tid & 3);
+            for (int q4 = 0; q4 < 4; ++q4) { ss += fpt[q4][0]; ss += fpt[q4][1]; ss += fpt[q4][2]; ss += fpt[q4][3]; }
+            rl[tid] = 1.0f / sqrtf(ss * (1.0f / (float)g.rs_D) + g.rs_eps);
+        }
+        if constexpr (BM > 256) {                          // lanes 4 i .. 4 i + 3 hold groups 0 .. 3 of row 256 + tid / 4: the same ascending chain
+            float run = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float before = q4 ? __shfl(run, (lane & ~3) + q4 - 1) : 0.f;
+                if ((tid & 3) == q4) { run = before; run += fpx[0]; run += fpx[1]; run += fpx[2]; run += fpx[3]; }
+            }
+            if ((tid & 3) == 3) rl[256 + (tid >> 2)] = 1.0f / sqrtf(run * (1.0f / (float)g.rs_D) + g.rs_eps);
+        }
     }
 #ifdef ASM16_STAGGER      // experiment (with a stagger=1 loop): block-dependent start position in K, wrapping at the end
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((unsigned)blockIdx.x % ASM16_STAGGER) * (unsigned)(nk / ASM16_STAGGER) * 128u));
@@ -321,25 +346,6 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
         float bA[4] = {0.f, 0.f, 0.f, 0.f}, bB[4] = {0.f, 0.f, 0.f, 0.f};
         static_assert(!FOLD || EPI == EPI_BIAS || EPI == EPI_GELU, "norm fold, consumer side: bias / GELU epilogues");
         if constexpr (FOLD) {
-            // 1 / rms of the tile's rows from the partials requested in front of the K loop (ascending order, the expression of
-            // rownorm_presum_kernel), one thread per row, into the LDS behind the two stages (the K loop never touches it; the
-            // first barrier below publishes it)
-            float* rl = reinterpret_cast<float*>(asm_smem + 2 * STAGE);
-            if (tid < BM) {
-                float ss = 0.f;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) { ss += fpt[q4][0]; ss += fpt[q4][1]; ss += fpt[q4][2]; ss += fpt[q4][3]; }
-                rl[tid] = 1.0f / sqrtf(ss * (1.0f / (float)g.rs_D) + g.rs_eps);
-            }
-            if constexpr (BM > 256) {                          // lanes 4 i .. 4 i + 3 hold groups 0 .. 3 of row 256 + tid / 4: the same ascending chain
-                float run = 0.f;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float before = q4 ? __shfl(run, (lane & ~3) + q4 - 1) : 0.f;
-                    if ((tid & 3) == q4) { run = before; run += fpx[0]; run += fpx[1]; run += fpx[2]; run += fpx[3]; }
-                }
-                if ((tid & 3) == 3) rl[256 + (tid >> 2)] = 1.0f / sqrtf(run * (1.0f / (float)g.rs_D) + g.rs_eps);
-            }
             const float* cp = g.cvec + (int64_t)(m0 / g.rows_per_batch) * g.cvec_stride;
             const f32x4 cA4 = *reinterpret_cast<const f32x4*>(cp + nA), cB4 = *reinterpret_cast<const f32x4*>(cp + nB);
 #pragma unroll
