@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
             // are computed on clamped addresses and not stored - no branch in front of a load)
             constexpr int UN = RP % 32 == 0 ? 4 : 5;
             static_assert((RP / 8) % UN == 0, "row steps");
-#pragma unroll (PF_R ? RP / 8 / UN : 1)
+#pragma unroll (PF_R ? RP / 8 / UN : 1)       // (round 6, measured: unrolled everywhere q2 -0.25 us, qkv +0.3, ff1's GELU rows +3 us)
             for (int k0 = 0; k0 < RP / 8; k0 += UN) {
                 f32x4 vA[UN], vB[UN];
                 bf16x4 qA[UN] = {}, qB[UN] = {};

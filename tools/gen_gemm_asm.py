@@ -711,11 +711,12 @@ def main():
             f.write("\n")
             f.write(store_functions16(name.replace("x", "_"), BM, BN, WGM, WGN))
             f.write("\n")
-            if name == "256x256" and not int(o16.get("trace", 0)):
-                f.write(c_function16_conv(name.replace("x", "_"), BM, BN, WGM, WGN, o16))
+            plain = {k: v for k, v in o16.items() if k != "trace"}     # (trace builds: these two flavours are emitted without stamps)
+            if name == "256x256":
+                f.write(c_function16_conv(name.replace("x", "_"), BM, BN, WGM, WGN, plain))
                 f.write("\n")
-            if name == "160x256" and not int(o16.get("trace", 0)):
-                f.write(c_function16(name.replace("x", "_"), BM, BN, WGM, WGN, dict(o16, res_rows=20)))
+            if name == "160x256":
+                f.write(c_function16(name.replace("x", "_"), BM, BN, WGM, WGN, dict(plain, res_rows=20)))
                 f.write("\n")
     print("wrote", out, opt)
 
