@@ -90,6 +90,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
     unsigned char* Abuf = halo_smem;
     unsigned char* Bbuf = halo_smem + 2 * A_ST;
     HSTAMP(0);
+    // the kernel arguments of the tile set-up requested together (left to the compiler: the geometry first, the operand pointers
+    // 450 instructions later behind a second scalar-cache miss, in front of the first LDS-DMA piece; gemm_asm.hip)
+#ifndef HALO_NO_KERNARG_BATCH
+    asm volatile("" :: "s"(g.A), "s"(g.W), "s"(g.C), "s"(g.bias), "s"(g.resid), "s"(g.N), "s"(g.K), "s"(g.Cin), "s"(g.T), "s"(g.H), "s"(g.Wd), "s"(g.ntaps), "s"(g.pad_t),
+                 "s"(g.ldc), "s"(g.ldr), "s"(gridDim.x));
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;

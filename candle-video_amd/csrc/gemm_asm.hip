@@ -184,6 +184,11 @@ __global__ __launch_bounds__(256, 1) void gemm_asm16_kernel(const GemmArgs g) {
 #ifdef GEMM_ASM_TRACE
     const uint32_t t_entry = (uint32_t)wall_clock64();
 #endif
+    // every kernel argument the set-up reads, requested together: left to the compiler they arrive in three dependent batches (one per
+    // branch of the tile mapping), each a scalar-cache miss of a block that has nothing else to do yet
+#ifndef ASM16_NO_KERNARG_BATCH
+    asm volatile("" :: "s"(g.A), "s"(g.W), "s"(g.M), "s"(g.N), "s"(g.K), "s"(g.lda), "s"(g.xcd_remap), "s"(g.group_m), "s"(g.rows_per_batch), "s"(gridDim.x));
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, q = lane >> 4;
     const int wm = wave / WGN, wn = wave % WGN;
