@@ -52,6 +52,12 @@ template <int BM, int BN, int NS, int EPI, bool SPEC, bool CONV = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_ring_kernel(const GemmArgs g) {
     static_assert(!CONV || SPEC, "conv mode: the stage bookkeeping lives in the producer waves");
     RSTAMP(0);
+    // the kernel arguments of the set-up requested together (the compiler's order: geometry, K partition, then - 400 instructions later,
+    // in front of the first LDS-DMA piece - the operand pointers, each batch a scalar-cache miss of a 15-us launch; gemm_asm.hip)
+#ifndef RING_NO_KERNARG_BATCH
+    asm volatile("" :: "s"(g.A), "s"(g.W), "s"(g.Wp), "s"(g.C), "s"(g.bias), "s"(g.M), "s"(g.N), "s"(g.K), "s"(g.lda), "s"(g.ldc), "s"(g.sk_sf), "s"(g.sk_ws), "s"(g.sk_cnt),
+                 "s"(g.defer_parts), "s"(gridDim.x));
+#endif
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16, NM = FM * FN;
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int PA = BM / 32, PW = BN / 32, P = PA + PW;      // LDS-DMA pieces per issuing wave per stage (activation, weight)
