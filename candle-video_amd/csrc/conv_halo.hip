@@ -82,11 +82,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_kernel(const GemmArg
     constexpr int NTHR = NW * 64;
     // loader waves: the first wave of every SIMD issues all LDS-DMA pieces, its partner (wave + 4) starts on its MFMAs at
     // once (see gemm_big.hip)
-    constexpr int NL = (HALO_LOADERS == 4 && BN == 128) ? 4 : NW;      // measured: +3..9 % at BN = 128, -4 % at BN = 256
+    constexpr int NL = (HALO_LOADERS == 4 && (BN == 128 || (BN == 64 && PIPE))) ? 4 : NW;      // measured: +3..9 % at BN = 128, -4 % at BN = 256
     constexpr int AJ = (A_PIECES + NL - 1) / NL, BJ = BN / (8 * NL);
     constexpr int B_STAGE = BN * ROWB;
     constexpr int A_ST = PIPE ? AJ * NL * 1024 : A_STAGE;       // PIPE: padded to whole piece rounds (dummy pieces land in the padding)
-    static_assert(!PIPE || (NL == 4 && BN == 128), "pipelined form: four loader waves, 128-wide tile");
+    static_assert(!PIPE || (NL == 4 && (BN == 128 || BN == 64)), "pipelined form: four loader waves, 128-wide tile (or conv_out's 64-wide one)");
     unsigned char* Abuf = halo_smem;
     unsigned char* Bbuf = halo_smem + 2 * A_ST;
     HSTAMP(0);
@@ -675,7 +675,11 @@ bool ltx_conv_halo_eligible(const GemmArgs& g, int epi, int bn) {
 int ltx_launch_conv_halo(const GemmArgs& g, int epi, int bn, hipStream_t s) {
     ltx_prof_kernel(LTX_PROFK_CONV_HALO);
     if (!ltx_conv_halo_eligible(g, epi, bn)) LTX_FAIL(LTX_ERR_ARG, "conv_halo: shape not eligible");
-    if (bn == 64) return launch_halo<64, 8, 1, EPI_UNPATCH, false>(g, s);      // conv_out: eight waves of 32 x 64
+#ifdef HALO_CONV_OUT_PLAIN
+    if (bn == 64) return launch_halo<64, 8, 1, EPI_UNPATCH, false>(g, s);      // conv_out: eight waves of 32 x 64, barrier-per-step form
+#else
+    if (bn == 64) return launch_halo<64, 8, 1, EPI_UNPATCH, true>(g, s);       // conv_out: eight waves of 32 x 64, pipelined form
+#endif
     if (bn == 256) return launch_halo_epi<256, 2, 4>(g, epi, s);
 #if HALO_LOADERS == 4
 #ifdef LTX_EXPERIMENTS     // x_conv_halo_pipe=0: the barrier-per-step form; x_conv_halo_w4=1: one wave per SIMD (four waves of 128 x 64; round 4: -3 %)
